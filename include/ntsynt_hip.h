@@ -1,0 +1,175 @@
+/*
+ * ntsynt_hip.h -- C ABI of libntsynt_hip.so: the MI355X (gfx950) implementation of ntSynt's
+ * hot path (canonical-ntHash minimizer sketch + common-k-mer Bloom filter + minimizer-graph
+ * chaining).  Plain pointers and sizes only; no exceptions cross this boundary.
+ *
+ * The reference has no in-process FFI for this path: its boundary is CLI + files
+ * (SURVEY.md 8(b)).  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference tree); INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions: every call returns 0 on success or a negative code (NTS_E*); the message is
+ * retrievable with nts_last_error(ctx) (ctx == NULL: the message of a failed nts_init).
+ * Handles are opaque.  One nts_ctx per GPU (owns one HIP stream); a ctx is not thread-safe.
+ * Buffers returned through `T**` out-parameters are allocated by the library on the host and
+ * released with nts_free().
+ */
+#ifndef NTSYNT_HIP_H
+#define NTSYNT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTS_OK 0
+#define NTS_EINVAL (-22)
+#define NTS_ENOMEM (-12)
+#define NTS_EHIP (-5)
+#define NTS_ERANGE (-34)
+
+typedef struct nts_ctx nts_ctx;
+typedef struct nts_genome nts_genome; /* one FASTA resident in HBM */
+typedef struct nts_bf nts_bf;         /* Bloom bit array resident in HBM */
+typedef struct nts_mx nts_mx;         /* minimizer list resident in HBM */
+
+/* hard-mask interval [start, end) in record coordinates (bedtools maskfasta semantics) */
+typedef struct
+{
+  uint32_t rec;
+  uint64_t start;
+  uint64_t end;
+} nts_interval;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int nts_init(int device, nts_ctx** out);
+void nts_destroy(nts_ctx* ctx);
+const char* nts_last_error(nts_ctx* ctx);
+int nts_sync(nts_ctx* ctx);
+/* HIP stream of the context (hipStream_t as void*), for callers that enqueue their own work */
+void* nts_stream(nts_ctx* ctx);
+
+/* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg).
+ * nts_profile(ctx,1) resets and enables; nts_timing() reports total ms and launch count of the
+ * kernel called `name` since then ("hash_probe", "window_min", "bf_insert", ...). */
+int nts_profile(nts_ctx* ctx, int enable);
+int nts_timing(nts_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
+
+/* ---- A1: Bloom filter sizing ----------------------------------------------------------------
+ * replaces approximate_bf_size(), src/ntsynt_make_common_bf.cpp:28-40, and the byte rounding of
+ * the btllib::KmerBloomFilter constructor used at :122-123.  approx_bytes = ceil(-n/ln(1-fpr))/8
+ * (truncating), ctor_bytes = approx_bytes rounded up to a multiple of 8. */
+int nts_bf_size_bytes(uint64_t genome_bp, double fpr, uint64_t* approx_bytes, uint64_t* ctor_bytes);
+
+/* ---- genome ---------------------------------------------------------------------------------
+ * replaces btllib::SeqReader(path, LONG_MODE) record streaming (src/...cpp:32-36,125-131).
+ * `seq` = the records' bases concatenated (ASCII, any case, no separators); record r occupies
+ * [rec_off[r], rec_off[r]+rec_len[r]).  Copied to HBM once. */
+int nts_genome_upload(nts_ctx* ctx,
+                      const uint8_t* seq,
+                      uint64_t n,
+                      const uint64_t* rec_off,
+                      const uint64_t* rec_len,
+                      uint32_t n_rec,
+                      nts_genome** out);
+void nts_genome_free(nts_ctx* ctx, nts_genome* g);
+/* total bases (sum of record lengths, what approximate_bf_size() counts) */
+uint64_t nts_genome_bases(const nts_genome* g);
+/* number of k-mers made only of A/C/G/T(U), i.e. the k-mers NtHash::roll() visits */
+int nts_genome_valid_kmers(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t* n_valid);
+
+/* ---- A2-A4: Bloom filter ----------------------------------------------------------------------
+ * nts_bf_create     : btllib::KmerBloomFilter(bytes, 1, k), cpp:122-123,136-137 (bytes = ctor_bytes)
+ * nts_bf_insert     : bf->insert(record.seq) over all records, cpp:128-131  (level-1 filter)
+ * nts_bf_cascade    : `if (bf->contains(h)) new_bf->insert(h)`, cpp:145-153 (literal cascade level)
+ * nts_bf_and        : acc &= other -- with one hash function the cascade equals the AND of the
+ *                     per-genome filters; this is the form the multi-GPU path reduces
+ * nts_bf_popcount   : numerator of bf->get_fpr(), cpp:132,154,162
+ * nts_bf_download / nts_bf_upload : raw bit array for bf->save()/load (cpp:164; smk:76) */
+int nts_bf_create(nts_ctx* ctx, uint64_t bytes, nts_bf** out);
+void nts_bf_free(nts_ctx* ctx, nts_bf* bf);
+uint64_t nts_bf_bytes(const nts_bf* bf);
+void* nts_bf_device_ptr(nts_bf* bf);
+int nts_bf_clear(nts_ctx* ctx, nts_bf* bf);
+int nts_bf_insert(nts_ctx* ctx, nts_bf* bf, const nts_genome* g, uint32_t k);
+int nts_bf_cascade(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nts_genome* g, uint32_t k);
+int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other);
+int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set);
+int nts_bf_download(nts_ctx* ctx, const nts_bf* bf, uint8_t* host, uint64_t bytes);
+int nts_bf_upload(nts_ctx* ctx, nts_bf* bf, const uint8_t* host, uint64_t bytes);
+
+/* ---- B1-B3, B5: minimizer sketch -----------------------------------------------------------------
+ * replaces `indexlr -k K -w W --long --pos -s common.bf genome.fa` (smk:81-85) and the re-sketch of
+ * hard-masked assemblies in the refinement rounds (bin/ntsynt_synteny.py:134-157,167-192): the mask
+ * intervals are applied to the resident sequence instead of writing masked FASTA files.
+ * Result: minimizers in (record, position) order; h1 = the hash indexlr prints. */
+int nts_sketch(nts_ctx* ctx,
+               const nts_genome* g,
+               uint32_t k,
+               uint32_t w,
+               const nts_bf* filter_or_null,
+               const nts_interval* mask,
+               uint64_t n_mask,
+               nts_mx** out);
+uint64_t nts_mx_count(const nts_mx* mx);
+void nts_mx_free(nts_ctx* ctx, nts_mx* mx);
+/* copy a minimizer list to caller-provided host arrays of nts_mx_count() elements */
+int nts_mx_download(nts_ctx* ctx, const nts_mx* mx, uint64_t* h1, uint32_t* rec, uint64_t* pos);
+/* device pointers (for an all-gather over RCCL): arrays of nts_mx_count() elements */
+int nts_mx_device_ptrs(const nts_mx* mx, void** h1, void** rec, void** pos);
+/* build a device list from host arrays (receiving side of the all-gather, tests) */
+int nts_mx_upload(nts_ctx* ctx,
+                  const uint64_t* h1,
+                  const uint32_t* rec,
+                  const uint64_t* pos,
+                  uint64_t n,
+                  nts_mx** out);
+
+/* test/bench hook: canonical h0 of every valid k-mer in (record, position) order (row B1) */
+int nts_hash_all(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t** h0, uint64_t* n_out);
+
+/* ---- C1-C5: minimizer graph -> collinear chains -----------------------------------------------------
+ * replaces ntjoin_utils.read_minimizers' duplicate removal, filter_minimizers, build_graph, and the
+ * edge-weight filter + path finding (call sites bin/ntsynt_synteny.py:607-620, 483-492).
+ * Input: G device lists in the reference's assembly order (descending file name).
+ * nts_graph_build computes, on the GPU:
+ *   - per assembly, hashes seen once (C1), intersected over assemblies (C2a);
+ *   - the undirected adjacency edges of the filtered lists with their weights (C2b).
+ * Output (host, library-allocated): the filtered lists and the distinct edges, enough for the host
+ * to apply the rare order-dependent rules (C3) exactly and then walk the weight-G chains (C4, C5).
+ *   v_hash[nv]           common hashes, ascending
+ *   occ_rec/occ_pos[G*nv] record and position of vertex v in assembly a at [a*nv+v]
+ *   list_v / list_off    per assembly, per surviving record list: vertex ids in list order;
+ *                        list a,l spans list_v[list_off[i] .. list_off[i+1]) with i enumerated
+ *                        assembly-major (n_lists[a] lists each)
+ *   e_u/e_v/e_w/e_first  distinct edges: endpoints (vertex ids, orientation of first sighting),
+ *                        weight, and the sequence number of the first sighting in the reference's
+ *                        traversal order (assembly, list, index)
+ */
+typedef struct
+{
+  uint64_t nv;
+  uint64_t* v_hash;
+  uint32_t* occ_rec;
+  uint64_t* occ_pos;
+  uint32_t n_asm;
+  uint64_t* n_lists;   /* [n_asm] */
+  uint64_t n_list_total;
+  uint64_t* list_off;  /* [n_list_total+1] */
+  uint32_t* list_v;    /* [list_off[n_list_total]] */
+  uint64_t ne;
+  uint32_t* e_u;
+  uint32_t* e_v;
+  uint32_t* e_w;
+  uint64_t* e_first;
+} nts_graph;
+int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, nts_mx* const* lists, nts_graph* out);
+void nts_graph_free(nts_graph* g);
+
+void nts_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

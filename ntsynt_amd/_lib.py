@@ -1,0 +1,97 @@
+"""ctypes binding of libntsynt_hip.so (C ABI: include/ntsynt_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be loaded this
+module raises, loudly."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libntsynt_hip.so")
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_vp = ctypes.c_void_p
+u32, u64 = ctypes.c_uint32, ctypes.c_uint64
+
+
+class Interval(ctypes.Structure):
+    _fields_ = [("rec", u32), ("start", u64), ("end", u64)]
+
+
+class Graph(ctypes.Structure):
+    _fields_ = [("nv", u64), ("v_hash", c_u64p), ("occ_rec", c_u32p), ("occ_pos", c_u64p),
+                ("n_asm", u32), ("n_lists", c_u64p), ("n_list_total", u64), ("list_off", c_u64p),
+                ("list_v", c_u32p), ("ne", u64), ("e_u", c_u32p), ("e_v", c_u32p), ("e_w", c_u32p),
+                ("e_first", c_u64p)]
+
+
+# every symbol include/ntsynt_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("nts_init", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_vp)]),
+    ("nts_destroy", None, [c_vp]),
+    ("nts_last_error", ctypes.c_char_p, [c_vp]),
+    ("nts_sync", ctypes.c_int, [c_vp]),
+    ("nts_stream", c_vp, [c_vp]),
+    ("nts_profile", ctypes.c_int, [c_vp, ctypes.c_int]),
+    ("nts_timing", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), c_u64p]),
+    ("nts_bf_size_bytes", ctypes.c_int, [u64, ctypes.c_double, c_u64p, c_u64p]),
+    ("nts_genome_upload", ctypes.c_int, [c_vp, c_vp, u64, c_u64p, c_u64p, u32, ctypes.POINTER(c_vp)]),
+    ("nts_genome_free", None, [c_vp, c_vp]),
+    ("nts_genome_bases", u64, [c_vp]),
+    ("nts_genome_valid_kmers", ctypes.c_int, [c_vp, c_vp, u32, c_u64p]),
+    ("nts_bf_create", ctypes.c_int, [c_vp, u64, ctypes.POINTER(c_vp)]),
+    ("nts_bf_free", None, [c_vp, c_vp]),
+    ("nts_bf_bytes", u64, [c_vp]),
+    ("nts_bf_device_ptr", c_vp, [c_vp]),
+    ("nts_bf_clear", ctypes.c_int, [c_vp, c_vp]),
+    ("nts_bf_insert", ctypes.c_int, [c_vp, c_vp, c_vp, u32]),
+    ("nts_bf_cascade", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, u32]),
+    ("nts_bf_and", ctypes.c_int, [c_vp, c_vp, c_vp]),
+    ("nts_bf_popcount", ctypes.c_int, [c_vp, c_vp, c_u64p]),
+    ("nts_bf_download", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
+    ("nts_bf_upload", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
+    ("nts_sketch", ctypes.c_int, [c_vp, c_vp, u32, u32, c_vp, ctypes.POINTER(Interval), u64,
+                                  ctypes.POINTER(c_vp)]),
+    ("nts_mx_count", u64, [c_vp]),
+    ("nts_mx_free", None, [c_vp, c_vp]),
+    ("nts_mx_download", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("nts_mx_device_ptrs", ctypes.c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                                          ctypes.POINTER(c_vp)]),
+    ("nts_mx_upload", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, u64, ctypes.POINTER(c_vp)]),
+    ("nts_hash_all", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_u64p), c_u64p]),
+    ("nts_graph_build", ctypes.c_int, [c_vp, u32, ctypes.POINTER(c_vp), ctypes.POINTER(Graph)]),
+    ("nts_graph_free", None, [ctypes.POINTER(Graph)]),
+    ("nts_free", None, [c_vp]),
+]
+
+
+def build(force=False):
+    """Compile libntsynt_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        args.append("-B")
+    subprocess.run(args, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is required (there is no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C ntsynt_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)       # AttributeError if the ABI and the header drift apart
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

@@ -1,0 +1,74 @@
+// Device-side arithmetic shared by the kernels: canonical ntHash2,
+// Bloom bit addressing (A2), exact 64-bit modulo by a runtime divisor.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nts {
+
+constexpr uint64_t SEED_A = 0x3c8bfbb395c60474ULL;
+constexpr uint64_t SEED_C = 0x3193c18562a02b4cULL;
+constexpr uint64_t SEED_G = 0x20323ed082572324ULL;
+constexpr uint64_t SEED_T = 0x295549f54be24456ULL;
+constexpr uint64_t MULTISEED = 0x90b45d39fb6da1faULL;
+constexpr uint64_t KEY_MAX = 0xFFFFFFFFFFFFFFFFULL;
+constexpr uint8_t CODE_INVALID = 4;
+
+// split rotate left by one: bits 0..32 form a 33-bit ring, bits 33..63 a 31-bit ring
+__host__ __device__ __forceinline__ uint64_t srol1(uint64_t x)
+{
+  const uint64_t m = ((x & 0x8000000000000000ULL) >> 30) | ((x & 0x100000000ULL) >> 32);
+  return ((x << 1) & 0xFFFFFFFDFFFFFFFFULL) | m;
+}
+
+__host__ __device__ __forceinline__ uint64_t sror1(uint64_t x)
+{
+  const uint64_t m = ((x & 0x200000000ULL) << 30) | ((x & 1ULL) << 32);
+  return ((x >> 1) & 0xFFFFFFFEFFFFFFFFULL) | m;
+}
+
+__host__ __device__ __forceinline__ uint64_t extend_h1(uint64_t h0, uint32_t k)
+{
+  uint64_t t = h0 * (1ULL ^ ((uint64_t)k * MULTISEED));
+  t ^= t >> 27;
+  return t;
+}
+
+// Kernel-argument block for the hashing kernels.
+//   roll_f[cin*4+cout] = seed[cin] ^ srol^k(seed[cout])             (forward strand update)
+//   roll_r[cin*4+cout] = srol^k(seed[3-cin]) ^ seed[3-cout]         (reverse strand update)
+struct HashParams
+{
+  uint64_t seed[4];
+  uint64_t roll_f[16];
+  uint64_t roll_r[16];
+  uint32_t k;
+};
+
+// Exact h % m for a runtime m: q = mulhi(h, floor(2^64/m)) is floor(h/m) or one less.
+struct FastMod
+{
+  uint64_t m;
+  uint64_t inv; // floor(2^64 / m)   (m >= 2)
+  __device__ __forceinline__ uint64_t operator()(uint64_t h) const
+  {
+    const uint64_t q = __umul64hi(h, inv);
+    uint64_t r = h - q * m;
+    if (r >= m) r -= m;
+    return r;
+  }
+};
+
+// Bloom bit `idx` lives in byte idx/8 at bit idx%8 (LSB first) == bit idx%32 of little-endian
+// 32-bit word idx/32.
+__device__ __forceinline__ bool bf_test(const uint32_t* __restrict__ words, uint64_t idx)
+{
+  return (words[idx >> 5] >> (idx & 31)) & 1u;
+}
+
+__device__ __forceinline__ void bf_set(uint32_t* words, uint64_t idx)
+{
+  atomicOr(&words[idx >> 5], 1u << (idx & 31));
+}
+
+} // namespace nts

@@ -1,0 +1,1252 @@
+// libntsynt_hip.so -- MI355X (gfx950) implementation of ntSynt's hot path behind the C ABI of
+// include/ntsynt_hip.h.  HIP kernels for: sequence encoding + valid-stretch detection, canonical
+// ntHash2 rolling hash with Bloom insert / probe, window-of-w rightmost-argmin over valid k-mers,
+// Bloom AND / popcount, and the minimizer-graph join.  No MFMA: integer ALU + LDS + HBM.
+//
+// Data layout in HBM (DESIGN.md "Data layout"):
+//   genome   : one byte per base, code 0..3 = A,C,G,T(U) (case-insensitive), 4 = anything else;
+//              records concatenated, PAD invalid bytes in front and behind.
+//   runs     : maximal intervals of consecutive valid k-mer starts ("run table"): run_pos[i] =
+//              offset of the first k-mer, run_vstart[i] = its index in the compact (valid-k-mer)
+//              numbering.  Windows are defined over that compact numbering.
+//   keys     : one u64 per valid k-mer: h0, or KEY_MAX when the common Bloom filter rejects it.
+//   bloom    : bit idx = h0 % bits at byte idx/8, bit idx%8 (LSB first).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/ntsynt_hip.h"
+#include "nts_device.h"
+
+using namespace nts;
+
+namespace {
+
+constexpr uint64_t PAD = 256;          // invalid bytes before and after the sequence
+constexpr int HASH_THREADS = 256;
+constexpr int HASH_PER_THREAD = 32;    // consecutive k-mers rolled by one lane
+constexpr int WIN_THREADS = 256;
+constexpr uint32_t WIN_TILE = 4096;    // windows per workgroup
+constexpr uint32_t WIN_CHUNK = 16;     // elements scanned sequentially by one lane
+constexpr uint32_t WIN_MAX_W = 12000;  // LDS bound: (WIN_TILE + w) * 12 B + tables <= 160 KiB
+
+std::string g_init_error;
+
+struct Timing
+{
+  double ms = 0;
+  uint64_t launches = 0;
+};
+
+} // namespace
+
+struct nts_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool profiling = false;
+  std::map<std::string, Timing> timings;
+  std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+};
+
+struct nts_genome
+{
+  uint64_t n = 0; // bytes of concatenated sequence
+  uint32_t n_rec = 0;
+  uint8_t* d_code = nullptr; // PAD + n + PAD bytes; base i at d_code[PAD + i]
+  std::vector<uint64_t> rec_off, rec_len;
+  uint64_t total_bases = 0;
+  // maximal stretches [a,b) of valid bases, clipped to records, ascending
+  std::vector<uint64_t> st_a, st_b;
+};
+
+struct nts_bf
+{
+  uint64_t bytes = 0;
+  uint32_t* d_words = nullptr;
+};
+
+struct nts_mx
+{
+  uint64_t n = 0;
+  uint64_t* d_h1 = nullptr;
+  uint32_t* d_rec = nullptr;
+  uint64_t* d_pos = nullptr;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                          \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                               \
+      return e_ == hipErrorOutOfMemory ? NTS_ENOMEM : NTS_EHIP;                                     \
+    }                                                                                               \
+  } while (0)
+
+int fail(nts_ctx* ctx, int code, const std::string& msg)
+{
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+// ---- timing: HIP events on the context's stream around each kernel ---------------------------
+struct ScopedTimer
+{
+  nts_ctx* ctx;
+  const char* name;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(nts_ctx* c, const char* n)
+    : ctx(c)
+    , name(n)
+  {
+    if (ctx->profiling) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, ctx->stream);
+    }
+  }
+  ~ScopedTimer()
+  {
+    if (ctx->profiling) {
+      hipEventRecord(b, ctx->stream);
+      ctx->pending.push_back({ name, { a, b } });
+    }
+  }
+};
+
+void drain_timings(nts_ctx* ctx)
+{
+  for (auto& p : ctx->pending) {
+    hipEventSynchronize(p.second.second);
+    float ms = 0;
+    hipEventElapsedTime(&ms, p.second.first, p.second.second);
+    auto& t = ctx->timings[p.first];
+    t.ms += ms;
+    t.launches += 1;
+    hipEventDestroy(p.second.first);
+    hipEventDestroy(p.second.second);
+  }
+  ctx->pending.clear();
+}
+
+// =================================================================================================
+// Kernels
+// =================================================================================================
+
+// ASCII -> code, in place.  16 bytes per lane, coalesced.
+__global__ __launch_bounds__(256) void k_encode(uint8_t* __restrict__ buf, uint64_t n)
+{
+  const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i >= n) return;
+  if (i + 16 <= n) {
+    uint4 v = *reinterpret_cast<const uint4*>(buf + i);
+    uint32_t wds[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t out = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        uint32_t c = (wds[q] >> (8 * b)) & 0xFFu;
+        c &= 0xDFu; // fold case
+        uint32_t code = (c == 'A') ? 0u : (c == 'C') ? 1u : (c == 'G') ? 2u : (c == 'T' || c == 'U') ? 3u : 4u;
+        out |= code << (8 * b);
+      }
+      wds[q] = out;
+    }
+    *reinterpret_cast<uint4*>(buf + i) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+  } else {
+    for (uint64_t j = i; j < n; ++j) {
+      uint32_t c = buf[j] & 0xDFu;
+      buf[j] = (c == 'A') ? 0 : (c == 'C') ? 1 : (c == 'G') ? 2 : (c == 'T' || c == 'U') ? 3 : 4;
+    }
+  }
+}
+
+// Boundaries of maximal valid stretches.  code points at base 0 (PAD bytes before it are invalid).
+// pass 0: count starts; pass 1: append starts / ends (unordered; sorted afterwards).
+template <int PASS>
+__global__ __launch_bounds__(256) void k_stretch(const uint8_t* __restrict__ code,
+                                                 uint64_t n,
+                                                 unsigned long long* __restrict__ counter,
+                                                 uint64_t* __restrict__ starts,
+                                                 uint64_t* __restrict__ ends,
+                                                 unsigned long long* __restrict__ cursors)
+{
+  const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (base >= n + 1) return;
+  // bytes base-1 .. base+15 ; position n is the (invalid) pad byte so a trailing stretch gets its end
+  uint32_t local = 0;
+  bool prev = code[(int64_t)base - 1] < CODE_INVALID;
+  for (int j = 0; j < 16; ++j) {
+    const uint64_t i = base + j;
+    if (i > n) break;
+    const bool cur = code[i] < CODE_INVALID;
+    if (cur != prev) {
+      if (PASS == 0) {
+        local += cur ? 1u : 0u;
+      } else {
+        if (cur)
+          starts[atomicAdd(&cursors[0], 1ULL)] = i;
+        else
+          ends[atomicAdd(&cursors[1], 1ULL)] = i;
+      }
+    }
+    prev = cur;
+  }
+  if (PASS == 0 && local) atomicAdd(counter, (unsigned long long)local);
+}
+
+// ---- canonical ntHash over the compact k-mer numbering ------------------------------------------
+// Each lane owns HASH_PER_THREAD consecutive compact indices: it locates the run holding the first
+// one (binary search in the run table), hashes that k-mer directly (k steps) and rolls on, starting
+// over at run boundaries.
+//   MODE 0: keys[j] = h0, or KEY_MAX if a filter is given and rejects h0   (sketch, rows B1+B2)
+//   MODE 1: bf_out |= bit(h0)                                               (row A2)
+//   MODE 2: if bf_in has bit(h0): bf_out |= bit(h0)                         (row A3, literal)
+enum { MODE_KEYS = 0, MODE_INSERT = 1, MODE_CASCADE = 2 };
+
+template <int MODE>
+__global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict__ code,
+                                                       const uint64_t* __restrict__ run_pos,
+                                                       const uint64_t* __restrict__ run_vstart,
+                                                       uint32_t n_runs,
+                                                       uint64_t n_valid,
+                                                       HashParams hp,
+                                                       const uint32_t* __restrict__ bf_in,
+                                                       uint32_t* __restrict__ bf_out,
+                                                       FastMod fm,
+                                                       uint64_t* __restrict__ keys)
+{
+  __shared__ uint64_t s_tab[36];
+  if (threadIdx.x < 16) {
+    s_tab[threadIdx.x] = hp.roll_f[threadIdx.x];
+    s_tab[16 + threadIdx.x] = hp.roll_r[threadIdx.x];
+  }
+  if (threadIdx.x < 4) s_tab[32 + threadIdx.x] = hp.seed[threadIdx.x];
+  __syncthreads();
+  const uint32_t k = hp.k;
+  uint64_t j = ((uint64_t)blockIdx.x * HASH_THREADS + threadIdx.x) * HASH_PER_THREAD;
+  if (j >= n_valid) return;
+  const uint64_t j_end = min(j + (uint64_t)HASH_PER_THREAD, n_valid);
+  // largest ri with run_vstart[ri] <= j
+  uint32_t lo = 0, hi = n_runs;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (run_vstart[mid] <= j)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  uint32_t ri = lo;
+  while (j < j_end) {
+    const uint64_t v0 = run_vstart[ri], v1 = run_vstart[ri + 1];
+    const uint64_t seg_end = min(j_end, v1);
+    uint64_t p = run_pos[ri] + (j - v0);
+    // direct hash of the k-mer at p
+    uint64_t f = 0, r = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+      f = srol1(f) ^ s_tab[32 + code[p + i]];
+      r = srol1(r) ^ s_tab[32 + 3 - code[p + k - 1 - i]];
+    }
+    for (;;) {
+      const uint64_t h0 = f + r;
+      if (MODE == MODE_KEYS) {
+        uint64_t key = h0;
+        if (bf_in != nullptr && !bf_test(bf_in, fm(h0))) key = KEY_MAX;
+        keys[j] = key;
+      } else if (MODE == MODE_INSERT) {
+        bf_set(bf_out, fm(h0));
+      } else {
+        const uint64_t idx = fm(h0);
+        if (bf_test(bf_in, idx)) bf_set(bf_out, idx);
+      }
+      ++j;
+      if (j >= seg_end) break;
+      const uint32_t cout = code[p], cin = code[p + k];
+      f = srol1(f) ^ s_tab[cin * 4 + cout];
+      r = sror1(r ^ s_tab[16 + cin * 4 + cout]);
+      ++p;
+    }
+    ++ri;
+  }
+}
+
+// ---- window-of-w rightmost argmin over the compact keys of one record ------------------------------
+// A workgroup owns WIN_TILE consecutive windows of one record.  Elements are cut into chunks of c =
+// min(16, w); per chunk a lane computes prefix / suffix argmins sequentially, a sparse table over the
+// chunk minima answers the run of whole chunks in between, so every window costs O(1) LDS reads.
+// "Better" = smaller key, ties to the larger index (btllib's `<=` rescan keeps the rightmost minimum).
+// A window's winner is emitted when it differs from the previous window's winner (the sequence of
+// winners is non-decreasing in position) and its key is not KEY_MAX.
+struct WinParams
+{
+  const uint64_t* keys;       // compact keys
+  const uint64_t* rec_vstart; // [n_rec] compact index of the record's first valid k-mer
+  const uint64_t* rec_nv;     // [n_rec] valid k-mers in the record
+  const uint64_t* tile_start; // [n_rec+1] prefix sum of tiles per record
+  uint32_t n_rec;
+  uint32_t w;
+  uint32_t chunk;
+  uint32_t levels;            // sparse-table levels
+  uint64_t* out_j;            // compact index of each emitted minimizer
+  uint64_t* out_key;          // its key (= h0)
+  unsigned long long* out_count;
+  uint64_t out_cap;
+};
+
+__device__ __forceinline__ uint32_t better_idx(const uint64_t* s_key, uint32_t a, uint32_t b)
+{
+  const uint64_t ka = s_key[a], kb = s_key[b];
+  if (ka < kb) return a;
+  if (kb < ka) return b;
+  return a > b ? a : b;
+}
+
+__global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // block -> (record, tile)
+  uint32_t lo = 0, hi = P.n_rec;
+  const uint64_t b = blockIdx.x;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (P.tile_start[mid] <= b)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const uint32_t rec = lo;
+  const uint64_t nv = P.rec_nv[rec];
+  const uint32_t w = P.w;
+  const uint64_t n_win_rec = nv - w + 1;
+  const uint64_t t0 = (b - P.tile_start[rec]) * (uint64_t)WIN_TILE;
+  const uint32_t cnt = (uint32_t)min((uint64_t)WIN_TILE, n_win_rec - t0);
+  const uint64_t tf = t0 > 0 ? t0 - 1 : 0;      // first window evaluated (one of overlap)
+  const uint32_t n_win = (uint32_t)(t0 + cnt - tf);
+  const uint32_t E = n_win + w - 1;             // elements tf .. tf+E-1 of the record
+  const uint32_t c = P.chunk;
+  const uint32_t n_chunks = (E + c - 1) / c;
+
+  uint64_t* s_key = reinterpret_cast<uint64_t*>(smem);
+  uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_key + E);
+  uint16_t* s_suf = s_pre + E;
+  uint16_t* s_st = s_suf + E; // levels x n_chunks
+
+  const uint64_t* gk = P.keys + P.rec_vstart[rec] + tf;
+  for (uint32_t e = threadIdx.x; e < E; e += WIN_THREADS) s_key[e] = gk[e];
+  __syncthreads();
+
+  for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += WIN_THREADS) {
+    const uint32_t a = ch * c, z = min(a + c, E);
+    uint32_t cur = a;
+    uint64_t kc = s_key[a];
+    s_pre[a] = (uint16_t)a;
+    for (uint32_t e = a + 1; e < z; ++e) {
+      const uint64_t ke = s_key[e];
+      if (ke <= kc) {
+        kc = ke;
+        cur = e;
+      }
+      s_pre[e] = (uint16_t)cur;
+    }
+    s_st[ch] = (uint16_t)cur;
+    cur = z - 1;
+    kc = s_key[cur];
+    s_suf[cur] = (uint16_t)cur;
+    for (uint32_t e = z - 1; e-- > a;) {
+      const uint64_t ke = s_key[e];
+      if (ke < kc) {
+        kc = ke;
+        cur = e;
+      }
+      s_suf[e] = (uint16_t)cur;
+    }
+  }
+  __syncthreads();
+  for (uint32_t L = 1; L < P.levels; ++L) {
+    const uint32_t half = 1u << (L - 1);
+    const uint16_t* prev = s_st + (size_t)(L - 1) * n_chunks;
+    uint16_t* cur = s_st + (size_t)L * n_chunks;
+    for (uint32_t i = threadIdx.x; i + 2 * half <= n_chunks; i += WIN_THREADS)
+      cur[i] = (uint16_t)better_idx(s_key, prev[i], prev[i + half]);
+    __syncthreads();
+  }
+
+  // windows: lane handles a contiguous slice so it can compare with the previous winner
+  const uint32_t per = (n_win + WIN_THREADS - 1) / WIN_THREADS;
+  const uint32_t w_lo = threadIdx.x * per;
+  const uint32_t w_hi = min(w_lo + per, n_win);
+  auto winner = [&](uint32_t e) -> uint32_t {
+    const uint32_t last = e + w - 1;
+    const uint32_t ca = e / c, cb = last / c;
+    uint32_t best = s_suf[e];
+    if (cb > ca) {
+      best = better_idx(s_key, best, s_pre[last]);
+      if (cb - ca >= 2) {
+        const uint32_t len = cb - ca - 1;
+        const uint32_t L = 31 - __clz(len);
+        const uint16_t* lvl = s_st + (size_t)L * n_chunks;
+        best = better_idx(s_key, best, lvl[ca + 1]);
+        best = better_idx(s_key, best, lvl[cb - (1u << L)]);
+      }
+    }
+    return best;
+  };
+  if (w_lo < w_hi) {
+    uint32_t prev = (w_lo > 0) ? winner(w_lo - 1) : 0xFFFFFFFFu;
+    for (uint32_t e = w_lo; e < w_hi; ++e) {
+      const uint32_t cur = winner(e);
+      const bool owned = (tf + e) >= t0;
+      const bool fresh = (e == 0 && tf == 0 && t0 == 0) ? true : (cur != prev);
+      if (owned && fresh && !(e == 0 && t0 > 0)) {
+        const uint64_t key = s_key[cur];
+        if (key != KEY_MAX) {
+          const unsigned long long slot = atomicAdd(P.out_count, 1ULL);
+          if (slot < P.out_cap) {
+            P.out_j[slot] = P.rec_vstart[rec] + tf + cur;
+            P.out_key[slot] = key;
+          }
+        }
+      }
+      prev = cur;
+    }
+  }
+}
+
+// compact index -> (record, position in record), and the printed hash h1
+__global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j_sorted,
+                                                  const uint64_t* __restrict__ key_sorted,
+                                                  uint64_t n_out,
+                                                  const uint64_t* __restrict__ run_pos,
+                                                  const uint64_t* __restrict__ run_vstart,
+                                                  uint32_t n_runs,
+                                                  const uint64_t* __restrict__ rec_off,
+                                                  uint32_t n_rec,
+                                                  uint32_t k,
+                                                  uint64_t* __restrict__ h1,
+                                                  uint32_t* __restrict__ rec,
+                                                  uint64_t* __restrict__ pos)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const uint64_t j = j_sorted[i];
+  uint32_t lo = 0, hi = n_runs;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (run_vstart[mid] <= j)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const uint64_t gp = run_pos[lo] + (j - run_vstart[lo]);
+  uint32_t a = 0, z = n_rec;
+  while (z - a > 1) {
+    const uint32_t mid = a + ((z - a) >> 1);
+    if (rec_off[mid] <= gp)
+      a = mid;
+    else
+      z = mid;
+  }
+  h1[i] = extend_h1(key_sorted[i], k);
+  rec[i] = a;
+  pos[i] = gp - rec_off[a];
+}
+
+__global__ __launch_bounds__(256) void k_bf_and(uint4* __restrict__ acc, const uint4* __restrict__ other, uint64_t n16)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n16; i += stride) {
+    uint4 a = acc[i];
+    const uint4 o = other[i];
+    a.x &= o.x;
+    a.y &= o.y;
+    a.z &= o.z;
+    a.w &= o.w;
+    acc[i] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bf_popcount(const uint4* __restrict__ words, uint64_t n16, unsigned long long* __restrict__ total)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long acc = 0;
+  for (; i < n16; i += stride) {
+    const uint4 v = words[i];
+    acc += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(total, acc);
+}
+
+// =================================================================================================
+// Host helpers
+// =================================================================================================
+
+HashParams make_hash_params(uint32_t k)
+{
+  HashParams hp;
+  const uint64_t seed[4] = { SEED_A, SEED_C, SEED_G, SEED_T };
+  uint64_t rotk[4];
+  for (int c = 0; c < 4; ++c) {
+    uint64_t x = seed[c];
+    for (uint32_t i = 0; i < k; ++i) x = srol1(x);
+    rotk[c] = x;
+    hp.seed[c] = seed[c];
+  }
+  for (int cin = 0; cin < 4; ++cin)
+    for (int cout = 0; cout < 4; ++cout) {
+      hp.roll_f[cin * 4 + cout] = seed[cin] ^ rotk[cout];
+      hp.roll_r[cin * 4 + cout] = rotk[3 - cin] ^ seed[3 - cout];
+    }
+  hp.k = k;
+  return hp;
+}
+
+FastMod make_fastmod(uint64_t m)
+{
+  FastMod fm;
+  fm.m = m;
+  // floor(2^64 / m) for m >= 2, not a power of two or otherwise: (2^64-1)/m differs only when m | 2^64
+  unsigned __int128 one = ((unsigned __int128)1) << 64;
+  fm.inv = (uint64_t)(one / m);
+  return fm;
+}
+
+struct RunTable
+{
+  std::vector<uint64_t> pos, vstart; // vstart has n_runs+1 entries
+  std::vector<uint64_t> rec_vstart, rec_nv;
+  uint64_t n_valid = 0;
+};
+
+// stretches minus mask intervals, keep pieces of at least k bases -> runs of k-mer starts
+int build_runs(nts_ctx* ctx, const nts_genome* g, uint32_t k, const nts_interval* mask, uint64_t n_mask, RunTable& rt)
+{
+  std::vector<std::pair<uint64_t, uint64_t>> mk;
+  mk.reserve(n_mask);
+  for (uint64_t i = 0; i < n_mask; ++i) {
+    if (mask[i].rec >= g->n_rec) return fail(ctx, NTS_EINVAL, "mask interval: record index out of range");
+    const uint64_t len = g->rec_len[mask[i].rec];
+    const uint64_t s = std::min(mask[i].start, len), e = std::min(mask[i].end, len);
+    if (e > s) mk.push_back({ g->rec_off[mask[i].rec] + s, g->rec_off[mask[i].rec] + e });
+  }
+  std::sort(mk.begin(), mk.end());
+  size_t mi = 0;
+  const size_t ns = g->st_a.size();
+  rt.pos.clear();
+  rt.vstart.clear();
+  uint64_t v = 0;
+  auto add_piece = [&](uint64_t a, uint64_t b) {
+    if (b > a && b - a >= k) {
+      rt.pos.push_back(a);
+      rt.vstart.push_back(v);
+      v += (b - a) - k + 1;
+    }
+  };
+  for (size_t s = 0; s < ns; ++s) {
+    uint64_t a = g->st_a[s];
+    const uint64_t b = g->st_b[s];
+    while (mi < mk.size() && mk[mi].second <= a) ++mi;
+    size_t q = mi;
+    while (q < mk.size() && mk[q].first < b) {
+      if (mk[q].first > a) add_piece(a, mk[q].first);
+      a = std::max(a, mk[q].second);
+      if (a >= b) break;
+      ++q;
+    }
+    if (a < b) add_piece(a, b);
+  }
+  rt.vstart.push_back(v);
+  rt.n_valid = v;
+  // per-record compact ranges
+  rt.rec_vstart.assign(g->n_rec, 0);
+  rt.rec_nv.assign(g->n_rec, 0);
+  size_t ri = 0;
+  const size_t nr = rt.pos.size();
+  for (uint32_t r = 0; r < g->n_rec; ++r) {
+    const uint64_t end = g->rec_off[r] + g->rec_len[r];
+    while (ri < nr && rt.pos[ri] < g->rec_off[r]) ++ri; // (cannot happen: stretches are clipped)
+    rt.rec_vstart[r] = ri < nr ? rt.vstart[ri] : v;
+    size_t q = ri;
+    while (q < nr && rt.pos[q] < end) ++q;
+    rt.rec_nv[r] = (q < nr ? rt.vstart[q] : v) - rt.rec_vstart[r];
+    ri = q;
+  }
+  return NTS_OK;
+}
+
+template <typename T>
+int dev_upload(nts_ctx* ctx, const std::vector<T>& h, T** d, size_t min_elems = 1)
+{
+  const size_t n = std::max(h.size(), min_elems);
+  HIP_TRY(ctx, hipMalloc((void**)d, n * sizeof(T)));
+  if (!h.empty()) HIP_TRY(ctx, hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return NTS_OK;
+}
+
+struct DevRuns
+{
+  uint64_t* pos = nullptr;
+  uint64_t* vstart = nullptr;
+  uint32_t n = 0;
+  ~DevRuns()
+  {
+    if (pos) hipFree(pos);
+    if (vstart) hipFree(vstart);
+  }
+};
+
+int upload_runs(nts_ctx* ctx, const RunTable& rt, DevRuns& dr)
+{
+  if (rt.pos.size() > 0xFFFFFFF0ULL) return fail(ctx, NTS_ERANGE, "too many valid runs");
+  dr.n = (uint32_t)rt.pos.size();
+  int rc = dev_upload(ctx, rt.pos, &dr.pos);
+  if (rc) return rc;
+  return dev_upload(ctx, rt.vstart, &dr.vstart);
+}
+
+template <int MODE>
+int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const RunTable& rt, const DevRuns& dr, uint32_t k,
+                const nts_bf* bf_in, nts_bf* bf_out, uint64_t* keys)
+{
+  if (rt.n_valid == 0) return NTS_OK;
+  const HashParams hp = make_hash_params(k);
+  const uint64_t bits = (bf_in ? bf_in->bytes : (bf_out ? bf_out->bytes : 8)) * 8;
+  const FastMod fm = make_fastmod(bits);
+  const uint64_t per_block = (uint64_t)HASH_THREADS * HASH_PER_THREAD;
+  const uint64_t blocks = (rt.n_valid + per_block - 1) / per_block;
+  if (blocks > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
+  ScopedTimer t(ctx, name);
+  hipLaunchKernelGGL(k_hash<MODE>, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, dr.pos,
+                     dr.vstart, dr.n, rt.n_valid, hp, bf_in ? bf_in->d_words : nullptr, bf_out ? bf_out->d_words : nullptr,
+                     fm, keys);
+  HIP_TRY(ctx, hipGetLastError());
+  return NTS_OK;
+}
+
+} // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int nts_init(int device, nts_ctx** out)
+{
+  if (!out) return NTS_EINVAL;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_init_error = std::string("no HIP device: ") + hipGetErrorString(e);
+    return NTS_EHIP;
+  }
+  if (device < 0 || device >= n) {
+    g_init_error = "device index out of range";
+    return NTS_EINVAL;
+  }
+  nts_ctx* ctx = new nts_ctx();
+  ctx->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_init_error = std::string("hipSetDevice/hipStreamCreate: ") + hipGetErrorString(e);
+    delete ctx;
+    return NTS_EHIP;
+  }
+  *out = ctx;
+  return NTS_OK;
+}
+
+void nts_destroy(nts_ctx* ctx)
+{
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  drain_timings(ctx);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* nts_last_error(nts_ctx* ctx)
+{
+  return ctx ? ctx->err.c_str() : g_init_error.c_str();
+}
+
+int nts_sync(nts_ctx* ctx)
+{
+  if (!ctx) return NTS_EINVAL;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return NTS_OK;
+}
+
+void* nts_stream(nts_ctx* ctx)
+{
+  return ctx ? (void*)ctx->stream : nullptr;
+}
+
+int nts_profile(nts_ctx* ctx, int enable)
+{
+  if (!ctx) return NTS_EINVAL;
+  drain_timings(ctx);
+  ctx->timings.clear();
+  ctx->profiling = enable != 0;
+  return NTS_OK;
+}
+
+int nts_timing(nts_ctx* ctx, const char* name, double* total_ms, uint64_t* launches)
+{
+  if (!ctx || !name) return NTS_EINVAL;
+  drain_timings(ctx);
+  auto it = ctx->timings.find(name);
+  if (total_ms) *total_ms = it == ctx->timings.end() ? 0.0 : it->second.ms;
+  if (launches) *launches = it == ctx->timings.end() ? 0 : it->second.launches;
+  return NTS_OK;
+}
+
+int nts_bf_size_bytes(uint64_t genome_bp, double fpr, uint64_t* approx_bytes, uint64_t* ctor_bytes)
+{
+  if (!(fpr > 0.0 && fpr < 1.0)) return NTS_EINVAL;
+  // src/ntsynt_make_common_bf.cpp:38-39
+  const long long genome_size = (long long)genome_bp;
+  const long long size_bits = (long long)std::ceil(((double)(-1 * genome_size)) / std::log(1 - fpr));
+  const uint64_t approx = (uint64_t)(size_bits / 8);
+  if (approx_bytes) *approx_bytes = approx;
+  if (ctor_bytes) *ctor_bytes = (uint64_t)(std::ceil((double)approx / 8.0) * 8.0);
+  return NTS_OK;
+}
+
+int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64_t* rec_off, const uint64_t* rec_len,
+                      uint32_t n_rec, nts_genome** out)
+{
+  if (!ctx || !out || (n && !seq) || (n_rec && (!rec_off || !rec_len))) return fail(ctx, NTS_EINVAL, "nts_genome_upload: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t prev_end = 0;
+  for (uint32_t r = 0; r < n_rec; ++r) {
+    if (rec_off[r] < prev_end || rec_off[r] + rec_len[r] > n)
+      return fail(ctx, NTS_EINVAL, "nts_genome_upload: records must be ascending, disjoint and inside seq");
+    prev_end = rec_off[r] + rec_len[r];
+  }
+  nts_genome* g = new nts_genome();
+  g->n = n;
+  g->n_rec = n_rec;
+  g->rec_off.assign(rec_off, rec_off + n_rec);
+  g->rec_len.assign(rec_len, rec_len + n_rec);
+  for (uint32_t r = 0; r < n_rec; ++r) g->total_bases += rec_len[r];
+  const uint64_t dev_bytes = PAD + n + PAD;
+  hipError_t e = hipMalloc((void**)&g->d_code, dev_bytes);
+  if (e != hipSuccess) {
+    delete g;
+    return fail(ctx, NTS_ENOMEM, std::string("hipMalloc genome: ") + hipGetErrorString(e));
+  }
+  auto bail = [&](int code, const std::string& msg) {
+    hipFree(g->d_code);
+    delete g;
+    return fail(ctx, code, msg);
+  };
+  if (hipMemsetAsync(g->d_code, CODE_INVALID, PAD, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(g->d_code + PAD + n, CODE_INVALID, PAD, ctx->stream) != hipSuccess)
+    return bail(NTS_EHIP, "hipMemset pads");
+  if (n) {
+    if (hipMemcpyAsync(g->d_code + PAD, seq, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return bail(NTS_EHIP, "hipMemcpy genome");
+    const uint64_t blocks = (n + 4095) / 4096;
+    hipLaunchKernelGGL(k_encode, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n);
+  }
+  // valid stretches: count, append, sort
+  unsigned long long* d_cnt = nullptr;
+  if (hipMalloc((void**)&d_cnt, 3 * sizeof(unsigned long long)) != hipSuccess) return bail(NTS_ENOMEM, "hipMalloc counters");
+  hipMemsetAsync(d_cnt, 0, 3 * sizeof(unsigned long long), ctx->stream);
+  const uint64_t sblocks = (n + 1 + 4095) / 4096;
+  hipLaunchKernelGGL(k_stretch<0>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, nullptr, nullptr,
+                     nullptr);
+  unsigned long long n_st = 0;
+  hipMemcpyAsync(&n_st, d_cnt, sizeof(n_st), hipMemcpyDeviceToHost, ctx->stream);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    hipFree(d_cnt);
+    return bail(NTS_EHIP, std::string("encode/stretch count: ") + hipGetErrorString(hipGetLastError()));
+  }
+  std::vector<uint64_t> hs(n_st), he(n_st);
+  if (n_st) {
+    uint64_t *d_s = nullptr, *d_e = nullptr, *d_s2 = nullptr, *d_e2 = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    bool ok = hipMalloc((void**)&d_s, n_st * 8) == hipSuccess && hipMalloc((void**)&d_e, n_st * 8) == hipSuccess &&
+              hipMalloc((void**)&d_s2, n_st * 8) == hipSuccess && hipMalloc((void**)&d_e2, n_st * 8) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(k_stretch<1>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, d_s, d_e,
+                         d_cnt + 1);
+      rocprim::radix_sort_keys(nullptr, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
+      ok = hipMalloc(&d_tmp, tmp_bytes) == hipSuccess;
+    }
+    if (ok) {
+      rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
+      rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_e, d_e2, n_st, 0, 64, ctx->stream);
+      hipMemcpyAsync(hs.data(), d_s2, n_st * 8, hipMemcpyDeviceToHost, ctx->stream);
+      hipMemcpyAsync(he.data(), d_e2, n_st * 8, hipMemcpyDeviceToHost, ctx->stream);
+      ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    hipFree(d_s);
+    hipFree(d_e);
+    hipFree(d_s2);
+    hipFree(d_e2);
+    hipFree(d_tmp);
+    if (!ok) {
+      hipFree(d_cnt);
+      return bail(NTS_EHIP, "stretch detection failed");
+    }
+  }
+  hipFree(d_cnt);
+  // clip stretches to records (k-mers never span two records)
+  uint32_t r = 0;
+  for (size_t s = 0; s < hs.size(); ++s) {
+    uint64_t a = hs[s];
+    const uint64_t b = he[s];
+    while (a < b) {
+      while (r < n_rec && g->rec_off[r] + g->rec_len[r] <= a) ++r;
+      if (r >= n_rec) break;
+      const uint64_t ra = g->rec_off[r], rb = ra + g->rec_len[r];
+      const uint64_t x = std::max(a, ra), y = std::min(b, rb);
+      if (y > x) {
+        g->st_a.push_back(x);
+        g->st_b.push_back(y);
+      }
+      if (b <= rb) break;
+      a = rb;
+    }
+  }
+  *out = g;
+  return NTS_OK;
+}
+
+void nts_genome_free(nts_ctx* ctx, nts_genome* g)
+{
+  if (!g) return;
+  if (ctx) hipSetDevice(ctx->device);
+  if (g->d_code) hipFree(g->d_code);
+  delete g;
+}
+
+uint64_t nts_genome_bases(const nts_genome* g)
+{
+  return g ? g->total_bases : 0;
+}
+
+int nts_genome_valid_kmers(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t* n_valid)
+{
+  if (!ctx || !g || !n_valid || k == 0) return fail(ctx, NTS_EINVAL, "nts_genome_valid_kmers: bad arguments");
+  uint64_t v = 0;
+  for (size_t s = 0; s < g->st_a.size(); ++s) {
+    const uint64_t len = g->st_b[s] - g->st_a[s];
+    if (len >= k) v += len - k + 1;
+  }
+  *n_valid = v;
+  return NTS_OK;
+}
+
+// ---- Bloom filter ------------------------------------------------------------------------------------
+int nts_bf_create(nts_ctx* ctx, uint64_t bytes, nts_bf** out)
+{
+  if (!ctx || !out || bytes == 0 || (bytes % 8) != 0) return fail(ctx, NTS_EINVAL, "nts_bf_create: bytes must be a positive multiple of 8");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  nts_bf* bf = new nts_bf();
+  bf->bytes = bytes;
+  const uint64_t alloc = (bytes + 15) / 16 * 16; // AND / popcount run on 16-byte lanes; tail stays zero
+  hipError_t e = hipMalloc((void**)&bf->d_words, alloc);
+  if (e != hipSuccess) {
+    delete bf;
+    return fail(ctx, NTS_ENOMEM, std::string("hipMalloc bloom: ") + hipGetErrorString(e));
+  }
+  e = hipMemsetAsync(bf->d_words, 0, alloc, ctx->stream);
+  if (e != hipSuccess) {
+    hipFree(bf->d_words);
+    delete bf;
+    return fail(ctx, NTS_EHIP, "hipMemset bloom");
+  }
+  *out = bf;
+  return NTS_OK;
+}
+
+void nts_bf_free(nts_ctx* ctx, nts_bf* bf)
+{
+  if (!bf) return;
+  if (ctx) hipSetDevice(ctx->device);
+  if (bf->d_words) hipFree(bf->d_words);
+  delete bf;
+}
+
+uint64_t nts_bf_bytes(const nts_bf* bf)
+{
+  return bf ? bf->bytes : 0;
+}
+
+void* nts_bf_device_ptr(nts_bf* bf)
+{
+  return bf ? (void*)bf->d_words : nullptr;
+}
+
+int nts_bf_clear(nts_ctx* ctx, nts_bf* bf)
+{
+  if (!ctx || !bf) return fail(ctx, NTS_EINVAL, "nts_bf_clear: bad arguments");
+  HIP_TRY(ctx, hipMemsetAsync(bf->d_words, 0, (bf->bytes + 15) / 16 * 16, ctx->stream));
+  return NTS_OK;
+}
+
+static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nts_genome* g, uint32_t k)
+{
+  if (!ctx || !next || !g || k == 0) return fail(ctx, NTS_EINVAL, "bloom pass: bad arguments");
+  if (prev && prev->bytes != next->bytes) return fail(ctx, NTS_EINVAL, "bloom pass: filters differ in size");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  RunTable rt;
+  int rc = build_runs(ctx, g, k, nullptr, 0, rt);
+  if (rc) return rc;
+  DevRuns dr;
+  if ((rc = upload_runs(ctx, rt, dr))) return rc;
+  if (prev)
+    rc = launch_hash<MODE_CASCADE>(ctx, "bf_cascade", g, rt, dr, k, prev, next, nullptr);
+  else
+    rc = launch_hash<MODE_INSERT>(ctx, "bf_insert", g, rt, dr, k, nullptr, next, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // run table buffers are released on return
+  return NTS_OK;
+}
+
+int nts_bf_insert(nts_ctx* ctx, nts_bf* bf, const nts_genome* g, uint32_t k)
+{
+  return bf_hash_pass(ctx, nullptr, bf, g, k);
+}
+
+int nts_bf_cascade(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nts_genome* g, uint32_t k)
+{
+  if (!prev) return fail(ctx, NTS_EINVAL, "nts_bf_cascade: prev is NULL");
+  return bf_hash_pass(ctx, prev, next, g, k);
+}
+
+int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other)
+{
+  if (!ctx || !acc || !other || acc->bytes != other->bytes) return fail(ctx, NTS_EINVAL, "nts_bf_and: filters differ in size");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t n16 = (acc->bytes + 15) / 16;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
+  ScopedTimer t(ctx, "bf_and");
+  hipLaunchKernelGGL(k_bf_and, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)acc->d_words, (const uint4*)other->d_words, n16);
+  HIP_TRY(ctx, hipGetLastError());
+  return NTS_OK;
+}
+
+int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set)
+{
+  if (!ctx || !bf || !bits_set) return fail(ctx, NTS_EINVAL, "nts_bf_popcount: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  unsigned long long* d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(unsigned long long)));
+  hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream);
+  const uint64_t n16 = (bf->bytes + 15) / 16;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
+  {
+    ScopedTimer t(ctx, "bf_popcount");
+    hipLaunchKernelGGL(k_bf_popcount, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4*)bf->d_words, n16, d);
+  }
+  unsigned long long h = 0;
+  hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipFree(d);
+  if (e != hipSuccess) return fail(ctx, NTS_EHIP, std::string("popcount: ") + hipGetErrorString(e));
+  *bits_set = h;
+  return NTS_OK;
+}
+
+int nts_bf_download(nts_ctx* ctx, const nts_bf* bf, uint8_t* host, uint64_t bytes)
+{
+  if (!ctx || !bf || !host || bytes != bf->bytes) return fail(ctx, NTS_EINVAL, "nts_bf_download: size mismatch");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(host, bf->d_words, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return NTS_OK;
+}
+
+int nts_bf_upload(nts_ctx* ctx, nts_bf* bf, const uint8_t* host, uint64_t bytes)
+{
+  if (!ctx || !bf || !host || bytes != bf->bytes) return fail(ctx, NTS_EINVAL, "nts_bf_upload: size mismatch");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(bf->d_words, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return NTS_OK;
+}
+
+// ---- sketch ---------------------------------------------------------------------------------------------
+int nts_hash_all(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t** h0, uint64_t* n_out)
+{
+  if (!ctx || !g || !h0 || !n_out || k == 0) return fail(ctx, NTS_EINVAL, "nts_hash_all: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  RunTable rt;
+  int rc = build_runs(ctx, g, k, nullptr, 0, rt);
+  if (rc) return rc;
+  DevRuns dr;
+  if ((rc = upload_runs(ctx, rt, dr))) return rc;
+  uint64_t* d_keys = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&d_keys, std::max<uint64_t>(rt.n_valid, 1) * 8));
+  rc = launch_hash<MODE_KEYS>(ctx, "hash_only", g, rt, dr, k, nullptr, nullptr, d_keys);
+  uint64_t* host = (uint64_t*)malloc(std::max<uint64_t>(rt.n_valid, 1) * 8);
+  if (rc == NTS_OK && rt.n_valid) {
+    hipMemcpyAsync(host, d_keys, rt.n_valid * 8, hipMemcpyDeviceToHost, ctx->stream);
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_keys);
+  if (rc != NTS_OK || e != hipSuccess) {
+    free(host);
+    return rc != NTS_OK ? rc : fail(ctx, NTS_EHIP, std::string("hash_all: ") + hipGetErrorString(e));
+  }
+  *h0 = host;
+  *n_out = rt.n_valid;
+  return NTS_OK;
+}
+
+int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const nts_bf* filter, const nts_interval* mask,
+               uint64_t n_mask, nts_mx** out)
+{
+  if (!ctx || !g || !out || k == 0 || w == 0 || (n_mask && !mask)) return fail(ctx, NTS_EINVAL, "nts_sketch: bad arguments");
+  if (w > WIN_MAX_W) return fail(ctx, NTS_ERANGE, "nts_sketch: w exceeds the LDS-resident window limit (12000)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  RunTable rt;
+  int rc = build_runs(ctx, g, k, mask, n_mask, rt);
+  if (rc) return rc;
+  nts_mx* mx = new nts_mx();
+  // tiles per record
+  std::vector<uint64_t> tile_start(g->n_rec + 1, 0);
+  for (uint32_t r = 0; r < g->n_rec; ++r) {
+    const uint64_t nv = rt.rec_nv[r];
+    const uint64_t n_win = nv >= w ? nv - w + 1 : 0;
+    tile_start[r + 1] = tile_start[r] + (n_win + WIN_TILE - 1) / WIN_TILE;
+  }
+  const uint64_t n_tiles = tile_start[g->n_rec];
+  if (rt.n_valid == 0 || n_tiles == 0) {
+    *out = mx;
+    return NTS_OK;
+  }
+  if (n_tiles > 0x7FFFFFFFULL) {
+    delete mx;
+    return fail(ctx, NTS_ERANGE, "too many window tiles for one launch");
+  }
+  DevRuns dr;
+  uint64_t *d_keys = nullptr, *d_rec_vstart = nullptr, *d_rec_nv = nullptr, *d_tile_start = nullptr, *d_rec_off = nullptr;
+  uint64_t *d_oj = nullptr, *d_ok = nullptr, *d_oj2 = nullptr, *d_ok2 = nullptr;
+  unsigned long long* d_count = nullptr;
+  void* d_tmp = nullptr;
+  auto cleanup = [&]() {
+    hipFree(d_keys);
+    hipFree(d_rec_vstart);
+    hipFree(d_rec_nv);
+    hipFree(d_tile_start);
+    hipFree(d_rec_off);
+    hipFree(d_oj);
+    hipFree(d_ok);
+    hipFree(d_oj2);
+    hipFree(d_ok2);
+    hipFree(d_count);
+    hipFree(d_tmp);
+  };
+#define SK_TRY(expr)                                                                                \
+  do {                                                                                              \
+    int rc_ = (expr);                                                                               \
+    if (rc_ != NTS_OK) {                                                                            \
+      hipStreamSynchronize(ctx->stream);                                                            \
+      cleanup();                                                                                    \
+      delete mx;                                                                                    \
+      return rc_;                                                                                   \
+    }                                                                                               \
+  } while (0)
+#define SK_HIP(expr)                                                                                \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                 \
+      hipStreamSynchronize(ctx->stream);                                                            \
+      cleanup();                                                                                    \
+      delete mx;                                                                                    \
+      return e_ == hipErrorOutOfMemory ? NTS_ENOMEM : NTS_EHIP;                                     \
+    }                                                                                               \
+  } while (0)
+
+  SK_TRY(upload_runs(ctx, rt, dr));
+  SK_HIP(hipMalloc((void**)&d_keys, rt.n_valid * 8));
+  SK_TRY(launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, rt, dr, k, filter, nullptr, d_keys));
+
+  SK_TRY(dev_upload(ctx, rt.rec_vstart, &d_rec_vstart));
+  SK_TRY(dev_upload(ctx, rt.rec_nv, &d_rec_nv));
+  SK_TRY(dev_upload(ctx, tile_start, &d_tile_start));
+  SK_TRY(dev_upload(ctx, g->rec_off, &d_rec_off));
+  SK_HIP(hipMalloc((void**)&d_count, sizeof(unsigned long long)));
+
+  WinParams P;
+  P.keys = d_keys;
+  P.rec_vstart = d_rec_vstart;
+  P.rec_nv = d_rec_nv;
+  P.tile_start = d_tile_start;
+  P.n_rec = g->n_rec;
+  P.w = w;
+  P.chunk = std::min<uint32_t>(WIN_CHUNK, w);
+  const uint32_t max_full = w / P.chunk;
+  P.levels = 1;
+  while ((1u << P.levels) <= max_full) ++P.levels;
+  const uint32_t E_max = WIN_TILE + 1 + w - 1;
+  const uint32_t chunks_max = (E_max + P.chunk - 1) / P.chunk;
+  const size_t lds = (size_t)E_max * 8 + (size_t)E_max * 2 * 2 + (size_t)P.levels * chunks_max * 2 + 64;
+  if (lds > 160 * 1024) SK_TRY(fail(ctx, NTS_ERANGE, "window tile does not fit LDS"));
+  SK_HIP(hipFuncSetAttribute((const void*)k_window_min, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+
+  uint64_t cap = std::max<uint64_t>(4096, 3 * rt.n_valid / w + 2 * n_tiles + 1024);
+  unsigned long long count = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    hipFree(d_oj);
+    hipFree(d_ok);
+    d_oj = d_ok = nullptr;
+    SK_HIP(hipMalloc((void**)&d_oj, cap * 8));
+    SK_HIP(hipMalloc((void**)&d_ok, cap * 8));
+    SK_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+    P.out_j = d_oj;
+    P.out_key = d_ok;
+    P.out_count = d_count;
+    P.out_cap = cap;
+    {
+      ScopedTimer t(ctx, "window_min");
+      hipLaunchKernelGGL(k_window_min, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
+    }
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipMemcpyAsync(&count, d_count, sizeof(count), hipMemcpyDeviceToHost, ctx->stream));
+    SK_HIP(hipStreamSynchronize(ctx->stream));
+    if (count <= cap) break;
+    cap = count; // exact size known now; run again
+  }
+  hipFree(d_keys);
+  d_keys = nullptr;
+  mx->n = count;
+  if (count) {
+    SK_HIP(hipMalloc((void**)&d_oj2, count * 8));
+    SK_HIP(hipMalloc((void**)&d_ok2, count * 8));
+    size_t tmp_bytes = 0;
+    {
+      ScopedTimer t(ctx, "sort_minimizers");
+      SK_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_oj, d_oj2, d_ok, d_ok2, count, 0, 64, ctx->stream));
+      SK_HIP(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+      SK_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_oj, d_oj2, d_ok, d_ok2, count, 0, 64, ctx->stream));
+    }
+    SK_HIP(hipMalloc((void**)&mx->d_h1, count * 8));
+    SK_HIP(hipMalloc((void**)&mx->d_rec, count * 4));
+    SK_HIP(hipMalloc((void**)&mx->d_pos, count * 8));
+    {
+      ScopedTimer t(ctx, "finalize");
+      hipLaunchKernelGGL(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_oj2, d_ok2, (uint64_t)count,
+                         dr.pos, dr.vstart, dr.n, d_rec_off, g->n_rec, k, mx->d_h1, mx->d_rec, mx->d_pos);
+    }
+    SK_HIP(hipGetLastError());
+  }
+  SK_HIP(hipStreamSynchronize(ctx->stream));
+  cleanup();
+  *out = mx;
+  return NTS_OK;
+#undef SK_TRY
+#undef SK_HIP
+}
+
+uint64_t nts_mx_count(const nts_mx* mx)
+{
+  return mx ? mx->n : 0;
+}
+
+void nts_mx_free(nts_ctx* ctx, nts_mx* mx)
+{
+  if (!mx) return;
+  if (ctx) hipSetDevice(ctx->device);
+  hipFree(mx->d_h1);
+  hipFree(mx->d_rec);
+  hipFree(mx->d_pos);
+  delete mx;
+}
+
+int nts_mx_download(nts_ctx* ctx, const nts_mx* mx, uint64_t* h1, uint32_t* rec, uint64_t* pos)
+{
+  if (!ctx || !mx) return fail(ctx, NTS_EINVAL, "nts_mx_download: bad arguments");
+  if (mx->n == 0) return NTS_OK;
+  if (!h1 || !rec || !pos) return fail(ctx, NTS_EINVAL, "nts_mx_download: NULL output");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(h1, mx->d_h1, mx->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(rec, mx->d_rec, mx->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(pos, mx->d_pos, mx->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return NTS_OK;
+}
+
+int nts_mx_device_ptrs(const nts_mx* mx, void** h1, void** rec, void** pos)
+{
+  if (!mx) return NTS_EINVAL;
+  if (h1) *h1 = mx->d_h1;
+  if (rec) *rec = mx->d_rec;
+  if (pos) *pos = mx->d_pos;
+  return NTS_OK;
+}
+
+int nts_mx_upload(nts_ctx* ctx, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos, uint64_t n, nts_mx** out)
+{
+  if (!ctx || !out || (n && (!h1 || !rec || !pos))) return fail(ctx, NTS_EINVAL, "nts_mx_upload: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  nts_mx* mx = new nts_mx();
+  mx->n = n;
+  if (n) {
+    if (hipMalloc((void**)&mx->d_h1, n * 8) != hipSuccess || hipMalloc((void**)&mx->d_rec, n * 4) != hipSuccess ||
+        hipMalloc((void**)&mx->d_pos, n * 8) != hipSuccess) {
+      nts_mx_free(ctx, mx);
+      return fail(ctx, NTS_ENOMEM, "nts_mx_upload: hipMalloc");
+    }
+    hipMemcpyAsync(mx->d_h1, h1, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(mx->d_rec, rec, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(mx->d_pos, pos, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      nts_mx_free(ctx, mx);
+      return fail(ctx, NTS_EHIP, "nts_mx_upload: copy");
+    }
+  }
+  *out = mx;
+  return NTS_OK;
+}
+
+int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, nts_mx* const* lists, nts_graph* out)
+{
+  (void)n_asm;
+  (void)lists;
+  (void)out;
+  return fail(ctx, NTS_EINVAL, "nts_graph_build: not built yet");
+}
+
+void nts_graph_free(nts_graph* g)
+{
+  if (!g) return;
+  free(g->v_hash);
+  free(g->occ_rec);
+  free(g->occ_pos);
+  free(g->n_lists);
+  free(g->list_off);
+  free(g->list_v);
+  free(g->e_u);
+  free(g->e_v);
+  free(g->e_w);
+  free(g->e_first);
+  memset(g, 0, sizeof(*g));
+}
+
+void nts_free(void* p)
+{
+  free(p);
+}
+
+} // extern "C"

@@ -1,0 +1,230 @@
+"""Host-side objects over the C ABI (include/ntsynt_hip.h): Context, Genome, BloomFilter, sketch.
+
+Names follow the interfaces of the reference they stand in for:
+  KmerBloomFilter.insert / contains-cascade / get_fpr / save   (btllib, used by
+      src/ntsynt_make_common_bf.cpp:121-164)
+  Indexlr-style minimize() -> minimizers per record             (btllib `indexlr`, smk:81-85)
+All compute happens in libntsynt_hip.so on the GPU; there is no CPU path here."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import Interval, c_vp, u64
+
+
+class NtsError(RuntimeError):
+    pass
+
+
+class Context:
+    """One per GPU (owns a HIP stream)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = c_vp()
+        rc = self.lib.nts_init(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise NtsError(f"nts_init({device}) failed: {self.lib.nts_last_error(None).decode()} "
+                           "(a real MI355X is required; there is no CPU fallback)")
+        self.h = h
+        self.device = int(device)
+
+    def check(self, rc, what=""):
+        if rc != 0:
+            raise NtsError(f"{what}: {self.lib.nts_last_error(self.h).decode()} (code {rc})")
+
+    def sync(self):
+        self.check(self.lib.nts_sync(self.h), "nts_sync")
+
+    def profile(self, enable=True):
+        self.check(self.lib.nts_profile(self.h, 1 if enable else 0), "nts_profile")
+
+    def timing(self, name):
+        ms, n = ctypes.c_double(), u64()
+        self.check(self.lib.nts_timing(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(n)), "nts_timing")
+        return ms.value, n.value
+
+    def close(self):
+        if self.h:
+            self.lib.nts_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bf_size_bytes(genome_bp, fpr):
+    """(approx_bytes, ctor_bytes): src/ntsynt_make_common_bf.cpp:28-40 + btllib ctor rounding."""
+    a, c = u64(), u64()
+    rc = _lib.load().nts_bf_size_bytes(int(genome_bp), float(fpr), ctypes.byref(a), ctypes.byref(c))
+    if rc != 0:
+        raise NtsError("nts_bf_size_bytes: bad arguments")
+    return a.value, c.value
+
+
+class Genome:
+    """A FASTA resident in HBM.  names: record ids; seq: uint8 array of the concatenated bases."""
+
+    def __init__(self, ctx, names, seq, rec_off, rec_len):
+        self.ctx = ctx
+        self.names = list(names)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        self.rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        self.rec_len = np.ascontiguousarray(rec_len, dtype=np.uint64)
+        h = c_vp()
+        ctx.check(ctx.lib.nts_genome_upload(ctx.h, seq.ctypes.data, seq.size,
+                                            self.rec_off.ctypes.data_as(_lib.c_u64p),
+                                            self.rec_len.ctypes.data_as(_lib.c_u64p),
+                                            len(self.names), ctypes.byref(h)), "nts_genome_upload")
+        self.h = h
+
+    @property
+    def total_bp(self):
+        return int(self.ctx.lib.nts_genome_bases(self.h))
+
+    def valid_kmers(self, k):
+        n = u64()
+        self.ctx.check(self.ctx.lib.nts_genome_valid_kmers(self.ctx.h, self.h, k, ctypes.byref(n)), "valid_kmers")
+        return n.value
+
+    def hash_all(self, k):
+        "canonical h0 of every valid k-mer in (record, position) order (test hook, row B1)"
+        p, n = _lib.c_u64p(), u64()
+        self.ctx.check(self.ctx.lib.nts_hash_all(self.ctx.h, self.h, k, ctypes.byref(p), ctypes.byref(n)), "nts_hash_all")
+        out = np.ctypeslib.as_array(p, shape=(max(n.value, 1),))[:n.value].copy()
+        self.ctx.lib.nts_free(p)
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.nts_genome_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class BloomFilter:
+    """btllib::KmerBloomFilter(bytes, 1, k) stand-in, bit array in HBM."""
+
+    def __init__(self, ctx, nbytes, k):
+        self.ctx, self.k = ctx, k
+        h = c_vp()
+        ctx.check(ctx.lib.nts_bf_create(ctx.h, int(nbytes), ctypes.byref(h)), "nts_bf_create")
+        self.h = h
+        self.bytes = int(nbytes)
+
+    def insert(self, genome):
+        "bf->insert(record.seq) for every record (cpp:128-131)"
+        self.ctx.check(self.ctx.lib.nts_bf_insert(self.ctx.h, self.h, genome.h, self.k), "nts_bf_insert")
+
+    def cascade_from(self, prev, genome):
+        "`if prev.contains(h): self.insert(h)` over every k-mer of genome (cpp:145-153)"
+        self.ctx.check(self.ctx.lib.nts_bf_cascade(self.ctx.h, prev.h, self.h, genome.h, self.k), "nts_bf_cascade")
+
+    def and_(self, other):
+        self.ctx.check(self.ctx.lib.nts_bf_and(self.ctx.h, self.h, other.h), "nts_bf_and")
+
+    def clear(self):
+        self.ctx.check(self.ctx.lib.nts_bf_clear(self.ctx.h, self.h), "nts_bf_clear")
+
+    def popcount(self):
+        n = u64()
+        self.ctx.check(self.ctx.lib.nts_bf_popcount(self.ctx.h, self.h, ctypes.byref(n)), "nts_bf_popcount")
+        return n.value
+
+    def get_fpr(self):
+        "occupancy (one hash function), what the reference prints at cpp:132,154,162"
+        return self.popcount() / float(self.bytes * 8)
+
+    def device_ptr(self):
+        return int(self.ctx.lib.nts_bf_device_ptr(self.h))
+
+    def to_numpy(self):
+        out = np.empty(self.bytes, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.nts_bf_download(self.ctx.h, self.h, out.ctypes.data, self.bytes), "nts_bf_download")
+        return out
+
+    def from_numpy(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.nts_bf_upload(self.ctx.h, self.h, arr.ctypes.data, arr.size), "nts_bf_upload")
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.nts_bf_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Minimizers:
+    """Device-resident minimizer list of one genome, in (record, position) order."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def __len__(self):
+        return int(self.ctx.lib.nts_mx_count(self.h))
+
+    def to_numpy(self):
+        n = len(self)
+        h1 = np.empty(n, dtype=np.uint64)
+        rec = np.empty(n, dtype=np.uint32)
+        pos = np.empty(n, dtype=np.uint64)
+        if n:
+            self.ctx.check(self.ctx.lib.nts_mx_download(self.ctx.h, self.h, h1.ctypes.data, rec.ctypes.data,
+                                                        pos.ctypes.data), "nts_mx_download")
+        return h1, rec, pos
+
+    @classmethod
+    def from_numpy(cls, ctx, h1, rec, pos):
+        h1 = np.ascontiguousarray(h1, dtype=np.uint64)
+        rec = np.ascontiguousarray(rec, dtype=np.uint32)
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        h = c_vp()
+        ctx.check(ctx.lib.nts_mx_upload(ctx.h, h1.ctypes.data, rec.ctypes.data, pos.ctypes.data, h1.size,
+                                        ctypes.byref(h)), "nts_mx_upload")
+        return cls(ctx, h)
+
+    def device_ptrs(self):
+        a, b, c = c_vp(), c_vp(), c_vp()
+        self.ctx.lib.nts_mx_device_ptrs(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return a.value, b.value, c.value
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.nts_mx_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sketch(ctx, genome, k, w, bf=None, masks=None):
+    """`indexlr -k k -w w --long --pos [-s bf]` on the resident genome.  masks: iterable of
+    (record index, start, end) hard-mask intervals applied on the fly (refinement rounds)."""
+    n_mask, arr = 0, None
+    if masks is not None and len(masks):
+        n_mask = len(masks)
+        arr = (Interval * n_mask)()
+        for i, (r, s, e) in enumerate(masks):
+            arr[i].rec, arr[i].start, arr[i].end = int(r), int(s), int(e)
+    h = c_vp()
+    ctx.check(ctx.lib.nts_sketch(ctx.h, genome.h, int(k), int(w), bf.h if bf is not None else None,
+                                 arr, n_mask, ctypes.byref(h)), "nts_sketch")
+    return Minimizers(ctx, h)

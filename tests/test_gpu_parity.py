@@ -1,0 +1,204 @@
+"""HIP path vs CPU oracle, bit-exact, through the C ABI (rows A1-A4, B1-B3, B5).  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from oracle import nts_oracle as O
+from tests.helpers import oracle_flat, random_records, to_device, to_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ntsynt_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+LENGTHS = [30000, 0, 5, 23, 24, 25, 1023, 1024, 1500, 70001, 3, 12000]
+
+
+def _family(seed, lengths=LENGTHS, **kw):
+    rng = np.random.default_rng(seed)
+    seqs = random_records(rng, lengths, **kw)
+    names = [f"r{i}" for i in range(len(seqs))]
+    return names, seqs
+
+
+@pytest.mark.parametrize("k", [20, 24, 31, 64])
+def test_hash_all(ctx, k):
+    names, seqs = _family(10 + k)
+    dev = to_device(ctx, names, seqs)
+    got = dev.hash_all(k)
+    exp = np.concatenate([O.hash_all(s, k)[1] for s in seqs])
+    assert dev.valid_kmers(k) == exp.size
+    assert np.array_equal(got, exp)
+
+
+def test_bf_size_matches_oracle():
+    from ntsynt_amd.device import bf_size_bytes
+    for n in (1, 1000, 29058289, 10**8, 3 * 10**9):
+        for fpr in (0.025, 0.01, 0.3):
+            a, c = bf_size_bytes(n, fpr)
+            assert a == O.bf_approx_bytes(n, fpr)
+            assert c == O.bf_ctor_bytes(a)
+
+
+@pytest.mark.parametrize("k", [20, 24])
+def test_bloom_insert_cascade_and(ctx, k):
+    from ntsynt_amd.device import BloomFilter
+    fams = [_family(100 + i, lengths=[40000, 0, 9000, 17], n_frac=0.005) for i in range(3)]
+    # make them related so the common filter is not empty
+    base = fams[0][1]
+    rng = np.random.default_rng(5)
+    seqs_list = [base]
+    for j in (1, 2):
+        mut = []
+        for s in base:
+            a = np.frombuffer(s, dtype=np.uint8).copy()
+            hit = rng.random(a.size) < 0.01
+            a[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+            mut.append(a.tobytes())
+        seqs_list.append(mut)
+    names = fams[0][0]
+    og = [to_oracle(names, s) for s in seqs_list]
+    dg = [to_device(ctx, names, s) for s in seqs_list]
+    nbytes = O.bf_ctor_bytes(O.bf_approx_bytes(og[0].total_bp, 0.025))
+    # level 1
+    o1 = O.bf_build(og[0], k, nbytes)
+    d1 = BloomFilter(ctx, nbytes, k)
+    d1.insert(dg[0])
+    assert np.array_equal(d1.to_numpy(), o1)
+    assert d1.popcount() == O.bf_popcount(o1)
+    # literal cascade (cpp:134-160)
+    o_prev, d_prev = o1, d1
+    for j in (1, 2):
+        o_next = O.bf_build(og[j], k, nbytes, prev=o_prev)
+        d_next = BloomFilter(ctx, nbytes, k)
+        d_next.cascade_from(d_prev, dg[j])
+        assert np.array_equal(d_next.to_numpy(), o_next)
+        o_prev, d_prev = o_next, d_next
+    # AND of independent per-genome filters == cascade
+    acc = BloomFilter(ctx, nbytes, k)
+    acc.insert(dg[0])
+    for j in (1, 2):
+        gj = BloomFilter(ctx, nbytes, k)
+        gj.insert(dg[j])
+        acc.and_(gj)
+    assert np.array_equal(acc.to_numpy(), o_prev)
+    assert abs(acc.get_fpr() - O.bf_fpr(o_prev)) < 1e-15
+    # upload / download round trip
+    rt = BloomFilter(ctx, nbytes, k)
+    rt.from_numpy(o_prev)
+    assert rt.popcount() == O.bf_popcount(o_prev)
+
+
+@pytest.mark.parametrize("k,w", [(24, 1000), (24, 100), (20, 10), (24, 1), (32, 17), (24, 16), (24, 15),
+                                 (24, 4097), (20, 250)])
+def test_sketch_no_filter(ctx, k, w):
+    from ntsynt_amd.device import sketch
+    names, seqs = _family(1000 + w)
+    og, dg = to_oracle(names, seqs), to_device(ctx, names, seqs)
+    exp = oracle_flat(O.minimize(og, k, w))
+    got = sketch(ctx, dg, k, w).to_numpy()
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b.astype(a.dtype))
+
+
+@pytest.mark.parametrize("k,w,fpr", [(24, 1000, 0.025), (24, 100, 0.025), (20, 10, 0.3), (24, 250, 0.9)])
+def test_sketch_with_filter(ctx, k, w, fpr):
+    "filter-in Bloom filter (indexlr -s): rejected k-mers take the UINT64_MAX sentinel"
+    from ntsynt_amd.device import BloomFilter, sketch
+    names, seqs = _family(2000 + w, lengths=[60000, 300, 0, 20000], n_frac=0.003)
+    rng = np.random.default_rng(w)
+    other = []
+    for s in seqs:
+        a = np.frombuffer(s, dtype=np.uint8).copy()
+        hit = rng.random(a.size) < 0.02
+        a[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+        # a long stretch unique to this genome: windows there hold only rejected k-mers
+        if a.size > 30000:
+            a[5000:12000] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=7000)]
+        other.append(a.tobytes())
+    og = [to_oracle(names, seqs), to_oracle(names, other)]
+    dg = [to_device(ctx, names, seqs), to_device(ctx, names, other)]
+    nbytes = O.bf_ctor_bytes(O.bf_approx_bytes(og[0].total_bp, fpr))
+    obf = O.bf_build(og[1], k, nbytes, prev=O.bf_build(og[0], k, nbytes))
+    dbf = BloomFilter(ctx, nbytes, k)
+    dbf.insert(dg[0])
+    tmp = BloomFilter(ctx, nbytes, k)
+    tmp.insert(dg[1])
+    dbf.and_(tmp)
+    assert np.array_equal(dbf.to_numpy(), obf)
+    for o, d in zip(og, dg):
+        exp = oracle_flat(O.minimize(o, k, w, obf))
+        got = sketch(ctx, d, k, w, dbf).to_numpy()
+        assert len(exp[0]) > 0
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b.astype(a.dtype))
+
+
+@pytest.mark.parametrize("w", [100, 10])
+def test_sketch_masked(ctx, w):
+    "refinement re-sketch (B5): masks applied on the resident genome == indexlr on the N-masked FASTA"
+    from ntsynt_amd.device import sketch
+    k = 24
+    names, seqs = _family(3000 + w, lengths=[80000, 40000, 100, 0])
+    masks = [(0, 1100, 30000), (0, 31000, 31010), (0, 50000, 79990), (1, 0, 500), (1, 20000, 60000), (2, 10, 20),
+             (0, 29000, 29500)]
+    masked = []
+    for i, s in enumerate(seqs):
+        b = bytearray(s)
+        for r, st, en in masks:
+            if r == i:
+                en = min(en, len(b))
+                b[st:en] = b"N" * max(0, en - st)
+        masked.append(bytes(b))
+    exp = oracle_flat(O.minimize(to_oracle(names, masked), k, w))
+    dg = to_device(ctx, names, seqs)
+    got = sketch(ctx, dg, k, w, None, masks).to_numpy()
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b.astype(a.dtype))
+    # and the unmasked sketch of the same handle is unaffected by the masked call
+    exp0 = oracle_flat(O.minimize(to_oracle(names, seqs), k, w))
+    got0 = sketch(ctx, dg, k, w).to_numpy()
+    for a, b in zip(got0, exp0):
+        assert np.array_equal(a, b.astype(a.dtype))
+
+
+def test_sketch_ties_and_monotone(ctx):
+    "homopolymer / low-complexity records: many equal hashes (rightmost-minimum rule) and long runs"
+    from ntsynt_amd.device import sketch
+    seqs = [b"A" * 5000, b"AC" * 4000, b"ACGT" * 3000 + b"N" + b"TTTT" * 2000, b"G" * 30 + b"N" * 10 + b"C" * 2000]
+    names = [f"t{i}" for i in range(len(seqs))]
+    og, dg = to_oracle(names, seqs), to_device(ctx, names, seqs)
+    for k, w in ((24, 100), (20, 1000), (24, 7)):
+        exp = oracle_flat(O.minimize(og, k, w))
+        got = sketch(ctx, dg, k, w).to_numpy()
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b.astype(a.dtype))
+
+
+def test_sketch_large_properties(ctx):
+    "size-independent properties at 40 Mbp: ordering, gap <= w in valid-k-mer space, idempotence"
+    from ntsynt_amd.device import sketch
+    rng = np.random.default_rng(77)
+    seqs = random_records(rng, [25_000_000, 15_000_000], n_frac=0.0, lower_frac=0.0)
+    names = ["a", "b"]
+    dg = to_device(ctx, names, seqs)
+    k, w = 24, 1000
+    h1, rec, pos = sketch(ctx, dg, k, w).to_numpy()
+    assert h1.size > 2 * 40_000_000 // (w + 1) * 0.9
+    for r in (0, 1):
+        p = pos[rec == r].astype(np.int64)
+        assert (np.diff(p) > 0).all()
+        assert np.diff(p).max() <= w and p[0] < w and (len(seqs[r]) - k - p[-1]) < w
+    h1b, recb, posb = sketch(ctx, dg, k, w).to_numpy()
+    assert np.array_equal(h1, h1b) and np.array_equal(pos, posb)
+    # spot-check against the oracle on a 300 kbp slice boundary-free region: whole record 1 prefix
+    sub = seqs[1][:300000]
+    exp = O.minimize(O.Genome(["s"], [sub]), k, w)[0]
+    m = (rec == 1) & (pos < 300000 - k - w)
+    n = int(m.sum())
+    assert np.array_equal(pos[m], exp[1][:n]) and np.array_equal(h1[m], exp[0][:n])
