@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- minimizer-sketch throughput of the HIP hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the sketch (canonical ntHash + common-Bloom probe + window-of-w argmin,
+rows B1-B3) over the rank's batch of synthetic genomes, which are resident in HBM (together with
+the common Bloom filter) before the timed region starts; for N>1 the step ends with the all-gather
+of the minimizer lists (SURVEY.md 8(e) exchange 2).  Weak scaling: every rank holds its own
+`--genomes` genomes of one family of N*genomes genomes; the common Bloom filter is the AND over the
+whole family (exchange 1, timed separately and reported under "bloom").
+
+N=1 workload = BASELINE.json configs[1]: 3 synthetic 100 Mbp genomes at 1 % divergence, k=24 w=1000.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_BASE = 1.0 + 64.0 + 32.0 / 1001.0   # sketch-with-filter, w=1000
+HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genomes", type=int, default=3, help="genomes per GPU")
+    ap.add_argument("--mbp", type=float, default=100.0, help="Mbp per genome")
+    ap.add_argument("--contigs", type=int, default=4)
+    ap.add_argument("--divergence", type=float, default=0.01)
+    ap.add_argument("-k", type=int, default=24)
+    ap.add_argument("-w", type=int, default=1000)
+    ap.add_argument("--fpr", type=float, default=0.025)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mbp", type=float, default=64.0)
+    return ap.parse_args()
+
+
+def upload(ctx, contigs):
+    from ntsynt_amd.device import Genome
+    lens = np.array([c.size for c in contigs], dtype=np.uint64)
+    off = np.concatenate(([0], np.cumsum(lens[:-1]))).astype(np.uint64)
+    return Genome(ctx, [f"chr{i + 1}" for i in range(len(contigs))], np.concatenate(contigs), off, lens)
+
+
+def cpu_baseline(args, contigs, bf_np):
+    """The CPU oracle (a port of btllib's algorithm class: rolling ntHash, ring-buffer window
+    minimum, Bloom probe per k-mer) on the box's host cores, on a bounded sample of the workload."""
+    from oracle import nts_oracle as O
+    try:
+        O.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    cores = os.cpu_count() or 1
+    # genome 0 cut into one record per core (windows do not cross records, so this is the same
+    # algorithm on `cores` independent pieces); repeated until >= ~8 s of wall time have elapsed
+    whole = np.concatenate(contigs)
+    per = max(whole.size // cores, 4 * args.w)
+    seqs = [whole[i:i + per].tobytes() for i in range(0, whole.size - per + 1, per)]
+    g = O.Genome([f"s{i}" for i in range(len(seqs))], seqs)
+    O.minimize(g, args.k, args.w, bf_np, threads=cores, native=native)   # warm-up (page in, spawn threads)
+    done, t = 0, time.time()
+    while time.time() - t < 8.0:
+        O.minimize(g, args.k, args.w, bf_np, threads=cores, native=native)
+        done += g.total_bp
+    dt = time.time() - t
+    return {"value": round(done / dt / 1e9, 4), "unit": "Gbases/s", "cores": cores, "kind": "port",
+            "sample": f"genome 0 ({g.total_bp / 1e6:.0f} Mbp) as {len(seqs)} records, one per thread (OpenMP), "
+                      f"sketch with the same common Bloom filter, {done // g.total_bp} passes in {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    from ntsynt_amd import dist as ndist
+    from ntsynt_amd import synth
+    from ntsynt_amd.device import (BloomFilter, Context, and_raw, bf_size_bytes, export_minimizers, sketch,
+                                   wrap_bloom)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = Context(local_rank)
+    k, w = args.k, args.w
+    total_bp = int(args.mbp * 1e6)
+
+    # ---- synthetic family: rank r owns genomes r*G .. r*G+G-1 ------------------------------------
+    anc = synth.make_ancestor(total_bp, args.contigs)
+    mine = list(range(rank * args.genomes, (rank + 1) * args.genomes))
+    host = [synth.derive_genome(anc, args.divergence, j) for j in mine]
+    genomes = [upload(ctx, g) for g in host]
+    bases = sum(g.total_bp for g in genomes)
+
+    # ---- common Bloom filter: per-genome filters, local AND, AND-all-reduce over ranks --------------
+    # sized from genome 0 of the family (the lexicographically first file, cpp:105-118): same on all ranks
+    _, nbytes = bf_size_bytes(total_bp // args.contigs * args.contigs, args.fpr)
+    ctx.profile(True)
+    t0 = time.time()
+    if world > 1:
+        buf = torch.zeros(ndist.padded_len(nbytes, world), dtype=torch.uint8, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        common = wrap_bloom(ctx, buf, nbytes, k)
+    else:
+        common = BloomFilter(ctx, nbytes, k)
+    common.insert(genomes[0])
+    tmp = BloomFilter(ctx, nbytes, k)
+    for g in genomes[1:]:
+        tmp.clear()
+        tmp.insert(g)
+        common.and_(tmp)
+    ctx.sync()
+    t_build = time.time() - t0
+    t_allreduce = 0.0
+    if world > 1:
+        t1 = time.time()
+
+        def and_into(a, b):
+            and_raw(ctx, a.data_ptr(), b.data_ptr(), a.numel())
+            ctx.sync()
+        ndist.allreduce_and(buf, and_into)
+        torch.cuda.synchronize()
+        t_allreduce = time.time() - t1
+    tmp.free()
+    ins_ms, ins_n = ctx.timing("bf_insert")
+    fpr_final = common.get_fpr()
+
+    def gather(mxs):
+        if world == 1:
+            return
+        for gi, mx in zip(mine, mxs):
+            n = len(mx)
+            dev = f"cuda:{local_rank}"
+            h1 = torch.empty(n, dtype=torch.int64, device=dev)
+            rec = torch.empty(n, dtype=torch.int32, device=dev)
+            pos = torch.empty(n, dtype=torch.int64, device=dev)
+            export_minimizers(ctx, mx, h1.data_ptr(), rec.data_ptr(), pos.data_ptr())
+            ndist.allgather_lists(h1, rec, pos, gi)
+
+    def step():
+        mxs = [sketch(ctx, g, k, w, common) for g in genomes]
+        gather(mxs)
+        n = sum(len(m) for m in mxs)
+        for m in mxs:
+            m.free()
+        return n
+
+    def fence():
+        ctx.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile(True)
+    fence()
+    t0 = time.time()
+    n_mx = 0
+    for _ in range(args.steps):
+        n_mx = step()
+    fence()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    hp_ms, hp_n = ctx.timing("hash_probe")
+    wm_ms, wm_n = ctx.timing("window_min")
+    st_ms, st_n = ctx.timing("sort_minimizers")
+    fz_ms, fz_n = ctx.timing("finalize")
+    # outside the timed region: the same sketch without the Bloom probe (ALU + streaming only)
+    sketch(ctx, genomes[0], k, w, None).free()
+    ctx.profile(True)
+    sketch(ctx, genomes[0], k, w, None).free()
+    ho_ms, ho_n = ctx.timing("hash_only")
+
+    if rank == 0:
+        value = bases * world * args.steps / dt / 1e9
+        per_launch_bases = bases / len(genomes)
+        avg_ms = hp_ms / max(hp_n, 1)
+        achieved = ALGO_BYTES_PER_BASE * per_launch_bases / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "minimizer-sketch Gbases/s (sketch with common Bloom filter, inputs resident in HBM)",
+            "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{args.genomes} synthetic {args.mbp:g} Mbp genomes per GPU at "
+                                   f"{args.divergence * 100:g}% divergence, k={k} w={w} fpr={args.fpr}",
+                       "genomes_per_gpu": args.genomes, "bases_per_step_per_gpu": bases,
+                       "minimizers_per_step_per_gpu": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)"},
+            "roofline": {"bound": "hbm", "kernel": "k_hash<MODE_KEYS> (hash_probe)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_base": round(ALGO_BYTES_PER_BASE, 3),
+                         "avg_launch_ms": round(avg_ms, 4), "launches": hp_n,
+                         "window_min_avg_ms": round(wm_ms / max(wm_n, 1), 4),
+                         "sort_avg_ms": round(st_ms / max(st_n, 1), 4),
+                         "finalize_avg_ms": round(fz_ms / max(fz_n, 1), 4),
+                         "hash_without_probe_avg_ms": round(ho_ms / max(ho_n, 1), 4)},
+            "bloom": {"bytes": nbytes, "build_s": round(t_build, 4), "allreduce_and_s": round(t_allreduce, 4),
+                      "bf_insert_avg_ms": round(ins_ms / max(ins_n, 1), 4),
+                      "bf_insert_Gbases_s": round(per_launch_bases / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 3)
+                      if ins_ms > 0 else None,
+                      "occupancy": round(fpr_final, 6)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, host[0], common.to_numpy())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

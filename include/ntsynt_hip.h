@@ -98,6 +98,14 @@ int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other);
 int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set);
 int nts_bf_download(nts_ctx* ctx, const nts_bf* bf, uint8_t* host, uint64_t bytes);
 int nts_bf_upload(nts_ctx* ctx, nts_bf* bf, const uint8_t* host, uint64_t bytes);
+/* Non-owning filter over caller-provided HBM (e.g. the buffer a collective runs on): `device_ptr` must be
+ * 16-byte aligned and hold `bytes` rounded up to a multiple of 16, the tail zeroed.  nts_bf_free() on a
+ * wrapped filter releases only the handle. */
+int nts_bf_wrap(nts_ctx* ctx, void* device_ptr, uint64_t bytes, nts_bf** out);
+/* acc &= other on raw device buffers (bytes a multiple of 16): the local reduction step of the
+ * bitwise-AND all-reduce of per-genome filters across GPUs (SURVEY.md 8(e) exchange 1; RCCL has no
+ * bitwise reduction). */
+int nts_and_raw(nts_ctx* ctx, void* acc_dev, const void* other_dev, uint64_t bytes);
 
 /* ---- B1-B3, B5: minimizer sketch -----------------------------------------------------------------
  * replaces `indexlr -k K -w W --long --pos -s common.bf genome.fa` (smk:81-85) and the re-sketch of
@@ -118,6 +126,8 @@ void nts_mx_free(nts_ctx* ctx, nts_mx* mx);
 int nts_mx_download(nts_ctx* ctx, const nts_mx* mx, uint64_t* h1, uint32_t* rec, uint64_t* pos);
 /* device pointers (for an all-gather over RCCL): arrays of nts_mx_count() elements */
 int nts_mx_device_ptrs(const nts_mx* mx, void** h1, void** rec, void** pos);
+/* device-to-device copy into caller buffers of nts_mx_count() elements (send side of the all-gather) */
+int nts_mx_export(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, void* pos_dev);
 /* build a device list from host arrays (receiving side of the all-gather, tests) */
 int nts_mx_upload(nts_ctx* ctx,
                   const uint64_t* h1,

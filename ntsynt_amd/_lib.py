@@ -52,6 +52,9 @@ SYMBOLS = [
     ("nts_bf_popcount", ctypes.c_int, [c_vp, c_vp, c_u64p]),
     ("nts_bf_download", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
     ("nts_bf_upload", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
+    ("nts_bf_wrap", ctypes.c_int, [c_vp, c_vp, u64, ctypes.POINTER(c_vp)]),
+    ("nts_and_raw", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
+    ("nts_mx_export", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("nts_sketch", ctypes.c_int, [c_vp, c_vp, u32, u32, c_vp, ctypes.POINTER(Interval), u64,
                                   ctypes.POINTER(c_vp)]),
     ("nts_mx_count", u64, [c_vp]),

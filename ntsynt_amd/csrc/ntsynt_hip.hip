@@ -57,6 +57,8 @@ struct nts_ctx
   bool profiling = false;
   std::map<std::string, Timing> timings;
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  // grow-only device scratch, reused across calls (a ctx serves one call at a time)
+  std::map<std::string, std::pair<void*, size_t>> ws;
 };
 
 struct nts_genome
@@ -74,6 +76,7 @@ struct nts_bf
 {
   uint64_t bytes = 0;
   uint32_t* d_words = nullptr;
+  bool owned = true;
 };
 
 struct nts_mx
@@ -99,6 +102,41 @@ int fail(nts_ctx* ctx, int code, const std::string& msg)
 {
   if (ctx) ctx->err = msg;
   return code;
+}
+
+// device scratch buffer `name` of at least `bytes` bytes (nullptr + ctx->err on failure)
+void* ws_get(nts_ctx* ctx, const char* name, size_t bytes)
+{
+  auto& b = ctx->ws[name];
+  if (b.second >= bytes && b.first) return b.first;
+  if (b.first) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(b.first);
+    b.first = nullptr;
+    b.second = 0;
+  }
+  const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    e = hipMalloc(&p, std::max<size_t>(bytes, 256));
+    if (e != hipSuccess) {
+      ctx->err = std::string("hipMalloc scratch '") + name + "': " + hipGetErrorString(e);
+      return nullptr;
+    }
+    b.second = std::max<size_t>(bytes, 256);
+  } else {
+    b.second = want;
+  }
+  b.first = p;
+  return p;
+}
+
+void ws_release(nts_ctx* ctx)
+{
+  for (auto& kv : ctx->ws)
+    if (kv.second.first) hipFree(kv.second.first);
+  ctx->ws.clear();
 }
 
 // ---- timing: HIP events on the context's stream around each kernel ---------------------------
@@ -209,13 +247,45 @@ __global__ __launch_bounds__(256) void k_stretch(const uint8_t* __restrict__ cod
 }
 
 // ---- canonical ntHash over the compact k-mer numbering ------------------------------------------
-// Each lane owns HASH_PER_THREAD consecutive compact indices: it locates the run holding the first
-// one (binary search in the run table), hashes that k-mer directly (k steps) and rolls on, starting
-// over at run boundaries.
-//   MODE 0: keys[j] = h0, or KEY_MAX if a filter is given and rejects h0   (sketch, rows B1+B2)
-//   MODE 1: bf_out |= bit(h0)                                               (row A2)
-//   MODE 2: if bf_in has bit(h0): bf_out |= bit(h0)                         (row A3, literal)
+// A workgroup owns KEY_TILE = 256 lanes x 32 consecutive compact indices.  Fast path (the whole tile
+// lies in one run, k <= FAST_K_MAX): the tile's bases are staged into LDS with coalesced 16-byte
+// loads, in a layout padded by 4 bytes per 32 (lane stride 36 B => conflict-free byte reads); each
+// lane hashes its first k-mer directly and rolls 31 times.  Bloom probes are issued in batches of 8
+// independent loads per lane to keep many HBM requests in flight.  Generic path (tile spans runs, as
+// in the masked refinement rounds, or huge k): every lane walks the run table itself.
+//   MODE_KEYS   : keys[phys(j)] = h0, or KEY_MAX if a filter is given and rejects h0   (rows B1+B2)
+//   MODE_INSERT : bf_out |= bit(h0)                                                   (row A2)
+//   MODE_CASCADE: if bf_in has bit(h0): bf_out |= bit(h0)                             (row A3, literal)
+// Key layout in HBM is tile-transposed so that both this kernel's stores and the window kernel's loads
+// coalesce: phys(j) = tile*8192 + (j%32)*256 + (j%8192)/32.
 enum { MODE_KEYS = 0, MODE_INSERT = 1, MODE_CASCADE = 2 };
+constexpr uint32_t KEY_TILE = HASH_THREADS * HASH_PER_THREAD; // 8192
+constexpr uint32_t FAST_K_MAX = 128;
+constexpr uint32_t SEQ_LDS_DWORDS = 2400; // (15 + 8192 + 127) bytes in the padded layout, rounded up
+static_assert(HASH_PER_THREAD == 32 && HASH_THREADS == 256, "key layout assumes 256 x 32 tiles");
+
+__host__ __device__ __forceinline__ uint64_t key_phys(uint64_t j)
+{
+  const uint64_t tile = j / KEY_TILE;
+  const uint32_t r = (uint32_t)(j % KEY_TILE);
+  return tile * KEY_TILE + (uint64_t)(r & 31u) * 256u + (r >> 5);
+}
+
+template <int MODE>
+__device__ __forceinline__ void hash_emit(uint64_t h0, bool live, uint64_t phys, const uint32_t* __restrict__ bf_in,
+                                          uint32_t* __restrict__ bf_out, const FastMod& fm, uint64_t* __restrict__ keys)
+{
+  if (MODE == MODE_KEYS) {
+    uint64_t key = h0;
+    if (bf_in != nullptr && !bf_test(bf_in, fm(h0))) key = KEY_MAX;
+    if (live) keys[phys] = key;
+  } else if (MODE == MODE_INSERT) {
+    if (live) bf_set(bf_out, fm(h0));
+  } else {
+    const uint64_t idx = fm(h0);
+    if (live && bf_test(bf_in, idx)) bf_set(bf_out, idx);
+  }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict__ code,
@@ -230,18 +300,97 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
                                                        uint64_t* __restrict__ keys)
 {
   __shared__ uint64_t s_tab[36];
-  if (threadIdx.x < 16) {
-    s_tab[threadIdx.x] = hp.roll_f[threadIdx.x];
-    s_tab[16 + threadIdx.x] = hp.roll_r[threadIdx.x];
+  __shared__ uint32_t s_seq[SEQ_LDS_DWORDS];
+  const uint32_t tid = threadIdx.x;
+  if (tid < 16) {
+    s_tab[tid] = hp.roll_f[tid];
+    s_tab[16 + tid] = hp.roll_r[tid];
   }
-  if (threadIdx.x < 4) s_tab[32 + threadIdx.x] = hp.seed[threadIdx.x];
-  __syncthreads();
+  if (tid < 4) s_tab[32 + tid] = hp.seed[tid];
   const uint32_t k = hp.k;
-  uint64_t j = ((uint64_t)blockIdx.x * HASH_THREADS + threadIdx.x) * HASH_PER_THREAD;
+  const uint64_t J0 = (uint64_t)blockIdx.x * KEY_TILE;
+  const uint32_t tile_len = (uint32_t)min((uint64_t)KEY_TILE, n_valid - J0);
+  // run holding J0 (same for every lane: broadcast loads)
+  uint32_t lo = 0, hi = n_runs;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (run_vstart[mid] <= J0)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const uint64_t v0 = run_vstart[lo], v1 = run_vstart[lo + 1];
+  const bool single = (J0 + tile_len <= v1) && (k <= FAST_K_MAX);
+  if (single) {
+    // ---- fast path --------------------------------------------------------------------------------
+    const uint64_t P0 = run_pos[lo] + (J0 - v0);
+    const uint32_t a = (uint32_t)(P0 & 15u);
+    const uint8_t* src = code + (P0 - a);
+    const uint32_t n_bytes = a + tile_len + k - 1;
+    const uint32_t n16 = (n_bytes + 15u) >> 4;
+    for (uint32_t c = tid; c < n16; c += HASH_THREADS) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + 16u * c);
+      const uint32_t d = 4u * c + (c >> 1);
+      s_seq[d] = v.x;
+      s_seq[d + 1] = v.y;
+      s_seq[d + 2] = v.z;
+      s_seq[d + 3] = v.w;
+    }
+    __syncthreads();
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_seq);
+    auto base_at = [&](uint32_t s) -> uint32_t { return sb[s + 4u * (s >> 5)] & 3u; };
+    const uint32_t first = 32u * tid;
+    const uint32_t n_mine = first < tile_len ? min(32u, tile_len - first) : 0u;
+    uint32_t s = a + first;
+    uint64_t f = 0, r = 0;
+    if (n_mine) {
+      for (uint32_t i = 0; i < k; ++i) {
+        f = srol1(f) ^ s_tab[32 + base_at(s + i)];
+        r = srol1(r) ^ s_tab[32 + 3 - base_at(s + k - 1 - i)];
+      }
+    }
+    const uint64_t out_base = J0 + tid;
+#pragma unroll 1
+    for (uint32_t b0 = 0; b0 < 32; b0 += 8) {
+      uint64_t h[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        h[u] = f + r;
+        const uint32_t cout = base_at(s), cin = base_at(s + k);
+        f = srol1(f) ^ s_tab[cin * 4 + cout];
+        r = sror1(r ^ s_tab[16 + cin * 4 + cout]);
+        ++s;
+      }
+      if (MODE == MODE_KEYS) {
+        if (bf_in != nullptr) {
+          uint32_t wd[8], bit[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const uint64_t idx = fm(h[u]);
+            wd[u] = bf_in[idx >> 5];
+            bit[u] = (uint32_t)idx & 31u;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (!((wd[u] >> bit[u]) & 1u)) h[u] = KEY_MAX;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (b0 + u < n_mine) keys[out_base + (uint64_t)(b0 + u) * 256u] = h[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hash_emit<MODE>(h[u], b0 + u < n_mine, 0, bf_in, bf_out, fm, keys);
+      }
+    }
+    return;
+  }
+  // ---- generic path ---------------------------------------------------------------------------------
+  __syncthreads();
+  uint64_t j = J0 + 32ull * tid;
   if (j >= n_valid) return;
   const uint64_t j_end = min(j + (uint64_t)HASH_PER_THREAD, n_valid);
-  // largest ri with run_vstart[ri] <= j
-  uint32_t lo = 0, hi = n_runs;
+  lo = 0;
+  hi = n_runs;
   while (hi - lo > 1) {
     const uint32_t mid = lo + ((hi - lo) >> 1);
     if (run_vstart[mid] <= j)
@@ -251,27 +400,16 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
   }
   uint32_t ri = lo;
   while (j < j_end) {
-    const uint64_t v0 = run_vstart[ri], v1 = run_vstart[ri + 1];
-    const uint64_t seg_end = min(j_end, v1);
-    uint64_t p = run_pos[ri] + (j - v0);
-    // direct hash of the k-mer at p
+    const uint64_t rv0 = run_vstart[ri], rv1 = run_vstart[ri + 1];
+    const uint64_t seg_end = min(j_end, rv1);
+    uint64_t p = run_pos[ri] + (j - rv0);
     uint64_t f = 0, r = 0;
     for (uint32_t i = 0; i < k; ++i) {
       f = srol1(f) ^ s_tab[32 + code[p + i]];
       r = srol1(r) ^ s_tab[32 + 3 - code[p + k - 1 - i]];
     }
     for (;;) {
-      const uint64_t h0 = f + r;
-      if (MODE == MODE_KEYS) {
-        uint64_t key = h0;
-        if (bf_in != nullptr && !bf_test(bf_in, fm(h0))) key = KEY_MAX;
-        keys[j] = key;
-      } else if (MODE == MODE_INSERT) {
-        bf_set(bf_out, fm(h0));
-      } else {
-        const uint64_t idx = fm(h0);
-        if (bf_test(bf_in, idx)) bf_set(bf_out, idx);
-      }
+      hash_emit<MODE>(f + r, true, key_phys(j), bf_in, bf_out, fm, keys);
       ++j;
       if (j >= seg_end) break;
       const uint32_t cout = code[p], cin = code[p + k];
@@ -283,16 +421,26 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
   }
 }
 
+// plain (untransposed) copy of the keys, for the nts_hash_all test hook
+__global__ __launch_bounds__(256) void k_keys_linear(const uint64_t* __restrict__ keys, uint64_t n, uint64_t* __restrict__ out)
+{
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) out[j] = keys[key_phys(j)];
+}
+
 // ---- window-of-w rightmost argmin over the compact keys of one record ------------------------------
-// A workgroup owns WIN_TILE consecutive windows of one record.  Elements are cut into chunks of c =
-// min(16, w); per chunk a lane computes prefix / suffix argmins sequentially, a sparse table over the
-// chunk minima answers the run of whole chunks in between, so every window costs O(1) LDS reads.
-// "Better" = smaller key, ties to the larger index (btllib's `<=` rescan keeps the rightmost minimum).
-// A window's winner is emitted when it differs from the previous window's winner (the sequence of
-// winners is non-decreasing in position) and its key is not KEY_MAX.
+// A workgroup owns WIN_TILE consecutive windows of one record; it loads the E = windows + w - 1 keys it
+// needs into LDS (un-transposing the key layout on the way; LDS index e + e/32 keeps both the
+// transposing stores and the later strided reads conflict-free).  Per chunk of c = min(16, w) keys a
+// lane finds the chunk's argmin; a sparse table over the chunk argmins answers "whole chunks" ranges.
+// Each lane then walks its contiguous slice of windows the way a sequential scan would: one full
+// range query for its first window, then O(1) per window (the new key replaces the winner if it is
+// <=, btllib's rightmost-minimum rule); only when the winner slides out of the window is the range
+// query repeated.  A winner is emitted when it differs from the previous window's winner and its key
+// is not KEY_MAX.
 struct WinParams
 {
-  const uint64_t* keys;       // compact keys
+  const uint64_t* keys;       // compact keys, tile-transposed (key_phys)
   const uint64_t* rec_vstart; // [n_rec] compact index of the record's first valid k-mer
   const uint64_t* rec_nv;     // [n_rec] valid k-mers in the record
   const uint64_t* tile_start; // [n_rec+1] prefix sum of tiles per record
@@ -300,15 +448,22 @@ struct WinParams
   uint32_t w;
   uint32_t chunk;
   uint32_t levels;            // sparse-table levels
-  uint64_t* out_j;            // compact index of each emitted minimizer
-  uint64_t* out_key;          // its key (= h0)
-  unsigned long long* out_count;
-  uint64_t out_cap;
+  uint64_t* out_j;            // compact index of each emitted minimizer: N_SEG segments of seg_cap slots,
+  uint64_t* out_key;          // its key (= h0)                          pre-filled with ~0 (sorts last)
+  unsigned long long* seg_count; // [N_SEG] slots reserved per segment (one returning atomic per workgroup)
+  uint64_t seg_cap;
 };
+constexpr uint32_t N_SEG = 64;
 
+__device__ __forceinline__ uint32_t pe(uint32_t e)
+{
+  return e + (e >> 5);
+}
+
+// smaller key wins, ties to the larger index
 __device__ __forceinline__ uint32_t better_idx(const uint64_t* s_key, uint32_t a, uint32_t b)
 {
-  const uint64_t ka = s_key[a], kb = s_key[b];
+  const uint64_t ka = s_key[pe(a)], kb = s_key[pe(b)];
   if (ka < kb) return a;
   if (kb < ka) return b;
   return a > b ? a : b;
@@ -317,7 +472,6 @@ __device__ __forceinline__ uint32_t better_idx(const uint64_t* s_key, uint32_t a
 __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // block -> (record, tile)
   uint32_t lo = 0, hi = P.n_rec;
   const uint64_t b = blockIdx.x;
   while (hi - lo > 1) {
@@ -340,39 +494,47 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
   const uint32_t n_chunks = (E + c - 1) / c;
 
   uint64_t* s_key = reinterpret_cast<uint64_t*>(smem);
-  uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_key + E);
-  uint16_t* s_suf = s_pre + E;
-  uint16_t* s_st = s_suf + E; // levels x n_chunks
+  uint32_t* s_ctl = reinterpret_cast<uint32_t*>(s_key + pe(E) + 1); // [0] emitted count, [1..2] reserved base
+  uint16_t* s_list = reinterpret_cast<uint16_t*>(s_ctl + 4);         // winners of this tile (<= n_win)
+  uint16_t* s_st = s_list + ((n_win + 8) & ~7u);                     // levels x n_chunks
+  if (threadIdx.x == 0) s_ctl[0] = 0;
 
-  const uint64_t* gk = P.keys + P.rec_vstart[rec] + tf;
-  for (uint32_t e = threadIdx.x; e < E; e += WIN_THREADS) s_key[e] = gk[e];
+  // ---- load: walk the key tiles the range [ja, jb) touches, one transposed row at a time -----------
+  const uint64_t ja = P.rec_vstart[rec] + tf, jb = ja + E;
+  for (uint64_t tile = ja / KEY_TILE; tile * KEY_TILE < jb; ++tile) {
+    const uint64_t tb = tile * KEY_TILE;
+    const uint32_t r_lo = (uint32_t)(max(ja, tb) - tb);
+    const uint32_t r_hi = (uint32_t)(min(jb, tb + KEY_TILE) - 1 - tb);
+    const uint32_t col_lo = r_lo >> 5, col_hi = r_hi >> 5;
+    const uint32_t col = col_lo + threadIdx.x;
+    if (col <= col_hi) {
+      const uint64_t* g = P.keys + tb + col;
+      const int64_t e0 = (int64_t)(tb + 32ull * col) - (int64_t)ja; // element index of row 0
+      uint64_t v[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) v[i] = g[(uint64_t)i * 256u];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const int64_t e = e0 + i;
+        if (e >= 0 && e < (int64_t)E) s_key[pe((uint32_t)e)] = v[i];
+      }
+    }
+  }
   __syncthreads();
 
+  // ---- chunk argmins + sparse table ------------------------------------------------------------------
   for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += WIN_THREADS) {
     const uint32_t a = ch * c, z = min(a + c, E);
     uint32_t cur = a;
-    uint64_t kc = s_key[a];
-    s_pre[a] = (uint16_t)a;
+    uint64_t kc = s_key[pe(a)];
     for (uint32_t e = a + 1; e < z; ++e) {
-      const uint64_t ke = s_key[e];
+      const uint64_t ke = s_key[pe(e)];
       if (ke <= kc) {
         kc = ke;
         cur = e;
       }
-      s_pre[e] = (uint16_t)cur;
     }
     s_st[ch] = (uint16_t)cur;
-    cur = z - 1;
-    kc = s_key[cur];
-    s_suf[cur] = (uint16_t)cur;
-    for (uint32_t e = z - 1; e-- > a;) {
-      const uint64_t ke = s_key[e];
-      if (ke < kc) {
-        kc = ke;
-        cur = e;
-      }
-      s_suf[e] = (uint16_t)cur;
-    }
   }
   __syncthreads();
   for (uint32_t L = 1; L < P.levels; ++L) {
@@ -384,43 +546,80 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
     __syncthreads();
   }
 
-  // windows: lane handles a contiguous slice so it can compare with the previous winner
-  const uint32_t per = (n_win + WIN_THREADS - 1) / WIN_THREADS;
-  const uint32_t w_lo = threadIdx.x * per;
-  const uint32_t w_hi = min(w_lo + per, n_win);
-  auto winner = [&](uint32_t e) -> uint32_t {
+  // rightmost argmin of elements [e, e+w-1]
+  auto range_query = [&](uint32_t e) -> uint32_t {
     const uint32_t last = e + w - 1;
     const uint32_t ca = e / c, cb = last / c;
-    uint32_t best = s_suf[e];
+    uint32_t best = e;
+    uint64_t kb = s_key[pe(e)];
+    const uint32_t head_end = (cb > ca) ? (ca + 1) * c : last + 1;
+    for (uint32_t x = e + 1; x < head_end; ++x) {
+      const uint64_t kx = s_key[pe(x)];
+      if (kx <= kb) {
+        kb = kx;
+        best = x;
+      }
+    }
     if (cb > ca) {
-      best = better_idx(s_key, best, s_pre[last]);
       if (cb - ca >= 2) {
         const uint32_t len = cb - ca - 1;
         const uint32_t L = 31 - __clz(len);
         const uint16_t* lvl = s_st + (size_t)L * n_chunks;
         best = better_idx(s_key, best, lvl[ca + 1]);
         best = better_idx(s_key, best, lvl[cb - (1u << L)]);
+        kb = s_key[pe(best)];
+      }
+      for (uint32_t x = cb * c; x <= last; ++x) {
+        const uint64_t kx = s_key[pe(x)];
+        if (kx <= kb) {
+          kb = kx;
+          best = x;
+        }
       }
     }
     return best;
   };
+
+  const uint32_t per = (n_win + WIN_THREADS - 1) / WIN_THREADS;
+  const uint32_t w_lo = threadIdx.x * per;
+  const uint32_t w_hi = min(w_lo + per, n_win);
   if (w_lo < w_hi) {
-    uint32_t prev = (w_lo > 0) ? winner(w_lo - 1) : 0xFFFFFFFFu;
-    for (uint32_t e = w_lo; e < w_hi; ++e) {
-      const uint32_t cur = winner(e);
-      const bool owned = (tf + e) >= t0;
-      const bool fresh = (e == 0 && tf == 0 && t0 == 0) ? true : (cur != prev);
-      if (owned && fresh && !(e == 0 && t0 > 0)) {
-        const uint64_t key = s_key[cur];
-        if (key != KEY_MAX) {
-          const unsigned long long slot = atomicAdd(P.out_count, 1ULL);
-          if (slot < P.out_cap) {
-            P.out_j[slot] = P.rec_vstart[rec] + tf + cur;
-            P.out_key[slot] = key;
-          }
-        }
-      }
-      prev = cur;
+    auto emit = [&](uint32_t idx) {
+      if (s_key[pe(idx)] != KEY_MAX) s_list[atomicAdd(&s_ctl[0], 1u)] = (uint16_t)idx;
+    };
+    uint32_t e = w_lo > 0 ? w_lo - 1 : 0;
+    uint32_t cur = range_query(e);
+    if (w_lo == 0 && t0 == 0) emit(cur); // very first window of the record
+    for (++e; e < w_hi; ++e) {
+      const uint32_t incoming = e + w - 1;
+      uint32_t nxt;
+      if (cur < e)
+        nxt = range_query(e);
+      else
+        nxt = (s_key[pe(incoming)] <= s_key[pe(cur)]) ? incoming : cur;
+      if (nxt != cur) emit(nxt); // windows e >= 1 of the tile are all owned (window 0 is the overlap)
+      cur = nxt;
+    }
+  }
+  // ---- flush: one returning atomic per workgroup, on one of N_SEG counters ---------------------------
+  __syncthreads();
+  const uint32_t n_emit = s_ctl[0];
+  if (n_emit == 0) return;
+  const uint32_t seg = blockIdx.x % N_SEG;
+  if (threadIdx.x == 0) {
+    const unsigned long long base = atomicAdd(&P.seg_count[seg], (unsigned long long)n_emit);
+    s_ctl[1] = (uint32_t)base;
+    s_ctl[2] = (uint32_t)(base >> 32);
+  }
+  __syncthreads();
+  const uint64_t base = ((uint64_t)s_ctl[2] << 32) | s_ctl[1];
+  const uint64_t jbase = P.rec_vstart[rec] + tf;
+  for (uint32_t i = threadIdx.x; i < n_emit; i += WIN_THREADS) {
+    const uint64_t slot = base + i;
+    if (slot < P.seg_cap) {
+      const uint32_t idx = s_list[i];
+      P.out_j[(uint64_t)seg * P.seg_cap + slot] = jbase + idx;
+      P.out_key[(uint64_t)seg * P.seg_cap + slot] = s_key[pe(idx)];
     }
   }
 }
@@ -526,6 +725,11 @@ FastMod make_fastmod(uint64_t m)
   return fm;
 }
 
+inline uint64_t key_buffer_elems(uint64_t n_valid)
+{
+  return std::max<uint64_t>((n_valid + KEY_TILE - 1) / KEY_TILE, 1) * KEY_TILE;
+}
+
 struct RunTable
 {
   std::vector<uint64_t> pos, vstart; // vstart has n_runs+1 entries
@@ -598,25 +802,30 @@ int dev_upload(nts_ctx* ctx, const std::vector<T>& h, T** d, size_t min_elems = 
   return NTS_OK;
 }
 
+// host vector -> named scratch buffer (the vector must outlive the stream work; callers sync)
+template <typename T>
+int ws_upload(nts_ctx* ctx, const char* name, const std::vector<T>& h, T** d)
+{
+  *d = (T*)ws_get(ctx, name, std::max<size_t>(h.size(), 1) * sizeof(T));
+  if (!*d) return NTS_ENOMEM;
+  if (!h.empty()) HIP_TRY(ctx, hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return NTS_OK;
+}
+
 struct DevRuns
 {
   uint64_t* pos = nullptr;
   uint64_t* vstart = nullptr;
   uint32_t n = 0;
-  ~DevRuns()
-  {
-    if (pos) hipFree(pos);
-    if (vstart) hipFree(vstart);
-  }
 };
 
 int upload_runs(nts_ctx* ctx, const RunTable& rt, DevRuns& dr)
 {
   if (rt.pos.size() > 0xFFFFFFF0ULL) return fail(ctx, NTS_ERANGE, "too many valid runs");
   dr.n = (uint32_t)rt.pos.size();
-  int rc = dev_upload(ctx, rt.pos, &dr.pos);
+  int rc = ws_upload(ctx, "run_pos", rt.pos, &dr.pos);
   if (rc) return rc;
-  return dev_upload(ctx, rt.vstart, &dr.vstart);
+  return ws_upload(ctx, "run_vstart", rt.vstart, &dr.vstart);
 }
 
 template <int MODE>
@@ -674,6 +883,8 @@ void nts_destroy(nts_ctx* ctx)
   if (!ctx) return;
   hipSetDevice(ctx->device);
   drain_timings(ctx);
+  hipStreamSynchronize(ctx->stream);
+  ws_release(ctx);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -881,8 +1092,34 @@ void nts_bf_free(nts_ctx* ctx, nts_bf* bf)
 {
   if (!bf) return;
   if (ctx) hipSetDevice(ctx->device);
-  if (bf->d_words) hipFree(bf->d_words);
+  if (bf->d_words && bf->owned) hipFree(bf->d_words);
   delete bf;
+}
+
+int nts_bf_wrap(nts_ctx* ctx, void* device_ptr, uint64_t bytes, nts_bf** out)
+{
+  if (!ctx || !out || !device_ptr || bytes == 0 || (bytes % 8) != 0 || ((uintptr_t)device_ptr % 16) != 0)
+    return fail(ctx, NTS_EINVAL, "nts_bf_wrap: need a 16-byte aligned buffer and a positive multiple of 8 bytes");
+  nts_bf* bf = new nts_bf();
+  bf->bytes = bytes;
+  bf->d_words = (uint32_t*)device_ptr;
+  bf->owned = false;
+  *out = bf;
+  return NTS_OK;
+}
+
+int nts_and_raw(nts_ctx* ctx, void* acc_dev, const void* other_dev, uint64_t bytes)
+{
+  if (!ctx || !acc_dev || !other_dev || (bytes % 16) != 0 || ((uintptr_t)acc_dev % 16) != 0 || ((uintptr_t)other_dev % 16) != 0)
+    return fail(ctx, NTS_EINVAL, "nts_and_raw: buffers must be 16-byte aligned, size a multiple of 16");
+  if (bytes == 0) return NTS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t n16 = bytes / 16;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
+  ScopedTimer t(ctx, "bf_and");
+  hipLaunchKernelGGL(k_bf_and, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)acc_dev, (const uint4*)other_dev, n16);
+  HIP_TRY(ctx, hipGetLastError());
+  return NTS_OK;
 }
 
 uint64_t nts_bf_bytes(const nts_bf* bf)
@@ -995,14 +1232,18 @@ int nts_hash_all(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t** h0, u
   DevRuns dr;
   if ((rc = upload_runs(ctx, rt, dr))) return rc;
   uint64_t* d_keys = nullptr;
-  HIP_TRY(ctx, hipMalloc((void**)&d_keys, std::max<uint64_t>(rt.n_valid, 1) * 8));
+  uint64_t* d_lin = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&d_keys, key_buffer_elems(rt.n_valid) * 8));
+  HIP_TRY(ctx, hipMalloc((void**)&d_lin, std::max<uint64_t>(rt.n_valid, 1) * 8));
   rc = launch_hash<MODE_KEYS>(ctx, "hash_only", g, rt, dr, k, nullptr, nullptr, d_keys);
   uint64_t* host = (uint64_t*)malloc(std::max<uint64_t>(rt.n_valid, 1) * 8);
   if (rc == NTS_OK && rt.n_valid) {
-    hipMemcpyAsync(host, d_keys, rt.n_valid * 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipLaunchKernelGGL(k_keys_linear, dim3((uint32_t)((rt.n_valid + 255) / 256)), dim3(256), 0, ctx->stream, d_keys, rt.n_valid, d_lin);
+    hipMemcpyAsync(host, d_lin, rt.n_valid * 8, hipMemcpyDeviceToHost, ctx->stream);
   }
   hipError_t e = hipStreamSynchronize(ctx->stream);
   hipFree(d_keys);
+  hipFree(d_lin);
   if (rc != NTS_OK || e != hipSuccess) {
     free(host);
     return rc != NTS_OK ? rc : fail(ctx, NTS_EHIP, std::string("hash_all: ") + hipGetErrorString(e));
@@ -1039,54 +1280,38 @@ int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const 
     return fail(ctx, NTS_ERANGE, "too many window tiles for one launch");
   }
   DevRuns dr;
-  uint64_t *d_keys = nullptr, *d_rec_vstart = nullptr, *d_rec_nv = nullptr, *d_tile_start = nullptr, *d_rec_off = nullptr;
-  uint64_t *d_oj = nullptr, *d_ok = nullptr, *d_oj2 = nullptr, *d_ok2 = nullptr;
-  unsigned long long* d_count = nullptr;
-  void* d_tmp = nullptr;
-  auto cleanup = [&]() {
-    hipFree(d_keys);
-    hipFree(d_rec_vstart);
-    hipFree(d_rec_nv);
-    hipFree(d_tile_start);
-    hipFree(d_rec_off);
-    hipFree(d_oj);
-    hipFree(d_ok);
-    hipFree(d_oj2);
-    hipFree(d_ok2);
-    hipFree(d_count);
-    hipFree(d_tmp);
+  auto bail = [&](int code) {
+    hipStreamSynchronize(ctx->stream);
+    nts_mx_free(ctx, mx);
+    return code;
   };
 #define SK_TRY(expr)                                                                                \
   do {                                                                                              \
     int rc_ = (expr);                                                                               \
-    if (rc_ != NTS_OK) {                                                                            \
-      hipStreamSynchronize(ctx->stream);                                                            \
-      cleanup();                                                                                    \
-      delete mx;                                                                                    \
-      return rc_;                                                                                   \
-    }                                                                                               \
+    if (rc_ != NTS_OK) return bail(rc_);                                                            \
   } while (0)
 #define SK_HIP(expr)                                                                                \
   do {                                                                                              \
     hipError_t e_ = (expr);                                                                         \
     if (e_ != hipSuccess) {                                                                         \
       ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                 \
-      hipStreamSynchronize(ctx->stream);                                                            \
-      cleanup();                                                                                    \
-      delete mx;                                                                                    \
-      return e_ == hipErrorOutOfMemory ? NTS_ENOMEM : NTS_EHIP;                                     \
+      return bail(e_ == hipErrorOutOfMemory ? NTS_ENOMEM : NTS_EHIP);                               \
     }                                                                                               \
   } while (0)
+#define SK_WS(ptr, type, name, bytes)                                                               \
+  type ptr = (type)ws_get(ctx, name, bytes);                                                        \
+  if (!ptr) return bail(NTS_ENOMEM)
 
   SK_TRY(upload_runs(ctx, rt, dr));
-  SK_HIP(hipMalloc((void**)&d_keys, rt.n_valid * 8));
+  SK_WS(d_keys, uint64_t*, "keys", key_buffer_elems(rt.n_valid) * 8);
   SK_TRY(launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, rt, dr, k, filter, nullptr, d_keys));
 
-  SK_TRY(dev_upload(ctx, rt.rec_vstart, &d_rec_vstart));
-  SK_TRY(dev_upload(ctx, rt.rec_nv, &d_rec_nv));
-  SK_TRY(dev_upload(ctx, tile_start, &d_tile_start));
-  SK_TRY(dev_upload(ctx, g->rec_off, &d_rec_off));
-  SK_HIP(hipMalloc((void**)&d_count, sizeof(unsigned long long)));
+  uint64_t *d_rec_vstart = nullptr, *d_rec_nv = nullptr, *d_tile_start = nullptr, *d_rec_off = nullptr;
+  SK_TRY(ws_upload(ctx, "rec_vstart", rt.rec_vstart, &d_rec_vstart));
+  SK_TRY(ws_upload(ctx, "rec_nv", rt.rec_nv, &d_rec_nv));
+  SK_TRY(ws_upload(ctx, "tile_start", tile_start, &d_tile_start));
+  SK_TRY(ws_upload(ctx, "rec_off", g->rec_off, &d_rec_off));
+  SK_WS(d_seg, unsigned long long*, "seg_count", N_SEG * sizeof(unsigned long long));
 
   WinParams P;
   P.keys = d_keys;
@@ -1101,49 +1326,57 @@ int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const 
   while ((1u << P.levels) <= max_full) ++P.levels;
   const uint32_t E_max = WIN_TILE + 1 + w - 1;
   const uint32_t chunks_max = (E_max + P.chunk - 1) / P.chunk;
-  const size_t lds = (size_t)E_max * 8 + (size_t)E_max * 2 * 2 + (size_t)P.levels * chunks_max * 2 + 64;
+  const size_t lds = (size_t)(E_max + E_max / 32 + 2) * 8 + 16 + (size_t)(WIN_TILE + 16) * 2 + (size_t)P.levels * chunks_max * 2 + 64;
   if (lds > 160 * 1024) SK_TRY(fail(ctx, NTS_ERANGE, "window tile does not fit LDS"));
   SK_HIP(hipFuncSetAttribute((const void*)k_window_min, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
-  uint64_t cap = std::max<uint64_t>(4096, 3 * rt.n_valid / w + 2 * n_tiles + 1024);
-  unsigned long long count = 0;
+  uint64_t seg_cap = std::max<uint64_t>(256, (3 * rt.n_valid / w + 2 * n_tiles) / N_SEG + 64);
+  uint64_t count = 0;
+  uint64_t *d_oj = nullptr, *d_ok = nullptr;
+  unsigned long long seg_counts[N_SEG];
   for (int attempt = 0; attempt < 2; ++attempt) {
-    hipFree(d_oj);
-    hipFree(d_ok);
-    d_oj = d_ok = nullptr;
-    SK_HIP(hipMalloc((void**)&d_oj, cap * 8));
-    SK_HIP(hipMalloc((void**)&d_ok, cap * 8));
-    SK_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+    const uint64_t slots = seg_cap * N_SEG;
+    d_oj = (uint64_t*)ws_get(ctx, "out_j", slots * 8);
+    d_ok = (uint64_t*)ws_get(ctx, "out_key", slots * 8);
+    if (!d_oj || !d_ok) return bail(NTS_ENOMEM);
+    SK_HIP(hipMemsetAsync(d_oj, 0xFF, slots * 8, ctx->stream));
+    SK_HIP(hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
     P.out_j = d_oj;
     P.out_key = d_ok;
-    P.out_count = d_count;
-    P.out_cap = cap;
+    P.seg_count = d_seg;
+    P.seg_cap = seg_cap;
     {
       ScopedTimer t(ctx, "window_min");
       hipLaunchKernelGGL(k_window_min, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
     }
     SK_HIP(hipGetLastError());
-    SK_HIP(hipMemcpyAsync(&count, d_count, sizeof(count), hipMemcpyDeviceToHost, ctx->stream));
+    SK_HIP(hipMemcpyAsync(seg_counts, d_seg, sizeof(seg_counts), hipMemcpyDeviceToHost, ctx->stream));
     SK_HIP(hipStreamSynchronize(ctx->stream));
-    if (count <= cap) break;
-    cap = count; // exact size known now; run again
+    uint64_t worst = 0;
+    count = 0;
+    for (uint32_t s = 0; s < N_SEG; ++s) {
+      worst = std::max<uint64_t>(worst, seg_counts[s]);
+      count += seg_counts[s];
+    }
+    if (worst <= seg_cap) break;
+    seg_cap = worst; // exact need known now; run again
   }
-  hipFree(d_keys);
-  d_keys = nullptr;
   mx->n = count;
   if (count) {
-    SK_HIP(hipMalloc((void**)&d_oj2, count * 8));
-    SK_HIP(hipMalloc((void**)&d_ok2, count * 8));
+    const uint64_t slots = seg_cap * N_SEG;
+    SK_WS(d_oj2, uint64_t*, "out_j2", slots * 8);
+    SK_WS(d_ok2, uint64_t*, "out_key2", slots * 8);
     size_t tmp_bytes = 0;
+    SK_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_oj, d_oj2, d_ok, d_ok2, slots, 0, 64, ctx->stream));
+    SK_WS(d_tmp, void*, "sort_tmp", std::max<size_t>(tmp_bytes, 16));
     {
       ScopedTimer t(ctx, "sort_minimizers");
-      SK_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_oj, d_oj2, d_ok, d_ok2, count, 0, 64, ctx->stream));
-      SK_HIP(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
-      SK_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_oj, d_oj2, d_ok, d_ok2, count, 0, 64, ctx->stream));
+      SK_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_oj, d_oj2, d_ok, d_ok2, slots, 0, 64, ctx->stream));
     }
-    SK_HIP(hipMalloc((void**)&mx->d_h1, count * 8));
-    SK_HIP(hipMalloc((void**)&mx->d_rec, count * 4));
-    SK_HIP(hipMalloc((void**)&mx->d_pos, count * 8));
+    // one allocation for the three result arrays: h1 | pos | rec
+    SK_HIP(hipMalloc((void**)&mx->d_h1, count * 20));
+    mx->d_pos = mx->d_h1 + count;
+    mx->d_rec = (uint32_t*)(mx->d_pos + count);
     {
       ScopedTimer t(ctx, "finalize");
       hipLaunchKernelGGL(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_oj2, d_ok2, (uint64_t)count,
@@ -1152,11 +1385,11 @@ int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const 
     SK_HIP(hipGetLastError());
   }
   SK_HIP(hipStreamSynchronize(ctx->stream));
-  cleanup();
   *out = mx;
   return NTS_OK;
 #undef SK_TRY
 #undef SK_HIP
+#undef SK_WS
 }
 
 uint64_t nts_mx_count(const nts_mx* mx)
@@ -1168,9 +1401,7 @@ void nts_mx_free(nts_ctx* ctx, nts_mx* mx)
 {
   if (!mx) return;
   if (ctx) hipSetDevice(ctx->device);
-  hipFree(mx->d_h1);
-  hipFree(mx->d_rec);
-  hipFree(mx->d_pos);
+  hipFree(mx->d_h1); // h1 | pos | rec share one allocation
   delete mx;
 }
 
@@ -1183,6 +1414,19 @@ int nts_mx_download(nts_ctx* ctx, const nts_mx* mx, uint64_t* h1, uint32_t* rec,
   HIP_TRY(ctx, hipMemcpyAsync(h1, mx->d_h1, mx->n * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(rec, mx->d_rec, mx->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(pos, mx->d_pos, mx->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return NTS_OK;
+}
+
+int nts_mx_export(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, void* pos_dev)
+{
+  if (!ctx || !mx) return fail(ctx, NTS_EINVAL, "nts_mx_export: bad arguments");
+  if (mx->n == 0) return NTS_OK;
+  if (!h1_dev || !rec_dev || !pos_dev) return fail(ctx, NTS_EINVAL, "nts_mx_export: NULL destination");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(h1_dev, mx->d_h1, mx->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(rec_dev, mx->d_rec, mx->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(pos_dev, mx->d_pos, mx->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return NTS_OK;
 }
@@ -1203,11 +1447,12 @@ int nts_mx_upload(nts_ctx* ctx, const uint64_t* h1, const uint32_t* rec, const u
   nts_mx* mx = new nts_mx();
   mx->n = n;
   if (n) {
-    if (hipMalloc((void**)&mx->d_h1, n * 8) != hipSuccess || hipMalloc((void**)&mx->d_rec, n * 4) != hipSuccess ||
-        hipMalloc((void**)&mx->d_pos, n * 8) != hipSuccess) {
+    if (hipMalloc((void**)&mx->d_h1, n * 20) != hipSuccess) {
       nts_mx_free(ctx, mx);
       return fail(ctx, NTS_ENOMEM, "nts_mx_upload: hipMalloc");
     }
+    mx->d_pos = mx->d_h1 + n;
+    mx->d_rec = (uint32_t*)(mx->d_pos + n);
     hipMemcpyAsync(mx->d_h1, h1, n * 8, hipMemcpyHostToDevice, ctx->stream);
     hipMemcpyAsync(mx->d_rec, rec, n * 4, hipMemcpyHostToDevice, ctx->stream);
     hipMemcpyAsync(mx->d_pos, pos, n * 8, hipMemcpyHostToDevice, ctx->stream);

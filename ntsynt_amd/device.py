@@ -228,3 +228,25 @@ def sketch(ctx, genome, k, w, bf=None, masks=None):
     ctx.check(ctx.lib.nts_sketch(ctx.h, genome.h, int(k), int(w), bf.h if bf is not None else None,
                                  arr, n_mask, ctypes.byref(h)), "nts_sketch")
     return Minimizers(ctx, h)
+
+
+def wrap_bloom(ctx, tensor, nbytes, k):
+    """BloomFilter view over a caller-owned device buffer (a torch uint8 tensor of at least
+    ceil16(nbytes) bytes, zero-initialised): lets RCCL collectives run on the very same memory."""
+    bf = BloomFilter.__new__(BloomFilter)
+    bf.ctx, bf.k, bf.bytes = ctx, k, int(nbytes)
+    h = c_vp()
+    ctx.check(ctx.lib.nts_bf_wrap(ctx.h, ctypes.c_void_p(tensor.data_ptr()), int(nbytes), ctypes.byref(h)), "nts_bf_wrap")
+    bf.h = h
+    bf._keepalive = tensor
+    return bf
+
+
+def and_raw(ctx, acc_ptr, other_ptr, nbytes):
+    "acc &= other on raw device pointers (local step of the AND all-reduce)"
+    ctx.check(ctx.lib.nts_and_raw(ctx.h, ctypes.c_void_p(acc_ptr), ctypes.c_void_p(other_ptr), int(nbytes)), "nts_and_raw")
+
+
+def export_minimizers(ctx, mx, h1_ptr, rec_ptr, pos_ptr):
+    ctx.check(ctx.lib.nts_mx_export(ctx.h, mx.h, ctypes.c_void_p(h1_ptr), ctypes.c_void_p(rec_ptr),
+                                    ctypes.c_void_p(pos_ptr)), "nts_mx_export")
