@@ -140,42 +140,57 @@ int nts_mx_upload(nts_ctx* ctx,
 int nts_hash_all(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t** h0, uint64_t* n_out);
 
 /* ---- C1-C5: minimizer graph -> collinear chains -----------------------------------------------------
- * replaces ntjoin_utils.read_minimizers' duplicate removal, filter_minimizers, build_graph, and the
- * edge-weight filter + path finding (call sites bin/ntsynt_synteny.py:607-620, 483-492).
- * Input: G device lists in the reference's assembly order (descending file name).
- * nts_graph_build computes, on the GPU:
- *   - per assembly, hashes seen once (C1), intersected over assemblies (C2a);
- *   - the undirected adjacency edges of the filtered lists with their weights (C2b).
- * Output (host, library-allocated): the filtered lists and the distinct edges, enough for the host
- * to apply the rare order-dependent rules (C3) exactly and then walk the weight-G chains (C4, C5).
- *   v_hash[nv]           common hashes, ascending
- *   occ_rec/occ_pos[G*nv] record and position of vertex v in assembly a at [a*nv+v]
- *   list_v / list_off    per assembly, per surviving record list: vertex ids in list order;
- *                        list a,l spans list_v[list_off[i] .. list_off[i+1]) with i enumerated
- *                        assembly-major (n_lists[a] lists each)
- *   e_u/e_v/e_w/e_first  distinct edges: endpoints (vertex ids, orientation of first sighting),
- *                        weight, and the sequence number of the first sighting in the reference's
- *                        traversal order (assembly, list, index)
+ * replaces ntjoin_utils.read_minimizers' duplicate removal, filter_minimizers and build_graph
+ * (call sites bin/ntsynt_synteny.py:607-612, 483, 539) and the path walk of Ntjoin.find_paths
+ * (bin/ntsynt_synteny.py:492, 620).
+ *
+ * nts_graph_build -- on the GPU (radix sorts + scans over all minimizers of all assemblies):
+ *   C1  per assembly, keep hashes seen exactly once (over ALL elements given);
+ *       then AND with the caller's `keep` mask (refinement rounds: rows C11's position filter);
+ *   C2a keep hashes that survive in every assembly; number them 0..nv-1 by ascending hash;
+ *   C2b undirected edges between list-adjacent survivors; a "list" is a maximal run of equal
+ *       `list_id` inside one assembly (NULL: the record index, i.e. one list per FASTA record);
+ *       weight = number of assemblies in which the pair is adjacent.
+ * Assemblies are given in the reference's order (descending file name).  Output (host arrays owned by
+ * the library; release with nts_graph_free):
+ *   v_hash[nv]            surviving hashes, ascending
+ *   occ_rec/occ_pos       record and position of vertex v in assembly a at [a*nv + v]
+ *   e_u/e_v               endpoints of each distinct edge, in the orientation of its first sighting
+ *   e_w                   weight
+ *   e_first               sequence number of the first sighting in the reference's traversal order
+ *                         (assembly, list, index) -- lets the host rebuild ntJoin's edge order exactly
  */
+typedef struct
+{
+  const uint64_t* h1;
+  const uint32_t* rec;
+  const uint64_t* pos;
+  const uint8_t* keep;      /* NULL = keep all */
+  const uint32_t* list_id;  /* NULL = rec */
+  uint64_t n;
+} nts_mxlist;
+
 typedef struct
 {
   uint64_t nv;
   uint64_t* v_hash;
   uint32_t* occ_rec;
   uint64_t* occ_pos;
-  uint32_t n_asm;
-  uint64_t* n_lists;   /* [n_asm] */
-  uint64_t n_list_total;
-  uint64_t* list_off;  /* [n_list_total+1] */
-  uint32_t* list_v;    /* [list_off[n_list_total]] */
   uint64_t ne;
   uint32_t* e_u;
   uint32_t* e_v;
   uint32_t* e_w;
   uint64_t* e_first;
 } nts_graph;
-int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, nts_mx* const* lists, nts_graph* out);
+int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* lists, nts_graph* out);
 void nts_graph_free(nts_graph* g);
+
+/* Host-side helper (no GPU work): connected components of an undirected graph given as edge arrays
+ * that are simple paths (two degree-1 ends, everything else degree 2, at least 2 vertices) -- what
+ * Ntjoin.find_paths keeps.  Path i is verts[off[i] .. off[i+1]); each path starts at its end with the
+ * smaller vertex id.  Paths are listed by ascending first vertex id.  Release with nts_free(). */
+int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, const uint32_t* e_v,
+                    uint64_t** off, uint32_t** verts, uint64_t* n_paths);
 
 void nts_free(void* p);
 

@@ -20,11 +20,13 @@ class Interval(ctypes.Structure):
     _fields_ = [("rec", u32), ("start", u64), ("end", u64)]
 
 
+class MxList(ctypes.Structure):
+    _fields_ = [("h1", c_vp), ("rec", c_vp), ("pos", c_vp), ("keep", c_vp), ("list_id", c_vp), ("n", u64)]
+
+
 class Graph(ctypes.Structure):
     _fields_ = [("nv", u64), ("v_hash", c_u64p), ("occ_rec", c_u32p), ("occ_pos", c_u64p),
-                ("n_asm", u32), ("n_lists", c_u64p), ("n_list_total", u64), ("list_off", c_u64p),
-                ("list_v", c_u32p), ("ne", u64), ("e_u", c_u32p), ("e_v", c_u32p), ("e_w", c_u32p),
-                ("e_first", c_u64p)]
+                ("ne", u64), ("e_u", c_u32p), ("e_v", c_u32p), ("e_w", c_u32p), ("e_first", c_u64p)]
 
 
 # every symbol include/ntsynt_hip.h declares: (name, restype, argtypes)
@@ -64,7 +66,8 @@ SYMBOLS = [
                                           ctypes.POINTER(c_vp)]),
     ("nts_mx_upload", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, u64, ctypes.POINTER(c_vp)]),
     ("nts_hash_all", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_u64p), c_u64p]),
-    ("nts_graph_build", ctypes.c_int, [c_vp, u32, ctypes.POINTER(c_vp), ctypes.POINTER(Graph)]),
+    ("nts_graph_build", ctypes.c_int, [c_vp, u32, ctypes.POINTER(MxList), ctypes.POINTER(Graph)]),
+    ("nts_walk_chains", ctypes.c_int, [u64, u64, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_u32p), c_u64p]),
     ("nts_graph_free", None, [ctypes.POINTER(Graph)]),
     ("nts_free", None, [c_vp]),
 ]

@@ -1465,23 +1465,298 @@ int nts_mx_upload(nts_ctx* ctx, const uint64_t* h1, const uint32_t* rec, const u
   return NTS_OK;
 }
 
-int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, nts_mx* const* lists, nts_graph* out)
+void nts_free(void* p)
 {
-  (void)n_asm;
-  (void)lists;
-  (void)out;
-  return fail(ctx, NTS_EINVAL, "nts_graph_build: not built yet");
+  free(p);
 }
 
-void nts_graph_free(nts_graph* g)
+} // extern "C"
+
+// ---- minimizer graph build (rows C1, C2a, C2b) --------------------------------------------------------
+namespace {
+
+// after a stable sort by hash, duplicates of one assembly are adjacent (global element index is
+// assembly-major): mark elements whose hash is unique within their assembly and kept by the caller
+__global__ __launch_bounds__(256) void k_g_valid(const uint64_t* __restrict__ h_sorted, const uint64_t* __restrict__ idx_sorted,
+                                                 const uint32_t* __restrict__ asm_of, const uint8_t* __restrict__ keep, uint64_t n,
+                                                 uint8_t* __restrict__ valid)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t h = h_sorted[i];
+  const uint64_t e = idx_sorted[i];
+  const uint32_t a = asm_of[e];
+  bool dup = false;
+  if (i > 0 && h_sorted[i - 1] == h && asm_of[idx_sorted[i - 1]] == a) dup = true;
+  if (i + 1 < n && h_sorted[i + 1] == h && asm_of[idx_sorted[i + 1]] == a) dup = true;
+  valid[i] = (!dup && keep[e]) ? 1 : 0;
+}
+
+// group heads (first element of each run of equal hashes): the hash is common iff exactly n_asm
+// valid elements carry it (each assembly contributes at most one)
+__global__ __launch_bounds__(256) void k_g_common(const uint64_t* __restrict__ h_sorted, const uint8_t* __restrict__ valid, uint64_t n,
+                                                  uint32_t n_asm, uint64_t* __restrict__ head_common)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t flag = 0;
+  const uint64_t h = h_sorted[i];
+  if (i == 0 || h_sorted[i - 1] != h) {
+    uint32_t cnt = 0;
+    for (uint64_t j = i; j < n && h_sorted[j] == h; ++j) cnt += valid[j];
+    flag = (cnt == n_asm) ? 1 : 0;
+  }
+  head_common[i] = flag;
+}
+
+// vid_scan = exclusive scan of head_common: every valid element of a common group gets the group's id
+__global__ __launch_bounds__(256) void k_g_assign(const uint64_t* __restrict__ h_sorted, const uint64_t* __restrict__ idx_sorted,
+                                                  const uint8_t* __restrict__ valid, const uint64_t* __restrict__ head_common,
+                                                  const uint64_t* __restrict__ vid_scan, uint64_t n, const uint32_t* __restrict__ asm_of,
+                                                  const uint32_t* __restrict__ rec, const uint64_t* __restrict__ pos, uint64_t nv,
+                                                  uint32_t* __restrict__ elem_vid, uint64_t* __restrict__ v_hash,
+                                                  uint32_t* __restrict__ occ_rec, uint64_t* __restrict__ occ_pos)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t h = h_sorted[i];
+  if (!(i == 0 || h_sorted[i - 1] != h) || !head_common[i]) return;
+  const uint64_t vid = vid_scan[i];
+  v_hash[vid] = h;
+  for (uint64_t j = i; j < n && h_sorted[j] == h; ++j) {
+    if (!valid[j]) continue;
+    const uint64_t e = idx_sorted[j];
+    elem_vid[e] = (uint32_t)vid;
+    const uint32_t a = asm_of[e];
+    occ_rec[(uint64_t)a * nv + vid] = rec[e];
+    occ_pos[(uint64_t)a * nv + vid] = pos[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_g_flag_kept(const uint32_t* __restrict__ elem_vid, uint64_t n, uint64_t* __restrict__ flag)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = elem_vid[i] != 0xFFFFFFFFu ? 1 : 0;
+}
+
+// compact the survivors in traversal order: c_vid / c_asm / c_list
+__global__ __launch_bounds__(256) void k_g_compact(const uint32_t* __restrict__ elem_vid, const uint64_t* __restrict__ where, uint64_t n,
+                                                   const uint32_t* __restrict__ asm_of, const uint32_t* __restrict__ list_id,
+                                                   uint32_t* __restrict__ c_vid, uint32_t* __restrict__ c_asm, uint32_t* __restrict__ c_list)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || elem_vid[i] == 0xFFFFFFFFu) return;
+  const uint64_t c = where[i];
+  c_vid[c] = elem_vid[i];
+  c_asm[c] = asm_of[i];
+  c_list[c] = list_id[i];
+}
+
+// adjacent survivors of one list -> edge occurrence (canonical key, sequence number); others get key ~0
+__global__ __launch_bounds__(256) void k_g_pairs(const uint32_t* __restrict__ c_vid, const uint32_t* __restrict__ c_asm,
+                                                 const uint32_t* __restrict__ c_list, uint64_t m, uint64_t* __restrict__ key,
+                                                 uint64_t* __restrict__ seq)
+{
+  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m) return;
+  uint64_t kk = ~0ULL;
+  if (c + 1 < m && c_asm[c] == c_asm[c + 1] && c_list[c] == c_list[c + 1]) {
+    const uint64_t u = c_vid[c], v = c_vid[c + 1];
+    kk = u < v ? ((u << 32) | v) : ((v << 32) | u);
+  }
+  key[c] = kk;
+  seq[c] = c;
+}
+
+__global__ __launch_bounds__(256) void k_g_edge_heads(const uint64_t* __restrict__ key_sorted, uint64_t m, uint64_t* __restrict__ head)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint64_t kk = key_sorted[i];
+  head[i] = (kk != ~0ULL && (i == 0 || key_sorted[i - 1] != kk)) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_g_edges(const uint64_t* __restrict__ key_sorted, const uint64_t* __restrict__ seq_sorted,
+                                                 const uint64_t* __restrict__ head, const uint64_t* __restrict__ head_scan, uint64_t m,
+                                                 const uint32_t* __restrict__ c_vid, uint32_t* __restrict__ e_u, uint32_t* __restrict__ e_v,
+                                                 uint32_t* __restrict__ e_w, uint64_t* __restrict__ e_first)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m || !head[i]) return;
+  const uint64_t kk = key_sorted[i];
+  uint32_t cnt = 0;
+  for (uint64_t j = i; j < m && key_sorted[j] == kk; ++j) ++cnt;
+  const uint64_t e = head_scan[i];
+  const uint64_t s = seq_sorted[i]; // stable sort: the first sighting leads its group
+  e_u[e] = c_vid[s];
+  e_v[e] = c_vid[s + 1];
+  e_w[e] = cnt;
+  e_first[e] = s;
+}
+
+template <typename T>
+T* host_copy(nts_ctx* ctx, const T* d, uint64_t n)
+{
+  T* h = (T*)malloc(std::max<uint64_t>(n, 1) * sizeof(T));
+  if (h && n) hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream);
+  return h;
+}
+
+} // namespace
+
+extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* lists, nts_graph* out)
+{
+  if (!ctx || !out || n_asm == 0 || !lists) return fail(ctx, NTS_EINVAL, "nts_graph_build: bad arguments");
+  memset(out, 0, sizeof(*out));
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t n = 0;
+  for (uint32_t a = 0; a < n_asm; ++a) {
+    if (lists[a].n && (!lists[a].h1 || !lists[a].rec || !lists[a].pos)) return fail(ctx, NTS_EINVAL, "nts_graph_build: NULL list arrays");
+    n += lists[a].n;
+  }
+  if (n >= 0xFFFFFFFFULL) return fail(ctx, NTS_ERANGE, "nts_graph_build: more than 2^32 minimizers");
+  auto finish_empty = [&]() {
+    out->v_hash = (uint64_t*)malloc(8);
+    out->occ_rec = (uint32_t*)malloc(8);
+    out->occ_pos = (uint64_t*)malloc(8);
+    out->e_u = (uint32_t*)malloc(8);
+    out->e_v = (uint32_t*)malloc(8);
+    out->e_w = (uint32_t*)malloc(8);
+    out->e_first = (uint64_t*)malloc(8);
+    return NTS_OK;
+  };
+  if (n == 0) return finish_empty();
+#define G_WS(ptr, type, name, bytes)                                                                \
+  type ptr = (type)ws_get(ctx, name, bytes);                                                        \
+  if (!ptr) return NTS_ENOMEM
+  G_WS(d_h, uint64_t*, "g_h", n * 8);
+  G_WS(d_idx, uint64_t*, "g_idx", n * 8);
+  G_WS(d_h2, uint64_t*, "g_h2", n * 8);
+  G_WS(d_idx2, uint64_t*, "g_idx2", n * 8);
+  G_WS(d_asm, uint32_t*, "g_asm", n * 4);
+  G_WS(d_rec, uint32_t*, "g_rec", n * 4);
+  G_WS(d_pos, uint64_t*, "g_pos", n * 8);
+  G_WS(d_keep, uint8_t*, "g_keep", n);
+  G_WS(d_list, uint32_t*, "g_list", n * 4);
+  G_WS(d_valid, uint8_t*, "g_valid", n);
+  G_WS(d_flag, uint64_t*, "g_flag", n * 8);
+  G_WS(d_scan, uint64_t*, "g_scan", (n + 1) * 8);
+  G_WS(d_evid, uint32_t*, "g_evid", n * 4);
+  // host staging (assembly-major concatenation)
+  std::vector<uint64_t> h_idx(n);
+  std::vector<uint32_t> h_asm(n);
+  std::vector<uint8_t> h_keep(n, 1);
+  uint64_t o = 0;
+  for (uint32_t a = 0; a < n_asm; ++a) {
+    const uint64_t m = lists[a].n;
+    if (m) {
+      HIP_TRY(ctx, hipMemcpyAsync(d_h + o, lists[a].h1, m * 8, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(d_rec + o, lists[a].rec, m * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(d_pos + o, lists[a].pos, m * 8, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(d_list + o, lists[a].list_id ? lists[a].list_id : lists[a].rec, m * 4, hipMemcpyHostToDevice, ctx->stream));
+      if (lists[a].keep) memcpy(h_keep.data() + o, lists[a].keep, m);
+    }
+    for (uint64_t i = 0; i < m; ++i) {
+      h_idx[o + i] = o + i;
+      h_asm[o + i] = a;
+    }
+    o += m;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(d_idx, h_idx.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_asm, h_asm.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_keep, h_keep.data(), n, hipMemcpyHostToDevice, ctx->stream));
+  const uint32_t nb = (uint32_t)((n + 255) / 256);
+  size_t tmp_sort = 0, tmp_scan = 0;
+  HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort, d_h, d_h2, d_idx, d_idx2, n, 0, 64, ctx->stream));
+  HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, tmp_scan, d_flag, d_scan, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
+  G_WS(d_tmp, void*, "g_tmp", std::max<size_t>(std::max(tmp_sort, tmp_scan), 16));
+  {
+    ScopedTimer t(ctx, "graph_build");
+    // C1 + keep mask
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp, tmp_sort, d_h, d_h2, d_idx, d_idx2, n, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_g_valid, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_idx2, d_asm, d_keep, n, d_valid);
+    // C2a
+    hipLaunchKernelGGL(k_g_common, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_valid, n, n_asm, d_flag);
+    HIP_TRY(ctx, rocprim::exclusive_scan(d_tmp, tmp_scan, d_flag, d_scan, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
+  }
+  uint64_t last_flag = 0, last_scan = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&last_flag, d_flag + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&last_scan, d_scan + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const uint64_t nv = last_scan + last_flag;
+  out->nv = nv;
+  if (nv == 0) return finish_empty();
+  G_WS(d_vhash, uint64_t*, "g_vhash", nv * 8);
+  G_WS(d_orec, uint32_t*, "g_orec", (uint64_t)n_asm * nv * 4);
+  G_WS(d_opos, uint64_t*, "g_opos", (uint64_t)n_asm * nv * 8);
+  HIP_TRY(ctx, hipMemsetAsync(d_evid, 0xFF, n * 4, ctx->stream));
+  {
+    ScopedTimer t(ctx, "graph_build");
+    hipLaunchKernelGGL(k_g_assign, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_idx2, d_valid, d_flag, d_scan, n, d_asm, d_rec, d_pos, nv,
+                       d_evid, d_vhash, d_orec, d_opos);
+    // survivors in traversal order
+    hipLaunchKernelGGL(k_g_flag_kept, dim3(nb), dim3(256), 0, ctx->stream, d_evid, n, d_flag);
+    HIP_TRY(ctx, rocprim::exclusive_scan(d_tmp, tmp_scan, d_flag, d_scan, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
+  }
+  const uint64_t m = (uint64_t)n_asm * nv; // every common hash occurs once per assembly
+  G_WS(d_cvid, uint32_t*, "g_cvid", (m + 1) * 4);
+  G_WS(d_casm, uint32_t*, "g_casm", m * 4);
+  G_WS(d_clist, uint32_t*, "g_clist", m * 4);
+  G_WS(d_key, uint64_t*, "g_key", m * 8);
+  G_WS(d_seq, uint64_t*, "g_seq", m * 8);
+  G_WS(d_key2, uint64_t*, "g_key2", m * 8);
+  G_WS(d_seq2, uint64_t*, "g_seq2", m * 8);
+  G_WS(d_eh, uint64_t*, "g_eh", m * 8);
+  G_WS(d_es, uint64_t*, "g_es", (m + 1) * 8);
+  size_t tmp_sort2 = 0, tmp_scan2 = 0;
+  HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort2, d_key, d_key2, d_seq, d_seq2, m, 0, 64, ctx->stream));
+  HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, tmp_scan2, d_eh, d_es, (uint64_t)0, m, rocprim::plus<uint64_t>(), ctx->stream));
+  G_WS(d_tmp2, void*, "g_tmp2", std::max<size_t>(std::max(tmp_sort2, tmp_scan2), 16));
+  const uint32_t mb = (uint32_t)((m + 255) / 256);
+  {
+    ScopedTimer t(ctx, "graph_build");
+    hipLaunchKernelGGL(k_g_compact, dim3(nb), dim3(256), 0, ctx->stream, d_evid, d_scan, n, d_asm, d_list, d_cvid, d_casm, d_clist);
+    hipLaunchKernelGGL(k_g_pairs, dim3(mb), dim3(256), 0, ctx->stream, d_cvid, d_casm, d_clist, m, d_key, d_seq);
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp2, tmp_sort2, d_key, d_key2, d_seq, d_seq2, m, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_g_edge_heads, dim3(mb), dim3(256), 0, ctx->stream, d_key2, m, d_eh);
+    HIP_TRY(ctx, rocprim::exclusive_scan(d_tmp2, tmp_scan2, d_eh, d_es, (uint64_t)0, m, rocprim::plus<uint64_t>(), ctx->stream));
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(&last_flag, d_eh + (m - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&last_scan, d_es + (m - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const uint64_t ne = last_scan + last_flag;
+  out->ne = ne;
+  G_WS(d_eu, uint32_t*, "g_eu", std::max<uint64_t>(ne, 1) * 4);
+  G_WS(d_ev, uint32_t*, "g_ev", std::max<uint64_t>(ne, 1) * 4);
+  G_WS(d_ew, uint32_t*, "g_ew", std::max<uint64_t>(ne, 1) * 4);
+  G_WS(d_ef, uint64_t*, "g_ef", std::max<uint64_t>(ne, 1) * 8);
+  if (ne) {
+    ScopedTimer t(ctx, "graph_build");
+    hipLaunchKernelGGL(k_g_edges, dim3(mb), dim3(256), 0, ctx->stream, d_key2, d_seq2, d_eh, d_es, m, d_cvid, d_eu, d_ev, d_ew, d_ef);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  out->v_hash = host_copy(ctx, d_vhash, nv);
+  out->occ_rec = host_copy(ctx, d_orec, (uint64_t)n_asm * nv);
+  out->occ_pos = host_copy(ctx, d_opos, (uint64_t)n_asm * nv);
+  out->e_u = host_copy(ctx, d_eu, ne);
+  out->e_v = host_copy(ctx, d_ev, ne);
+  out->e_w = host_copy(ctx, d_ew, ne);
+  out->e_first = host_copy(ctx, d_ef, ne);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (!out->v_hash || !out->occ_rec || !out->occ_pos || !out->e_u || !out->e_v || !out->e_w || !out->e_first) {
+    nts_graph_free(out);
+    return fail(ctx, NTS_ENOMEM, "nts_graph_build: host allocation failed");
+  }
+  return NTS_OK;
+#undef G_WS
+}
+
+extern "C" void nts_graph_free(nts_graph* g)
 {
   if (!g) return;
   free(g->v_hash);
   free(g->occ_rec);
   free(g->occ_pos);
-  free(g->n_lists);
-  free(g->list_off);
-  free(g->list_v);
   free(g->e_u);
   free(g->e_v);
   free(g->e_w);
@@ -1489,9 +1764,68 @@ void nts_graph_free(nts_graph* g)
   memset(g, 0, sizeof(*g));
 }
 
-void nts_free(void* p)
+// Host-side: components that are simple paths (Ntjoin.find_paths keeps exactly those).
+extern "C" int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, const uint32_t* e_v, uint64_t** off, uint32_t** verts,
+                               uint64_t* n_paths)
 {
-  free(p);
+  if (!off || !verts || !n_paths || (ne && (!e_u || !e_v))) return NTS_EINVAL;
+  std::vector<uint32_t> deg(nv, 0);
+  for (uint64_t e = 0; e < ne; ++e) {
+    if (e_u[e] >= nv || e_v[e] >= nv) return NTS_EINVAL;
+    ++deg[e_u[e]];
+    ++deg[e_v[e]];
+  }
+  // neighbour slots for vertices of degree <= 2; vertices of higher degree poison their component
+  const uint32_t NONE = 0xFFFFFFFFu;
+  std::vector<uint32_t> nb(2 * nv, NONE);
+  for (uint64_t e = 0; e < ne; ++e) {
+    const uint32_t u = e_u[e], v = e_v[e];
+    if (deg[u] <= 2) nb[2 * (uint64_t)u + (nb[2 * (uint64_t)u] == NONE ? 0 : 1)] = v;
+    if (deg[v] <= 2) nb[2 * (uint64_t)v + (nb[2 * (uint64_t)v] == NONE ? 0 : 1)] = u;
+  }
+  std::vector<uint64_t> o(1, 0);
+  std::vector<uint32_t> out;
+  std::vector<uint8_t> seen(nv, 0);
+  for (uint64_t s = 0; s < nv; ++s) {
+    if (deg[s] != 1 || seen[s]) continue;
+    // walk from this end; the path is kept if it ends at another degree-1 vertex through degree-2 ones
+    const size_t mark = out.size();
+    uint32_t prev = NONE, cur = (uint32_t)s;
+    bool ok = true;
+    for (;;) {
+      seen[cur] = 1;
+      out.push_back(cur);
+      uint32_t nxt = NONE;
+      if (deg[cur] > 2) {
+        ok = false;
+        break;
+      }
+      const uint32_t a = nb[2 * (uint64_t)cur], b = nb[2 * (uint64_t)cur + 1];
+      if (a != NONE && a != prev)
+        nxt = a;
+      else if (b != NONE && b != prev)
+        nxt = b;
+      else if (a != NONE && b != NONE && a == prev && b == prev)
+        nxt = NONE; // parallel edges back to prev: not a simple path
+      if (nxt == NONE) break;
+      prev = cur;
+      cur = nxt;
+      if (seen[cur]) { // ran into something already visited: not a simple path
+        ok = false;
+        break;
+      }
+    }
+    if (ok && out.size() - mark >= 2 && deg[out.back()] == 1) {
+      o.push_back(out.size());
+    } else {
+      out.resize(mark);
+    }
+  }
+  *n_paths = o.size() - 1;
+  *off = (uint64_t*)malloc(o.size() * sizeof(uint64_t));
+  *verts = (uint32_t*)malloc(std::max<size_t>(out.size(), 1) * sizeof(uint32_t));
+  if (!*off || !*verts) return NTS_ENOMEM;
+  memcpy(*off, o.data(), o.size() * sizeof(uint64_t));
+  if (!out.empty()) memcpy(*verts, out.data(), out.size() * sizeof(uint32_t));
+  return NTS_OK;
 }
-
-} // extern "C"

@@ -1,0 +1,64 @@
+"""Device-side minimizer-graph build (rows C1, C2) and the native chain walk (row C5) over the C ABI."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .synteny import GraphArrays
+
+
+def build_graph_device(ctx, lists, keeps=None, list_ids=None):
+    """lists[a] = (h1 uint64[], rec, pos) in the reference's assembly order; keeps[a]: bool mask or
+    None; list_ids[a]: list id per element or None (= record).  Runs nts_graph_build on the GPU."""
+    G = len(lists)
+    arr = (_lib.MxList * G)()
+    hold = []
+    for a, (h1, rec, pos) in enumerate(lists):
+        h1 = np.ascontiguousarray(h1, dtype=np.uint64)
+        rec = np.ascontiguousarray(rec, dtype=np.uint32)
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        hold += [h1, rec, pos]
+        arr[a].h1, arr[a].rec, arr[a].pos, arr[a].n = h1.ctypes.data, rec.ctypes.data, pos.ctypes.data, h1.size
+        arr[a].keep = arr[a].list_id = None
+        if keeps is not None and keeps[a] is not None:
+            kp = np.ascontiguousarray(keeps[a], dtype=np.uint8)
+            hold.append(kp)
+            arr[a].keep = kp.ctypes.data
+        if list_ids is not None and list_ids[a] is not None:
+            li = np.ascontiguousarray(list_ids[a], dtype=np.uint32)
+            hold.append(li)
+            arr[a].list_id = li.ctypes.data
+    g = _lib.Graph()
+    ctx.check(ctx.lib.nts_graph_build(ctx.h, G, arr, ctypes.byref(g)), "nts_graph_build")
+    nv, ne = int(g.nv), int(g.ne)
+
+    def take(ptr, n, dtype):
+        if n == 0:
+            return np.zeros(0, dtype=dtype)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+    out = GraphArrays(
+        v_hash=take(g.v_hash, nv, np.uint64),
+        occ_rec=take(g.occ_rec, G * nv, np.int64).reshape(G, nv),
+        occ_pos=take(g.occ_pos, G * nv, np.int64).reshape(G, nv),
+        e_u=take(g.e_u, ne, np.int64), e_v=take(g.e_v, ne, np.int64), e_w=take(g.e_w, ne, np.int64),
+        e_first=take(g.e_first, ne, np.int64))
+    ctx.lib.nts_graph_free(ctypes.byref(g))
+    return out
+
+
+def walk_chains(nv, e_u, e_v):
+    """Components that are simple paths -> (offsets int64[n_paths+1], vertices int64[]).
+    Native host helper nts_walk_chains (no GPU involved)."""
+    lib = _lib.load()
+    eu = np.ascontiguousarray(e_u, dtype=np.uint32)
+    ev = np.ascontiguousarray(e_v, dtype=np.uint32)
+    off, verts, n = _lib.c_u64p(), _lib.c_u32p(), _lib.u64()
+    rc = lib.nts_walk_chains(int(nv), eu.size, eu.ctypes.data, ev.ctypes.data, ctypes.byref(off), ctypes.byref(verts),
+                             ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"nts_walk_chains failed ({rc})")
+    o = np.ctypeslib.as_array(off, shape=(n.value + 1,)).astype(np.int64, copy=True)
+    v = np.ctypeslib.as_array(verts, shape=(max(int(o[-1]), 1),))[:int(o[-1])].astype(np.int64, copy=True)
+    lib.nts_free(off)
+    lib.nts_free(verts)
+    return o, v

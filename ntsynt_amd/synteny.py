@@ -1,0 +1,555 @@
+"""Minimizer graph -> synteny blocks on the host side of the HIP path.
+
+This is the array-based counterpart of the reference's graph stage (bin/ntsynt_synteny.py,
+bin/synteny_block.py, bin/assembly_block.py; ntJoin's graph helpers): vertices are integer ids,
+hashes/positions live in numpy arrays, edges in flat arrays kept in the reference's edge order.
+The heavy joins (duplicate removal, cross-assembly intersection, adjacency edges: rows C1, C2) are
+done by `graph_fn` (the GPU: ntsynt_amd.graph.build_graph_device) and the re-sketch of masked
+genomes (row B5) by `sketch_fn` (the GPU: nts_sketch); this module holds the rules that decide the
+output bytes.  It never touches the oracle.
+
+Reference behaviours reproduced on purpose (cited as S:<line> = bin/ntsynt_synteny.py):
+  * edge order = dict-of-dicts order of ntJoin's build_graph (drives S:573-586 and S:297-300);
+  * in refinement rounds bubble removal only promotes weights, its vertex deletions are lost (S:483-491);
+  * a path whose contig changes keeps only its last run (S:71-77);
+  * vertex names compare as decimal strings when normalising flagged pairs (S:351).
+"""
+import re
+import sys
+from dataclasses import dataclass, field
+
+import numpy as np
+
+MX_SUFFIX = re.compile(r'^(\S+)\.k\d+\.w\d+.tsv')
+
+
+@dataclass
+class GraphArrays:
+    """Result of one graph build (mirror of nts_graph in include/ntsynt_hip.h)."""
+    v_hash: np.ndarray                      # [nv] uint64, ascending
+    occ_rec: np.ndarray                     # [G, nv] int64
+    occ_pos: np.ndarray                     # [G, nv] int64
+    e_u: np.ndarray                         # [ne] int64, orientation of first sighting
+    e_v: np.ndarray
+    e_w: np.ndarray                         # [ne] int64
+    e_first: np.ndarray                     # [ne] int64 sequence number of first sighting
+
+
+def dict_order(e_u, e_first, nv):
+    """Permutation putting edges in the order `[(s, t) for s in edges for t in edges[s]]` yields:
+    sources by the time they first became a source, then by creation time."""
+    if e_u.size == 0:
+        return np.zeros(0, dtype=np.int64)
+    src_rank = np.full(nv, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(src_rank, e_u, e_first)
+    return np.lexsort((e_first, src_rank[e_u]))
+
+
+@dataclass
+class Block:
+    vids: np.ndarray                        # vertex ids in path order
+    rec: list                               # per assembly: contig (record index)
+    ori: list                               # per assembly: '+', '-', '?'
+    reason: object = None
+    # after collinear merging only the ends and the count matter
+    first_pos: list = field(default_factory=list)
+    last_pos: list = field(default_factory=list)
+    n_mx: int = 0
+
+
+class SyntenyEngine:
+    """files: minimizer-TSV names identifying the assemblies (any order; sorted descending like
+    S:34); contig_names[a]: record names of assembly a (indexable by record id);
+    graph_fn(lists, keep, list_ids) -> GraphArrays with lists[a] = (h1, rec, pos) arrays;
+    sketch_fn(a, masks, w) -> (h1, rec, pos) of assembly a re-sketched with hard masks [(rec, s, e)]."""
+
+    def __init__(self, files, contig_names, k, w, w_rounds, bp, collinear_merge, z, prefix, graph_fn, sketch_fn,
+                 walk_fn, simplify=True, m=90, n=0, log=None):
+        order = sorted(range(len(files)), key=lambda i: files[i], reverse=True)
+        self.input_order = order                       # engine index a -> caller's assembly index
+        self.files = [files[i] for i in order]
+        self.contigs = [contig_names[i] for i in order]
+        self.G = len(files)
+        self.k, self.w, self.w_rounds = k, w, list(w_rounds)
+        self.bp, self.z, self.prefix, self.m = bp, z, prefix, m
+        self.simplify = simplify
+        self.n = n or self.G
+        cm = str(collinear_merge)
+        if mt := re.search(r"^(\d+)w$", cm):
+            self.collinear_merge = int(mt.group(1)) * w
+        elif mt := re.search(r"^(\d+)$", cm):
+            self.collinear_merge = int(mt.group(1))
+        else:
+            raise ValueError("--collinear-merge must be provided with an integer value or string in the form '<num>w'")
+        self.graph_fn, self.sketch_fn, self.walk_fn = graph_fn, sketch_fn, walk_fn
+        self.log = log or (lambda *a: None)
+        self.outputs = {}
+        self.stats = {"bubbles": 0, "unoriented": 0, "indel_cuts": 0, "small_blocks": 0, "merged": 0, "eroded_edges": 0}
+        self.ref = self.G - 1                          # lexicographically smallest file (S:34 + ntJoin)
+        self.out_order = sorted(range(self.G), key=lambda a: self.files[a])
+        # graph state
+        self.v_hash = np.zeros(0, np.uint64)
+        self.v_alive = np.zeros(0, bool)
+        self.v_rec = np.zeros((self.G, 0), np.int64)
+        self.v_pos = np.zeros((self.G, 0), np.int64)
+        self.e_u = np.zeros(0, np.int64)
+        self.e_v = np.zeros(0, np.int64)
+        self.e_w = np.zeros(0, np.int64)
+        self.e_alive = np.zeros(0, bool)
+
+    # ------------------------------------------------------------------ graph bookkeeping
+    def _degrees(self):
+        m = self.e_alive
+        return np.bincount(np.concatenate((self.e_u[m], self.e_v[m])), minlength=self.v_hash.size)
+
+    def _delete_vertices(self, vids):
+        if len(vids) == 0:
+            return
+        dead = np.zeros(self.v_hash.size, bool)
+        dead[np.asarray(vids, dtype=np.int64)] = True
+        self.v_alive &= ~dead
+        self.e_alive &= ~(dead[self.e_u] | dead[self.e_v])
+
+    def _edge_lookup(self):
+        "sorted (min<<32|max) keys of the live edges -> edge index"
+        idx = np.flatnonzero(self.e_alive)
+        lo = np.minimum(self.e_u[idx], self.e_v[idx])
+        hi = np.maximum(self.e_u[idx], self.e_v[idx])
+        key = (lo << 32) | hi
+        srt = np.argsort(key, kind="stable")
+        return key[srt], idx[srt]
+
+    def _find_edges(self, us, vs, lookup=None):
+        keys, idx = lookup or self._edge_lookup()
+        lo, hi = np.minimum(us, vs), np.maximum(us, vs)
+        q = (lo << 32) | hi
+        p = np.searchsorted(keys, q)
+        p = np.minimum(p, max(keys.size - 1, 0))
+        ok = (keys[p] == q) if keys.size else np.zeros(q.size, bool)
+        return idx[p][ok] if keys.size else np.zeros(0, np.int64)
+
+    def _add_graph(self, ga, hash_to_vid=None):
+        """Append the vertices/edges of one build (rows C2b): new hashes become new vertex ids, edges are
+        appended in dict order after the existing ones."""
+        nv0 = self.v_hash.size
+        if nv0 == 0:
+            local_to_global = np.arange(ga.v_hash.size, dtype=np.int64)
+            self.v_hash = ga.v_hash.copy()
+            self.v_alive = np.ones(ga.v_hash.size, bool)
+            self.v_rec = ga.occ_rec.astype(np.int64).copy()
+            self.v_pos = ga.occ_pos.astype(np.int64).copy()
+        else:
+            # per hash, the live vertex carrying it (a deleted vertex may share its hash with a re-created one)
+            srt = np.lexsort((self.v_alive, self.v_hash))
+            sh = self.v_hash[srt]
+            last = np.flatnonzero(np.r_[sh[1:] != sh[:-1], True])
+            uh, uid = sh[last], srt[last]
+            p = np.minimum(np.searchsorted(uh, ga.v_hash), uh.size - 1)
+            hit = (uh[p] == ga.v_hash) & self.v_alive[uid[p]]
+            local_to_global = np.where(hit, uid[p], -1)
+            new = np.flatnonzero(local_to_global < 0)
+            local_to_global[new] = nv0 + np.arange(new.size)
+            self.v_hash = np.concatenate((self.v_hash, ga.v_hash[new]))
+            self.v_alive = np.concatenate((self.v_alive, np.ones(new.size, bool)))
+            self.v_rec = np.concatenate((self.v_rec, ga.occ_rec[:, new].astype(np.int64)), axis=1)
+            self.v_pos = np.concatenate((self.v_pos, ga.occ_pos[:, new].astype(np.int64)), axis=1)
+            # S:282-290: positions of every hash that survived the filters are overwritten
+            self.v_rec[:, local_to_global] = ga.occ_rec
+            self.v_pos[:, local_to_global] = ga.occ_pos
+        order = dict_order(ga.e_u, ga.e_first, ga.v_hash.size)
+        eu, ev, ew = local_to_global[ga.e_u[order]], local_to_global[ga.e_v[order]], ga.e_w[order].astype(np.int64)
+        if nv0 and eu.size:
+            # an edge that already exists keeps its slot and takes the new weight (never seen in practice)
+            keys, idx = self._edge_lookup()
+            if keys.size:
+                q = (np.minimum(eu, ev) << 32) | np.maximum(eu, ev)
+                p = np.minimum(np.searchsorted(keys, q), keys.size - 1)
+                dup = keys[p] == q
+                self.e_w[idx[p][dup]] = ew[dup]
+                eu, ev, ew = eu[~dup], ev[~dup], ew[~dup]
+        self.e_u = np.concatenate((self.e_u, eu))
+        self.e_v = np.concatenate((self.e_v, ev))
+        self.e_w = np.concatenate((self.e_w, ew))
+        self.e_alive = np.concatenate((self.e_alive, np.ones(eu.size, bool)))
+        return local_to_global
+
+    # ------------------------------------------------------------------ C3: bubble removal (S:548-590)
+    def _simplify(self, apply_deletions):
+        wmax = self.G                                      # sum of the weights, all 1 (S:32, S:571)
+        deg = self._degrees()
+        cand = np.flatnonzero(self.e_alive & (deg[self.e_u] == 3) & (deg[self.e_v] == 3))
+        if cand.size == 0:
+            return
+        cv = np.unique(np.concatenate((self.e_u[cand], self.e_v[cand])))
+        is_cv = np.zeros(self.v_hash.size, bool)
+        is_cv[cv] = True
+        inc = np.flatnonzero(self.e_alive & (is_cv[self.e_u] | is_cv[self.e_v]))
+        adj = {}
+        for e in inc.tolist():
+            u, v = int(self.e_u[e]), int(self.e_v[e])
+            adj.setdefault(u, {})[v] = e
+            adj.setdefault(v, {})[u] = e
+        doomed = []
+        for e in cand.tolist():                            # ascending edge index = reference edge order
+            s, t = int(self.e_u[e]), int(self.e_v[e])
+            if [int(self.e_w[x]) for x in adj[s].values()].count(wmax) != 1:
+                continue
+            if [int(self.e_w[x]) for x in adj[t].values()].count(wmax) != 1:
+                continue
+            # neighbours of s other than t that also neighbour t: need t's full adjacency, which `adj`
+            # holds because t is a candidate vertex too
+            common = [u for u in adj[s] if u != t and u in adj[t]]
+            if len(common) == 1:
+                doomed.append(common[0])
+                self.stats["bubbles"] += 1
+                self.e_w[e] = wmax
+        if apply_deletions:
+            self._delete_vertices(doomed)
+
+    # ------------------------------------------------------------------ C5/C6/C7: paths -> blocks
+    def _paths(self):
+        m = self.e_alive
+        off, verts = self.walk_fn(self.v_hash.size, self.e_u[m], self.e_v[m])
+        paths = []
+        ref_pos = self.v_pos[self.ref]
+        for i in range(off.size - 1):
+            p = verts[off[i]:off[i + 1]]
+            # start at the end with the smaller position in the reference assembly (ntJoin's
+            # determine_source_vertex; two vertices never share a position in one assembly)
+            if ref_pos[p[-1]] < ref_pos[p[0]]:
+                p = p[::-1]
+            paths.append(p)
+        return paths
+
+    def _orient(self, pos):
+        if pos.size < 2:
+            return "+"
+        d = np.diff(pos)
+        if (d > 0).all():
+            return "+"
+        if (d < 0).all():
+            return "-"
+        pos_perc = int((d > 0).sum()) / float(pos.size - 1) * 100
+        neg_perc = 100 - pos_perc
+        if pos_perc >= self.m:
+            return "+"
+        if neg_perc >= self.m:
+            return "-"
+        return "?"
+
+    def _blocks_of_paths(self, paths):
+        out, drop = [], []
+        for p in paths:
+            if p.size > 1:
+                change = np.zeros(p.size - 1, bool)
+                for a in range(self.G):
+                    r = self.v_rec[a][p]
+                    change |= r[1:] != r[:-1]
+                nz = np.flatnonzero(change)
+                if nz.size:
+                    p = p[nz[-1] + 1:]                     # earlier runs are dropped silently (S:71-77)
+            ori = [self._orient(self.v_pos[a][p]) for a in range(self.G)]
+            if all(o in ("+", "-") for o in ori):
+                out.append(Block(p, [int(self.v_rec[a][p[0]]) for a in range(self.G)], ori))
+            else:
+                drop.append(p)
+        if drop:
+            self._delete_vertices(np.concatenate(drop))
+            self.stats["unoriented"] += len(drop)
+        return out
+
+    # ------------------------------------------------------------------ C8: indel split (S:364-409)
+    def _split_indels(self, blocks):
+        out, cut_u, cut_v = [], [], []
+        for b in blocks:
+            p = b.vids
+            if p.size < 2:
+                out.append(b)
+                continue
+            gaps = np.stack([np.abs(self.v_pos[a][p[:-1]] - self.v_pos[a][p[1:]]) for a in range(self.G)])
+            spread = gaps.max(axis=0) - gaps.min(axis=0)
+            cuts = np.flatnonzero(spread > self.bp)
+            if cuts.size == 0:
+                out.append(b)
+                continue
+            cut_u.append(p[cuts])
+            self.stats["indel_cuts"] += int(cuts.size)
+            cut_v.append(p[cuts + 1])
+            bounds = np.concatenate(([0], cuts + 1, [p.size]))
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                out.append(Block(p[lo:hi], list(b.rec), list(b.ori)))   # contig / orientation inherited (S:383)
+        if cut_u:
+            dead = self._find_edges(np.concatenate(cut_u), np.concatenate(cut_v))
+            self.e_alive[dead] = False
+        return out
+
+    # ------------------------------------------------------------------ C9 (S:411-426)
+    def _drop_small(self, blocks, min_mx):
+        keep, drop = [], []
+        for b in blocks:
+            (keep if b.vids.size >= min_mx else drop).append(b)
+        if drop:
+            self._delete_vertices(np.concatenate([b.vids for b in drop]))
+            self.stats["small_blocks"] += len(drop)
+        return keep
+
+    # ------------------------------------------------------------------ C10: geometry, order, text
+    def _finish(self, b):
+        if not b.first_pos:
+            b.first_pos = [int(self.v_pos[a][b.vids[0]]) for a in range(self.G)]
+            b.last_pos = [int(self.v_pos[a][b.vids[-1]]) for a in range(self.G)]
+            b.n_mx = int(b.vids.size)
+        return b
+
+    def _start(self, b, a):
+        return min(b.first_pos[a], b.last_pos[a])
+
+    def _end(self, b, a):
+        return max(b.first_pos[a], b.last_pos[a]) + self.k
+
+    def _long_enough(self, b):
+        return all(self._end(b, a) - self._start(b, a) >= self.z for a in range(self.G))
+
+    def _sorted(self, blocks):
+        for b in blocks:
+            self._finish(b)
+        return sorted(blocks, key=lambda b: (self.contigs[self.ref][b.rec[self.ref]], self._start(b, self.ref)))
+
+    def _text(self, b, num, verbose):
+        rows = []
+        for a in self.out_order:
+            mt = MX_SUFFIX.search(self.files[a])
+            name = mt.group(1) if mt else self.files[a]
+            row = f"{num}\t{name}\t{self.contigs[a][b.rec[a]]}\t{self._start(b, a)}\t{self._end(b, a)}\t{b.ori[a]}\t{b.n_mx}"
+            if verbose:
+                row = f"{row.strip()}\t{b.reason}"
+            rows.append(row + "\n")
+        return "".join(rows)
+
+    def _emit(self, name, blocks, verbose=False):
+        rows, num = [], 0
+        for b in blocks:
+            if self._long_enough(b):
+                rows.append(self._text(b, num, verbose))
+                num += 1
+        text = "".join(rows)
+        self.outputs[name] = text
+        with open(name, "w", encoding="utf-8") as fh:
+            fh.write(text)
+
+    # ------------------------------------------------------------------ C12: collinear merge (S:428-472)
+    def _merge(self, blocks):
+        out = []
+        cur = blocks[0]
+        for b in blocks[1:]:
+            same_ori = all(cur.ori[a] == b.ori[a] for a in range(self.G))
+            same_ctg = all(cur.rec[a] == b.rec[a] for a in range(self.G))
+            diffs = []
+            for a in range(self.G):
+                if cur.ori[a] == "-" and b.ori[a] == "-":
+                    diffs.append(self._start(cur, a) - self._end(b, a))
+                else:
+                    diffs.append(self._start(b, a) - self._end(cur, a))
+            spread = max(diffs) - min(diffs)
+            if (not same_ori) or (not same_ctg) or spread > self.bp - self.k or max(diffs) >= self.collinear_merge:
+                if not same_ctg:
+                    b.reason = "id_change"
+                elif not same_ori:
+                    b.reason = "ori_change"
+                elif any(d < 0 for d in diffs):
+                    b.reason = "inconsistent_order"
+                elif spread > self.bp - self.k:
+                    b.reason = "indel"
+                elif max(diffs) >= self.collinear_merge:
+                    b.reason = "merge"
+                out.append(cur)
+                cur = b
+            else:
+                cur.last_pos = list(b.last_pos)            # minimizers.extend(): only ends and count matter
+                cur.n_mx += b.n_mx
+                self.stats["merged"] += 1
+        out.append(cur)
+        return out
+
+    # ------------------------------------------------------------------ B5 + C11: refinement inputs
+    def _mask_intervals(self, blocks, w):
+        masks = [[] for _ in range(self.G)]
+        lim = max(2 * w, w + self.k + 1)
+        for b in blocks:
+            self._finish(b)
+            for a in range(self.G):
+                s, e = self._start(b, a), self._end(b, a)
+                if e - s > lim:
+                    s2, e2 = s + (w + self.k), e - (w + self.k)
+                    if e2 > s2:
+                        masks[a].append((b.rec[a], s2, e2))
+        return masks
+
+    def _new_round_graph(self, blocks, new_w, prev_w):
+        masks = self._mask_intervals(blocks, prev_w)
+        nv = self.v_hash.size
+        internal = np.zeros(nv, bool)
+        terminal = np.zeros(nv, bool)
+        for b in blocks:
+            terminal[b.vids[0]] = True
+            terminal[b.vids[-1]] = True
+            internal[b.vids[1:-1]] = True
+        # block interiors [min+1, max) per assembly, per contig (S:194-203)
+        spans = [dict() for _ in range(self.G)]
+        for b in blocks:
+            for a in range(self.G):
+                lo = min(int(self.v_pos[a][b.vids[0]]), int(self.v_pos[a][b.vids[-1]]))
+                hi = max(int(self.v_pos[a][b.vids[0]]), int(self.v_pos[a][b.vids[-1]]))
+                if hi - lo >= 2:
+                    spans[a].setdefault(b.rec[a], []).append((lo + 1, hi))
+        uh, inv = np.unique(self.v_hash, return_inverse=True)
+        internal_h = np.bincount(inv, weights=internal & self.v_alive, minlength=uh.size) > 0
+        lists, keeps, list_ids = [], [], []
+        for a in range(self.G):
+            h1, rec, pos = self.sketch_fn(self.input_order[a], masks[a], new_w)
+            h1 = np.asarray(h1, np.uint64)
+            rec = np.asarray(rec, np.int64)
+            pos = np.asarray(pos, np.int64)
+            # C1: hashes seen once in this (masked) assembly
+            _, inv, cnt = np.unique(h1, return_inverse=True, return_counts=True)
+            uniq = cnt[inv] == 1
+            # is the hash an internal minimizer of a block?  (S:274: `mx not in black_list`)
+            if uh.size:
+                p = np.minimum(np.searchsorted(uh, h1), uh.size - 1)
+                is_internal = (uh[p] == h1) & internal_h[p]
+            else:
+                is_internal = np.zeros(h1.size, bool)
+            inside = np.zeros(h1.size, bool)
+            cut_before = np.zeros(h1.size, bool)
+            for r, ivs in spans[a].items():
+                sel = np.flatnonzero((rec == r) & uniq)
+                if sel.size == 0:
+                    continue
+                ivs = sorted(ivs)
+                st = np.array([x[0] for x in ivs], np.int64)
+                mx_end = np.maximum.accumulate(np.array([x[1] for x in ivs], np.int64))
+
+                def overlaps(s, e):
+                    i = np.searchsorted(st, e, side="left")
+                    return (i > 0) & (mx_end[np.maximum(i - 1, 0)] > s) & (e > s)
+                pp = pos[sel]
+                inside[sel] = overlaps(pp, pp + 1)
+            kept = uniq & ~is_internal & ~inside
+            # cut a list wherever the span between two consecutive kept minimizers crosses a block interior
+            for r, ivs in spans[a].items():
+                sel = np.flatnonzero((rec == r) & kept)
+                if sel.size < 2:
+                    continue
+                ivs = sorted(ivs)
+                st = np.array([x[0] for x in ivs], np.int64)
+                mx_end = np.maximum.accumulate(np.array([x[1] for x in ivs], np.int64))
+                s, e = pos[sel[:-1]], pos[sel[1:]]
+                i = np.searchsorted(st, e, side="left")
+                ov = (i > 0) & (mx_end[np.maximum(i - 1, 0)] > s) & (e > s)
+                cut_before[sel[1:][ov]] = True
+            # list ids: a new list at every record change and at every cut
+            new_list = np.ones(h1.size, bool)
+            if h1.size:
+                new_list[1:] = (rec[1:] != rec[:-1]) | cut_before[1:]
+            lid = np.cumsum(new_list) - 1
+            lists.append((h1, rec, pos))
+            keeps.append(kept)
+            list_ids.append(lid)
+        ga = self.graph_fn(lists, keeps, list_ids)
+        self._add_graph(ga)
+        return terminal
+
+    # ------------------------------------------------------------------ last-round erosion (S:292-362)
+    def _refine_graph(self, flagged):
+        if flagged[0].size == 0:
+            return
+        deg = self._degrees()
+        m = self.e_alive
+        idx = np.flatnonzero(m)
+        inc = {}
+        involved = set()
+
+        def neighbours(v):
+            if v not in inc:
+                sel = idx[(self.e_u[idx] == v) | (self.e_v[idx] == v)]
+                inc[v] = [(int(e), int(self.e_v[e]) if int(self.e_u[e]) == v else int(self.e_u[e])) for e in sel]
+            return inc[v]
+
+        def too_close(a, b):
+            return bool((np.abs(self.v_pos[:, a] - self.v_pos[:, b]) < self.k).any())
+        dead = set()
+        for s, t in zip(flagged[0].tolist(), flagged[1].tolist()):
+            if str(int(self.v_hash[s])) > str(int(self.v_hash[t])):
+                s, t = t, s
+            if deg[s] != 1 or deg[t] != 1:
+                continue
+            erode_target, cs, ct = True, s, t
+            visited = {s, t}
+            while too_close(cs, ct):
+                v = ct if erode_target else cs
+                nb = neighbours(v)
+                dead.update(e for e, _ in nb)
+                nxt = [u for _, u in nb if u not in visited]
+                if not nxt:
+                    break
+                assert len(nxt) == 1
+                if erode_target:
+                    ct = nxt[0]
+                    visited.add(ct)
+                else:
+                    cs = nxt[0]
+                    visited.add(cs)
+                erode_target = not erode_target
+        if dead:
+            self.e_alive[np.fromiter(dead, dtype=np.int64)] = False
+            self.stats["eroded_edges"] += len(dead)
+        del involved
+
+    # ------------------------------------------------------------------ drivers (S:476-530, S:593-647)
+    def _round_blocks(self):
+        blocks = self._blocks_of_paths(self._paths())
+        blocks = self._split_indels(blocks)
+        return self._drop_small(blocks, 4)
+
+    def run(self, initial_lists):
+        """initial_lists[i] = (h1, rec, pos) of assembly i in the caller's order."""
+        if len(self.w_rounds) != len(set(self.w_rounds)):
+            print("Error: duplicate values found in w_rounds!", file=sys.stderr, flush=True)
+            sys.exit(1)
+        lists = [initial_lists[i] for i in self.input_order]
+        ga = self.graph_fn(lists, None, None)
+        self._add_graph(ga)
+        if self.simplify:
+            self._simplify(apply_deletions=True)
+        if self.n > 1:
+            self.e_alive &= self.e_w >= self.n
+        blocks = self._round_blocks()
+        ordered = self._sorted(blocks)
+        if not ordered:
+            print("Error - no paths found. Try adjusting the specified k/w parameters.")
+            sys.exit(1)
+        self._emit(f"{self.prefix}.synteny_blocks.tsv", ordered)
+        prev_w = self.w
+        for new_w in self.w_rounds:
+            self.log(f"Extending synteny blocks with w = {new_w}")
+            self._new_round_graph(blocks, new_w, prev_w)
+            if self.simplify:
+                self._simplify(apply_deletions=False)
+            last = new_w == self.w_rounds[-1]
+            light = self.e_alive & (self.e_w < self.n)
+            flagged = (self.e_u[light], self.e_v[light])
+            if last or self.n > 1:
+                self.e_alive &= ~light
+            if last:
+                self._refine_graph(flagged)
+            blocks = self._round_blocks()
+            ordered = self._sorted(blocks)
+            self._emit(f"{self.prefix}.pre-collinear-merge.synteny_blocks.tsv", ordered)
+            if last and ordered:
+                merged = self._merge(ordered)
+                merged = [b for b in merged if self._long_enough(b)]
+                if merged:
+                    merged = self._merge(merged)
+                self._emit(f"{self.prefix}.synteny_blocks.tsv", merged, verbose=True)
+            prev_w = new_w
+        return self.outputs

@@ -28,8 +28,34 @@ def make_ancestor(total_bp, n_contigs, seed=BASE_SEED):
     return [random_dna(per, rng) for _ in range(n_contigs)]
 
 
+def _micro_events(contigs, rng, n_events):
+    """Small rearrangements (0.3-3 kbp segments moved / copied / inverted a few tens of kbp away): they
+    create bubbles in the minimizer graph, short blocks, and nearby collinear blocks that merge."""
+    out = []
+    for g in contigs:
+        g = g.copy()
+        for _ in range(n_events):
+            ln = int(rng.integers(300, 3000))
+            if g.size < 20 * ln:
+                break
+            st = int(rng.integers(ln, g.size - 2 * ln))
+            kind = rng.random()
+            seg = g[st:st + ln].copy()
+            if kind < 0.4:      # move
+                rest = np.concatenate([g[:st], g[st + ln:]])
+                dst = int(np.clip(st + rng.integers(-60000, 60000), ln, rest.size - ln))
+                g = np.concatenate([rest[:dst], seg, rest[dst:]])
+            elif kind < 0.7:    # copy
+                dst = int(np.clip(st + rng.integers(-60000, 60000), ln, g.size - ln))
+                g = np.concatenate([g[:dst], seg, g[dst:]])
+            else:               # invert in place
+                g[st:st + ln] = revcomp(seg)
+        out.append(g)
+    return out
+
+
 def derive_genome(ancestor, divergence, j, seed=BASE_SEED, structural=True, n_runs=False,
-                  soft_mask=False):
+                  soft_mask=False, micro=0):
     """Genome j of a family.  `divergence` is the pairwise fraction (0.01 for 1 %)."""
     rng = np.random.Generator(np.random.PCG64(seed + 1 + j))
     contigs = []
@@ -44,6 +70,8 @@ def derive_genome(ancestor, divergence, j, seed=BASE_SEED, structural=True, n_ru
         contigs.append(g)
     if structural and j > 0:
         contigs = _structural_events(contigs, rng)
+    if micro and j > 0:
+        contigs = _micro_events(contigs, rng, micro)
     if n_runs:
         for g in contigs:
             n_ev = max(1, g.size // 200000)
@@ -116,13 +144,13 @@ def write_fasta(path, contigs, names=None, line_width=0):
 
 
 def make_family(outdir, n_genomes, total_bp, n_contigs, divergence, seed=BASE_SEED, prefix="syn",
-                structural=True, n_runs=False, soft_mask=False, line_width=0):
+                structural=True, n_runs=False, soft_mask=False, line_width=0, micro=0):
     """Write `n_genomes` FASTA files; returns their paths."""
     import os
     anc = make_ancestor(total_bp, n_contigs, seed)
     paths = []
     for j in range(n_genomes):
-        g = derive_genome(anc, divergence, j, seed, structural, n_runs, soft_mask)
+        g = derive_genome(anc, divergence, j, seed, structural, n_runs, soft_mask, micro)
         p = os.path.join(outdir, f"{prefix}{j}.fa")
         write_fasta(p, g, line_width=line_width)
         paths.append(p)

@@ -1,0 +1,108 @@
+"""End to end on the GPU: FASTA files -> byte-identical artefacts vs the CPU oracle pipeline, the
+device graph build vs its numpy statement, and the ntSynt-compatible CLI."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from ntsynt_amd import synth
+from oracle import nts_oracle as O
+from oracle import synteny_oracle as SO
+from tests.graph_ref import build_graph_numpy
+from tests.helpers import oracle_flat
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _both(tmp_path, paths, **kw):
+    from ntsynt_amd import pipeline
+    cwd = os.getcwd()
+    try:
+        os.makedirs(tmp_path / "ora")
+        os.makedirs(tmp_path / "hip")
+        os.chdir(tmp_path / "ora")
+        ora = SO.run_pipeline(paths, prefix="p", **kw)
+        os.chdir(tmp_path / "hip")
+        eng = pipeline.run(paths, prefix="p", log=lambda *a: None, **kw)
+    finally:
+        os.chdir(cwd)
+    return ora, eng
+
+
+CASES = [
+    dict(n=3, bp=3_000_000, ctg=3, div=0.01, seed=21, micro=0, n_runs=True,
+         kw=dict(k=24, w=1000, w_rounds=[100, 10], indel=500, merge=3000, block_size=500)),
+    dict(n=2, bp=2_000_000, ctg=2, div=0.005, seed=9, micro=12, n_runs=False,
+         kw=dict(k=24, w=200, w_rounds=[50, 10], indel=5000, merge=20000, block_size=300)),
+    dict(n=4, bp=1_600_000, ctg=2, div=0.02, seed=33, micro=6, n_runs=True,
+         kw=dict(k=20, w=500, w_rounds=[250, 100], indel=50000, merge="100w", block_size=1000)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=["d05-3g", "micro-2g", "d1-4g"])
+def test_pipeline_byte_identical(tmp_path, case):
+    paths = synth.make_family(str(tmp_path), case["n"], case["bp"], case["ctg"], case["div"], seed=case["seed"],
+                              micro=case["micro"], n_runs=case["n_runs"], soft_mask=True,
+                              line_width=(60 if case["seed"] % 2 else 0))
+    ora, eng = _both(tmp_path, paths, **case["kw"])
+    k, w = case["kw"]["k"], case["kw"]["w"]
+    assert eng.outputs["p.synteny_blocks.tsv"] == ora.outputs["p.synteny_blocks.tsv"]
+    assert eng.outputs["p.pre-collinear-merge.synteny_blocks.tsv"] == ora.outputs["p.pre-collinear-merge.synteny_blocks.tsv"]
+    assert len(eng.outputs["p.synteny_blocks.tsv"].splitlines()) >= 2 * case["n"]
+    for p in paths:
+        name = f"{os.path.basename(p)}.k{k}.w{w}.tsv"
+        assert open(tmp_path / "hip" / name).read() == open(tmp_path / "ora" / name).read(), name
+    # the Bloom filter file holds the same bits as the oracle's cascade
+    from ntsynt_amd.pipeline import read_bf
+    bits, kk = read_bf(str(tmp_path / "hip" / "p.common.bf"))
+    assert kk == k and np.array_equal(bits, ora.bf)
+
+
+def test_graph_build_device_vs_numpy(tmp_path):
+    from ntsynt_amd.device import Context
+    from ntsynt_amd.graph import build_graph_device
+    paths = synth.make_family(str(tmp_path), 3, 1_500_000, 2, 0.01, seed=5, micro=8)
+    genomes = [O.read_fasta(p) for p in paths]
+    lists = [oracle_flat(O.minimize(g, 24, 300)) for g in genomes]
+    rng = np.random.default_rng(3)
+    keeps = [rng.random(len(l[0])) < 0.97 for l in lists]
+    lids = [(l[1].astype(np.int64) * 1000 + np.cumsum(rng.random(len(l[0])) < 0.01)).astype(np.uint32) for l in lists]
+    ctx = Context(0)
+    for kp, li in ((None, None), (keeps, lids)):
+        d = build_graph_device(ctx, lists, kp, li)
+        h = build_graph_numpy(lists, kp, li)
+        assert np.array_equal(d.v_hash, h.v_hash) and d.v_hash.size > 1000
+        assert np.array_equal(d.occ_rec, h.occ_rec) and np.array_equal(d.occ_pos, h.occ_pos)
+        for f in ("e_u", "e_v", "e_w", "e_first"):
+            assert np.array_equal(getattr(d, f), getattr(h, f)), f
+    ctx.close()
+
+
+def test_cli_runs_like_the_reference_tests(tmp_path):
+    "tests/ntsynt_tests.py:40-59 shape: `ntSynt ... -d 0.5 --indel 500 --merge 3000`, positional and --fastas_list"
+    paths = synth.make_family(str(tmp_path), 3, 1_200_000, 2, 0.01, seed=8)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bin", "ntSynt"), "--force", *paths, "-k20", "-w", "500", "-d", "0.5",
+           "--prefix", "cli", "--indel", "500", "--merge", "3000"]
+    subprocess.run(cmd, cwd=tmp_path, env=env, check=True, stdout=subprocess.DEVNULL)
+    fof = tmp_path / "list.tsv"
+    fof.write_text("\n".join(paths) + "\n")
+    cmd2 = [sys.executable, os.path.join(ROOT, "bin", "ntSynt"), "--force", "--fastas_list", str(fof), "-k20", "-w", "500",
+            "-d", "0.5", "--prefix", "cli-fof", "--indel", "500", "--merge", "3000"]
+    subprocess.run(cmd2, cwd=tmp_path, env=env, check=True, stdout=subprocess.DEVNULL)
+    a = (tmp_path / "cli.synteny_blocks.tsv").read_text()
+    b = (tmp_path / "cli-fof.synteny_blocks.tsv").read_text()
+    assert a == b and len(a.splitlines()) >= 6
+    cwd = os.getcwd()
+    try:
+        os.makedirs(tmp_path / "ora")
+        os.chdir(tmp_path / "ora")
+        ora = SO.run_pipeline(paths, k=20, w=500, w_rounds=[100, 10], indel=500, merge="3000", block_size=500, prefix="cli")
+    finally:
+        os.chdir(cwd)
+    assert a == ora.outputs["cli.synteny_blocks.tsv"]
+    for p in paths:
+        assert os.path.exists(tmp_path / f"{os.path.basename(p)}.fai")
