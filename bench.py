@@ -11,7 +11,9 @@ of the minimizer lists (SURVEY.md 8(e) exchange 2).  Weak scaling: every rank ho
 whole family (exchange 1, timed separately and reported under "bloom").
 
 N=1 workload = BASELINE.json configs[1]: 3 synthetic 100 Mbp genomes at 1 % divergence, k=24 w=1000.
-Prints ONE JSON line (rank 0).
+The timed steps use the library's default policy (exact pruning of Bloom probes, nts_pruned.inc); the
+same sketch with every k-mer probed ("dense", SURVEY.md 8(d)'s 65 B/base formulation) is run after the
+timed region and reported under roofline.unpruned.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -24,8 +26,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_BASE = 1.0 + 64.0 + 32.0 / 1001.0   # sketch-with-filter, w=1000
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+SECTOR = 64.0                                        # bytes moved per Bloom probe
 
 
 def parse():
@@ -40,8 +42,10 @@ def parse():
     ap.add_argument("-k", type=int, default=24)
     ap.add_argument("-w", type=int, default=1000)
     ap.add_argument("--fpr", type=float, default=0.025)
+    ap.add_argument("--mode", choices=["auto", "dense", "pruned"], default="auto")
+    ap.add_argument("--prune-c", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mbp", type=float, default=64.0)
+    ap.add_argument("--no-dense-leg", action="store_true")
     return ap.parse_args()
 
 
@@ -95,6 +99,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = Context(local_rank)
+    ctx.sketch_mode(args.mode, args.prune_c)
     k, w = args.k, args.w
     total_bp = int(args.mbp * 1e6)
 
@@ -162,37 +167,63 @@ def main():
         ctx.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.profile(True)
-    fence()
-    t0 = time.time()
-    n_mx = 0
-    for _ in range(args.steps):
-        n_mx = step()
-    fence()
-    dt = time.time() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    hp_ms, hp_n = ctx.timing("hash_probe")
-    wm_ms, wm_n = ctx.timing("window_min")
-    st_ms, st_n = ctx.timing("sort_minimizers")
-    fz_ms, fz_n = ctx.timing("finalize")
-    # outside the timed region: the same sketch without the Bloom probe (ALU + streaming only)
-    sketch(ctx, genomes[0], k, w, None).free()
-    ctx.profile(True)
-    sketch(ctx, genomes[0], k, w, None).free()
-    ho_ms, ho_n = ctx.timing("hash_only")
+    def timed(n_warm, n_steps):
+        for _ in range(n_warm):
+            step()
+        ctx.profile(True)
+        fence()
+        t_start = time.time()
+        n_mx = 0
+        for _ in range(n_steps):
+            n_mx = step()
+        fence()
+        el = time.time() - t_start
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, n_mx
+
+    dt, n_mx = timed(args.warmup, args.steps)
+    names = ["hash_select", "cand_compact", "sparse_win", "hash_probe", "window_min", "sort_minimizers", "finalize"]
+    tm = {n: ctx.timing(n) for n in names}
+    cand, gaps, gap_kmers = ctx.sketch_stats()
+    per_launch_bases = bases / len(genomes)
+
+    def avg(n):
+        return tm[n][0] / max(tm[n][1], 1)
+
+    dense = None
+    if args.mode != "dense" and not args.no_dense_leg and world == 1:
+        ctx.sketch_mode("dense")
+        d_dt, _ = timed(1, max(2, args.steps // 2))
+        hp_ms, hp_n = ctx.timing("hash_probe")
+        wm_ms, wm_n = ctx.timing("window_min")
+        a_ms = hp_ms / max(hp_n, 1)
+        bpb = 1.0 + SECTOR + 32.0 / (w + 1)
+        ach = bpb * per_launch_bases / (a_ms * 1e-3) / 1e9
+        dense = {"kernel": "k_hash<MODE_KEYS> (every k-mer probed)", "algorithmic_bytes_per_base": round(bpb, 3),
+                 "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(a_ms, 4),
+                 "window_min_avg_ms": round(wm_ms / max(wm_n, 1), 4),
+                 "value_Gbases_s": round(bases * max(2, args.steps // 2) / d_dt / 1e9, 3)}
+        ctx.sketch_mode(args.mode, args.prune_c)
 
     if rank == 0:
         value = bases * world * args.steps / dt / 1e9
-        per_launch_bases = bases / len(genomes)
-        avg_ms = hp_ms / max(hp_n, 1)
-        achieved = ALGO_BYTES_PER_BASE * per_launch_bases / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        pruned_run = tm["hash_select"][1] > 0
+        if pruned_run:
+            kern, a_ms = "k_hash_select (hash every k-mer, probe candidates only)", avg("hash_select")
+            probe_frac = min(1.0, args.prune_c / w)
+            # bytes the pruned kernel has to move per base: the base, one sector per probed candidate,
+            # 16 B per accepted candidate written
+            bpb = 1.0 + SECTOR * probe_frac + 16.0 * cand / per_launch_bases
+        else:
+            kern, a_ms = "k_hash<MODE_KEYS> (every k-mer probed)", avg("hash_probe")
+            bpb = 1.0 + SECTOR + 32.0 / (w + 1)
+        achieved = bpb * per_launch_bases / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
         out = {
             "metric": "minimizer-sketch Gbases/s (sketch with common Bloom filter, inputs resident in HBM)",
             "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
@@ -200,17 +231,17 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.genomes} synthetic {args.mbp:g} Mbp genomes per GPU at "
                                    f"{args.divergence * 100:g}% divergence, k={k} w={w} fpr={args.fpr}",
+                       "sketch_mode": args.mode, "prune_c": args.prune_c,
                        "genomes_per_gpu": args.genomes, "bases_per_step_per_gpu": bases,
                        "minimizers_per_step_per_gpu": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)"},
-            "roofline": {"bound": "hbm", "kernel": "k_hash<MODE_KEYS> (hash_probe)",
+            "roofline": {"bound": "hbm", "kernel": kern,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_base": round(ALGO_BYTES_PER_BASE, 3),
-                         "avg_launch_ms": round(avg_ms, 4), "launches": hp_n,
-                         "window_min_avg_ms": round(wm_ms / max(wm_n, 1), 4),
-                         "sort_avg_ms": round(st_ms / max(st_n, 1), 4),
-                         "finalize_avg_ms": round(fz_ms / max(fz_n, 1), 4),
-                         "hash_without_probe_avg_ms": round(ho_ms / max(ho_n, 1), 4)},
+                         "algorithmic_bytes_per_base": round(bpb, 3),
+                         "avg_launch_ms": round(a_ms, 4), "launches": tm["hash_select" if pruned_run else "hash_probe"][1],
+                         "other_kernels_avg_ms": {n: round(avg(n), 4) for n in names if tm[n][1]},
+                         "candidates_per_launch": cand, "uncovered_ranges": gaps, "uncovered_kmers": gap_kmers,
+                         "unpruned": dense},
             "bloom": {"bytes": nbytes, "build_s": round(t_build, 4), "allreduce_and_s": round(t_allreduce, 4),
                       "bf_insert_avg_ms": round(ins_ms / max(ins_n, 1), 4),
                       "bf_insert_Gbases_s": round(per_launch_bases / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 3)

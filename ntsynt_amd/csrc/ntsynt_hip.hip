@@ -59,6 +59,12 @@ struct nts_ctx
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
   // grow-only device scratch, reused across calls (a ctx serves one call at a time)
   std::map<std::string, std::pair<void*, size_t>> ws;
+  // sketch policy: 0 auto (pruned when w >= 256), 1 dense, 2 pruned; prune_c/w = fraction of hashes kept as candidates
+  std::vector<std::pair<void*, uint64_t>> mx_pool; // recycled result allocations
+  size_t win_lds_set = 0;
+  int sketch_mode = 0;
+  uint32_t prune_c = 32;
+  uint64_t last_candidates = 0, last_gaps = 0, last_gap_kmers = 0;
 };
 
 struct nts_genome
@@ -70,6 +76,9 @@ struct nts_genome
   uint64_t total_bases = 0;
   // maximal stretches [a,b) of valid bases, clipped to records, ascending
   std::vector<uint64_t> st_a, st_b;
+  uint64_t* d_rec_off = nullptr; // [n_rec] record offsets on the device
+  // per-k run table + record tables, built on first use and kept on the device (unmasked sketches)
+  mutable std::map<uint32_t, struct GenomeTables*> tables;
 };
 
 struct nts_bf
@@ -82,6 +91,7 @@ struct nts_bf
 struct nts_mx
 {
   uint64_t n = 0;
+  uint64_t cap_bytes = 0; // size of the single allocation behind d_h1 | d_pos | d_rec
   uint64_t* d_h1 = nullptr;
   uint32_t* d_rec = nullptr;
   uint64_t* d_pos = nullptr;
@@ -297,7 +307,8 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
                                                        const uint32_t* __restrict__ bf_in,
                                                        uint32_t* __restrict__ bf_out,
                                                        FastMod fm,
-                                                       uint64_t* __restrict__ keys)
+                                                       uint64_t* __restrict__ keys,
+                                                       const uint32_t* __restrict__ tile_ids)
 {
   __shared__ uint64_t s_tab[36];
   __shared__ uint32_t s_seq[SEQ_LDS_DWORDS];
@@ -308,7 +319,8 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
   }
   if (tid < 4) s_tab[32 + tid] = hp.seed[tid];
   const uint32_t k = hp.k;
-  const uint64_t J0 = (uint64_t)blockIdx.x * KEY_TILE;
+  // tile_ids (optional): the key tiles to compute, for the dense fallback on uncovered ranges only
+  const uint64_t J0 = (uint64_t)(tile_ids ? tile_ids[blockIdx.x] : blockIdx.x) * KEY_TILE;
   const uint32_t tile_len = (uint32_t)min((uint64_t)KEY_TILE, n_valid - J0);
   // run holding J0 (same for every lane: broadcast loads)
   uint32_t lo = 0, hi = n_runs;
@@ -828,24 +840,135 @@ int upload_runs(nts_ctx* ctx, const RunTable& rt, DevRuns& dr)
   return ws_upload(ctx, "run_vstart", rt.vstart, &dr.vstart);
 }
 
-template <int MODE>
-int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const RunTable& rt, const DevRuns& dr, uint32_t k,
-                const nts_bf* bf_in, nts_bf* bf_out, uint64_t* keys)
+} // namespace
+
+// Run table and per-record tables of one (genome, k): host copy + device arrays.  Cached in the genome
+// handle for unmasked calls (`owned`), built into context scratch for masked refinement rounds.
+struct GenomeTables
 {
+  RunTable rt;
+  uint64_t *d_run_pos = nullptr, *d_run_vstart = nullptr, *d_rec_vstart = nullptr, *d_rec_nv = nullptr;
+  uint32_t n_runs = 0;
+  bool owned = false;
+  mutable std::map<uint32_t, std::pair<uint64_t, uint64_t*>> win_tiles; // w -> (tiles, device prefix array)
+  uint64_t n_win_tiles(uint32_t w) const
+  {
+    auto it = win_tiles.find(w);
+    if (it != win_tiles.end()) return it->second.first;
+    uint64_t n = 0;
+    for (uint64_t nv : rt.rec_nv) n += ((nv >= w ? nv - w + 1 : 0) + WIN_TILE - 1) / WIN_TILE;
+    win_tiles[w] = { n, nullptr };
+    return n;
+  }
+  int win_tiles_device(nts_ctx* ctx, uint32_t w, const uint64_t** out) const
+  {
+    n_win_tiles(w);
+    auto& e = win_tiles[w];
+    if (!e.second) {
+      std::vector<uint64_t> ts(rt.rec_nv.size() + 1, 0);
+      for (size_t r = 0; r < rt.rec_nv.size(); ++r) {
+        const uint64_t nv = rt.rec_nv[r];
+        ts[r + 1] = ts[r] + ((nv >= w ? nv - w + 1 : 0) + WIN_TILE - 1) / WIN_TILE;
+      }
+      uint64_t* d = nullptr;
+      if (owned) {
+        HIP_TRY(ctx, hipMalloc((void**)&d, ts.size() * 8));
+        HIP_TRY(ctx, hipMemcpy(d, ts.data(), ts.size() * 8, hipMemcpyHostToDevice));
+        e.second = d;
+      } else {
+        int rc = ws_upload(ctx, "win_tiles_masked", ts, &d);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `ts` dies here
+        *out = d;
+        return NTS_OK;
+      }
+    }
+    *out = e.second;
+    return NTS_OK;
+  }
+  void release()
+  {
+    if (!owned) return;
+    hipFree(d_run_pos);
+    hipFree(d_run_vstart);
+    hipFree(d_rec_vstart);
+    hipFree(d_rec_nv);
+    for (auto& kv : win_tiles)
+      if (kv.second.second) hipFree(kv.second.second);
+  }
+};
+
+namespace {
+
+int get_tables(nts_ctx* ctx, const nts_genome* g, uint32_t k, const nts_interval* mask, uint64_t n_mask, GenomeTables& scratch,
+               const GenomeTables** out)
+{
+  if (n_mask == 0) {
+    auto it = g->tables.find(k);
+    if (it != g->tables.end()) {
+      *out = it->second;
+      return NTS_OK;
+    }
+    GenomeTables* T = new GenomeTables();
+    int rc = build_runs(ctx, g, k, nullptr, 0, T->rt);
+    if (rc) {
+      delete T;
+      return rc;
+    }
+    if (T->rt.pos.size() > 0xFFFFFFF0ULL) {
+      delete T;
+      return fail(ctx, NTS_ERANGE, "too many valid runs");
+    }
+    T->owned = true;
+    T->n_runs = (uint32_t)T->rt.pos.size();
+    auto up = [&](const std::vector<uint64_t>& h, uint64_t** d) -> bool {
+      if (hipMalloc((void**)d, std::max<size_t>(h.size(), 1) * 8) != hipSuccess) return false;
+      return h.empty() || hipMemcpy(*d, h.data(), h.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(T->rt.pos, &T->d_run_pos) || !up(T->rt.vstart, &T->d_run_vstart) || !up(T->rt.rec_vstart, &T->d_rec_vstart) ||
+        !up(T->rt.rec_nv, &T->d_rec_nv)) {
+      T->release();
+      delete T;
+      return fail(ctx, NTS_ENOMEM, "genome tables: device allocation failed");
+    }
+    g->tables[k] = T;
+    *out = T;
+    return NTS_OK;
+  }
+  int rc = build_runs(ctx, g, k, mask, n_mask, scratch.rt);
+  if (rc) return rc;
+  if (scratch.rt.pos.size() > 0xFFFFFFF0ULL) return fail(ctx, NTS_ERANGE, "too many valid runs");
+  scratch.n_runs = (uint32_t)scratch.rt.pos.size();
+  if ((rc = ws_upload(ctx, "run_pos", scratch.rt.pos, &scratch.d_run_pos))) return rc;
+  if ((rc = ws_upload(ctx, "run_vstart", scratch.rt.vstart, &scratch.d_run_vstart))) return rc;
+  if ((rc = ws_upload(ctx, "rec_vstart", scratch.rt.rec_vstart, &scratch.d_rec_vstart))) return rc;
+  if ((rc = ws_upload(ctx, "rec_nv", scratch.rt.rec_nv, &scratch.d_rec_nv))) return rc;
+  *out = &scratch;
+  return NTS_OK;
+}
+
+template <int MODE>
+int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const GenomeTables& T, uint32_t k,
+                const nts_bf* bf_in, nts_bf* bf_out, uint64_t* keys, const uint32_t* d_tile_ids = nullptr, uint64_t n_tile_ids = 0)
+{
+  const RunTable& rt = T.rt;
   if (rt.n_valid == 0) return NTS_OK;
+  if (d_tile_ids && n_tile_ids == 0) return NTS_OK;
   const HashParams hp = make_hash_params(k);
   const uint64_t bits = (bf_in ? bf_in->bytes : (bf_out ? bf_out->bytes : 8)) * 8;
   const FastMod fm = make_fastmod(bits);
   const uint64_t per_block = (uint64_t)HASH_THREADS * HASH_PER_THREAD;
-  const uint64_t blocks = (rt.n_valid + per_block - 1) / per_block;
+  const uint64_t blocks = d_tile_ids ? n_tile_ids : (rt.n_valid + per_block - 1) / per_block;
   if (blocks > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
   ScopedTimer t(ctx, name);
-  hipLaunchKernelGGL(k_hash<MODE>, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, dr.pos,
-                     dr.vstart, dr.n, rt.n_valid, hp, bf_in ? bf_in->d_words : nullptr, bf_out ? bf_out->d_words : nullptr,
-                     fm, keys);
+  hipLaunchKernelGGL(k_hash<MODE>, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, T.d_run_pos,
+                     T.d_run_vstart, T.n_runs, rt.n_valid, hp, bf_in ? bf_in->d_words : nullptr, bf_out ? bf_out->d_words : nullptr,
+                     fm, keys, d_tile_ids);
   HIP_TRY(ctx, hipGetLastError());
   return NTS_OK;
 }
+
+#include "nts_pruned.inc"
 
 } // namespace
 
@@ -885,6 +1008,7 @@ void nts_destroy(nts_ctx* ctx)
   drain_timings(ctx);
   hipStreamSynchronize(ctx->stream);
   ws_release(ctx);
+  for (auto& p : ctx->mx_pool) hipFree(p.first);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1036,6 +1160,9 @@ int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64
       a = rb;
     }
   }
+  if (hipMalloc((void**)&g->d_rec_off, std::max<uint32_t>(n_rec, 1) * 8) != hipSuccess ||
+      (n_rec && hipMemcpy(g->d_rec_off, g->rec_off.data(), n_rec * 8, hipMemcpyHostToDevice) != hipSuccess))
+    return bail(NTS_ENOMEM, "hipMalloc record offsets");
   *out = g;
   return NTS_OK;
 }
@@ -1043,7 +1170,15 @@ int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64
 void nts_genome_free(nts_ctx* ctx, nts_genome* g)
 {
   if (!g) return;
-  if (ctx) hipSetDevice(ctx->device);
+  if (ctx) {
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+  }
+  for (auto& kv : g->tables) {
+    kv.second->release();
+    delete kv.second;
+  }
+  if (g->d_rec_off) hipFree(g->d_rec_off);
   if (g->d_code) hipFree(g->d_code);
   delete g;
 }
@@ -1144,15 +1279,14 @@ static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nt
   if (!ctx || !next || !g || k == 0) return fail(ctx, NTS_EINVAL, "bloom pass: bad arguments");
   if (prev && prev->bytes != next->bytes) return fail(ctx, NTS_EINVAL, "bloom pass: filters differ in size");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  RunTable rt;
-  int rc = build_runs(ctx, g, k, nullptr, 0, rt);
+  GenomeTables scratch;
+  const GenomeTables* T = nullptr;
+  int rc = get_tables(ctx, g, k, nullptr, 0, scratch, &T);
   if (rc) return rc;
-  DevRuns dr;
-  if ((rc = upload_runs(ctx, rt, dr))) return rc;
   if (prev)
-    rc = launch_hash<MODE_CASCADE>(ctx, "bf_cascade", g, rt, dr, k, prev, next, nullptr);
+    rc = launch_hash<MODE_CASCADE>(ctx, "bf_cascade", g, *T, k, prev, next, nullptr);
   else
-    rc = launch_hash<MODE_INSERT>(ctx, "bf_insert", g, rt, dr, k, nullptr, next, nullptr);
+    rc = launch_hash<MODE_INSERT>(ctx, "bf_insert", g, *T, k, nullptr, next, nullptr);
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // run table buffers are released on return
   return NTS_OK;
@@ -1226,16 +1360,16 @@ int nts_hash_all(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t** h0, u
 {
   if (!ctx || !g || !h0 || !n_out || k == 0) return fail(ctx, NTS_EINVAL, "nts_hash_all: bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  RunTable rt;
-  int rc = build_runs(ctx, g, k, nullptr, 0, rt);
+  GenomeTables scratch;
+  const GenomeTables* T = nullptr;
+  int rc = get_tables(ctx, g, k, nullptr, 0, scratch, &T);
   if (rc) return rc;
-  DevRuns dr;
-  if ((rc = upload_runs(ctx, rt, dr))) return rc;
+  const RunTable& rt = T->rt;
   uint64_t* d_keys = nullptr;
   uint64_t* d_lin = nullptr;
   HIP_TRY(ctx, hipMalloc((void**)&d_keys, key_buffer_elems(rt.n_valid) * 8));
   HIP_TRY(ctx, hipMalloc((void**)&d_lin, std::max<uint64_t>(rt.n_valid, 1) * 8));
-  rc = launch_hash<MODE_KEYS>(ctx, "hash_only", g, rt, dr, k, nullptr, nullptr, d_keys);
+  rc = launch_hash<MODE_KEYS>(ctx, "hash_only", g, *T, k, nullptr, nullptr, d_keys);
   uint64_t* host = (uint64_t*)malloc(std::max<uint64_t>(rt.n_valid, 1) * 8);
   if (rc == NTS_OK && rt.n_valid) {
     hipLaunchKernelGGL(k_keys_linear, dim3((uint32_t)((rt.n_valid + 255) / 256)), dim3(256), 0, ctx->stream, d_keys, rt.n_valid, d_lin);
@@ -1253,33 +1387,291 @@ int nts_hash_all(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t** h0, u
   return NTS_OK;
 }
 
-int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const nts_bf* filter, const nts_interval* mask,
-               uint64_t n_mask, nts_mx** out)
+} // extern "C"
+
+namespace {
+
+struct OutSegs
+{
+  uint64_t* d_j = nullptr;
+  uint64_t* d_key = nullptr;
+  unsigned long long* d_count = nullptr;
+  uint64_t seg_cap = 0;
+};
+
+// window tiles over a table of (pseudo-)records; returns the number of tiles
+uint64_t tiles_of(const std::vector<uint64_t>& nv, uint32_t w, std::vector<uint64_t>& tile_start)
+{
+  tile_start.assign(nv.size() + 1, 0);
+  for (size_t r = 0; r < nv.size(); ++r) {
+    const uint64_t n_win = nv[r] >= w ? nv[r] - w + 1 : 0;
+    tile_start[r + 1] = tile_start[r] + (n_win + WIN_TILE - 1) / WIN_TILE;
+  }
+  return tile_start.back();
+}
+
+// dense window kernel over (pseudo-)records already resident on the device; keys must be present for them
+int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vs, const uint64_t* d_nv, const uint64_t* d_ts,
+                        uint32_t n_rec, uint64_t n_tiles, uint32_t w, const OutSegs& out, const char* tag)
+{
+  if (n_tiles == 0) return NTS_OK;
+  if (n_tiles > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "too many window tiles for one launch");
+  WinParams P;
+  P.keys = d_keys;
+  P.rec_vstart = d_vs;
+  P.rec_nv = d_nv;
+  P.tile_start = d_ts;
+  P.n_rec = n_rec;
+  P.w = w;
+  P.chunk = std::min<uint32_t>(WIN_CHUNK, w);
+  const uint32_t max_full = w / P.chunk;
+  P.levels = 1;
+  while ((1u << P.levels) <= max_full) ++P.levels;
+  const uint32_t E_max = WIN_TILE + 1 + w - 1;
+  const uint32_t chunks_max = (E_max + P.chunk - 1) / P.chunk;
+  const size_t lds = (size_t)(E_max + E_max / 32 + 2) * 8 + 16 + (size_t)(WIN_TILE + 16) * 2 + (size_t)P.levels * chunks_max * 2 + 64;
+  if (lds > 160 * 1024) return fail(ctx, NTS_ERANGE, "window tile does not fit LDS");
+  if (lds > ctx->win_lds_set) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_window_min, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ctx->win_lds_set = lds;
+  }
+  P.out_j = out.d_j;
+  P.out_key = out.d_key;
+  P.seg_count = out.d_count;
+  P.seg_cap = out.seg_cap;
+  ScopedTimer t(ctx, tag);
+  hipLaunchKernelGGL(k_window_min, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  return NTS_OK;
+}
+
+int run_window_dense_host(nts_ctx* ctx, const uint64_t* d_keys, const std::vector<uint64_t>& vstart, const std::vector<uint64_t>& nv,
+                          uint32_t w, const OutSegs& out, const char* tag)
+{
+  std::vector<uint64_t> tile_start;
+  const uint64_t n_tiles = tiles_of(nv, w, tile_start);
+  if (n_tiles == 0) return NTS_OK;
+  if (nv.size() > 0xFFFFFFF0ULL) return fail(ctx, NTS_ERANGE, "too many uncovered ranges");
+  uint64_t *d_vs = nullptr, *d_nv = nullptr, *d_ts = nullptr;
+  int rc;
+  if ((rc = ws_upload(ctx, "win_vstart", vstart, &d_vs))) return rc;
+  if ((rc = ws_upload(ctx, "win_nv", nv, &d_nv))) return rc;
+  if ((rc = ws_upload(ctx, "win_tiles", tile_start, &d_ts))) return rc;
+  return launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, (uint32_t)nv.size(), n_tiles, w, out, tag);
+}
+
+constexpr uint32_t GAP_PEEK = 1024; // uncovered ranges fetched together with the counters
+
+// Pruned path; see nts_pruned.inc.  Fills `out` with every minimizer (sparse + dense on uncovered ranges) and
+// leaves the per-segment minimizer counts in seg_counts (the stream is synchronised on return).
+int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter, const OutSegs& out,
+               unsigned long long* seg_counts)
+{
+  const RunTable& rt = T.rt;
+  const uint64_t V = rt.n_valid;
+  const uint64_t n_kt = (V + KEY_TILE - 1) / KEY_TILE;
+  if (n_kt > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
+  // threshold: a fraction c/w of all hashes, c = ctx->prune_c
+  const unsigned __int128 full = ((unsigned __int128)1) << 64;
+  unsigned __int128 t128 = full / w * ctx->prune_c;
+  const uint64_t tau = t128 >= full - 1 ? KEY_MAX - 1 : (uint64_t)t128;
+  const double frac = std::min(1.0, (double)ctx->prune_c / (double)w);
+#define PR_WS(ptr, type, name, bytes)                                                               \
+  type ptr = (type)ws_get(ctx, name, bytes);                                                        \
+  if (!ptr) return NTS_ENOMEM
+  PR_WS(d_toff, uint64_t*, "sel_tile_off", n_kt * 8);
+  PR_WS(d_tcnt, uint32_t*, "sel_tile_cnt", n_kt * 4);
+  PR_WS(d_tcnt64, uint64_t*, "sel_tile_cnt64", n_kt * 8);
+  PR_WS(d_tscan, uint64_t*, "sel_tile_scan", n_kt * 8);
+  // control block: [0..63] candidate segment counters, [64] uncovered-range counter
+  PR_WS(d_ctl, unsigned long long*, "sel_ctl", (N_SEG + 1) * 8);
+  const uint64_t gap_cap = V / w + g->n_rec + 16;
+  PR_WS(d_glo, uint64_t*, "gap_lo", gap_cap * 8);
+  PR_WS(d_ghi, uint64_t*, "gap_hi", gap_cap * 8);
+  uint64_t cseg_cap = (uint64_t)((double)V * frac * 1.25 / N_SEG) + 8192;
+  unsigned long long ctl[N_SEG + 1];
+  std::vector<uint64_t> glo(GAP_PEEK), ghi(GAP_PEEK);
+  size_t scan_bytes = 0;
+  HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, d_tcnt64, d_tscan, (uint64_t)0, n_kt, rocprim::plus<uint64_t>(), ctx->stream));
+  PR_WS(d_scan_tmp, void*, "sel_scan_tmp", std::max<size_t>(scan_bytes, 16));
+  uint64_t m = 0, n_gap = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    PR_WS(d_sj, uint64_t*, "sel_seg_j", cseg_cap * N_SEG * 8);
+    PR_WS(d_sk, uint64_t*, "sel_seg_key", cseg_cap * N_SEG * 8);
+    const uint64_t m_max = cseg_cap * N_SEG;
+    PR_WS(d_pj, uint64_t*, "cand_j", m_max * 8);
+    PR_WS(d_pk, uint64_t*, "cand_key", m_max * 8);
+    HIP_TRY(ctx, hipMemsetAsync(d_ctl, 0, (N_SEG + 1) * 8, ctx->stream));
+    SelParams S;
+    S.code = g->d_code + PAD;
+    S.run_pos = T.d_run_pos;
+    S.run_vstart = T.d_run_vstart;
+    S.n_runs = T.n_runs;
+    S.n_valid = V;
+    S.hp = make_hash_params(k);
+    S.bf = filter ? filter->d_words : nullptr;
+    S.fm = make_fastmod((filter ? filter->bytes : 8) * 8);
+    S.tau = tau;
+    S.seg_j = d_sj;
+    S.seg_key = d_sk;
+    S.seg_cap = cseg_cap;
+    S.seg_count = d_ctl;
+    S.tile_off = d_toff;
+    S.tile_cnt = d_tcnt;
+    {
+      ScopedTimer t(ctx, filter ? "hash_select" : "hash_select_nofilter");
+      hipLaunchKernelGGL(k_hash_select, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
+    }
+    {
+      ScopedTimer t(ctx, "cand_compact");
+      hipLaunchKernelGGL(k_cnt_to_u64, dim3((uint32_t)((n_kt + 255) / 256)), dim3(256), 0, ctx->stream, d_tcnt, n_kt, d_tcnt64);
+      HIP_TRY(ctx, rocprim::exclusive_scan(d_scan_tmp, scan_bytes, d_tcnt64, d_tscan, (uint64_t)0, n_kt, rocprim::plus<uint64_t>(), ctx->stream));
+      hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)n_kt), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tscan, n_kt,
+                         d_pj, d_pk, m_max);
+    }
+    SparseParams Q;
+    Q.pj = d_pj;
+    Q.pk = d_pk;
+    Q.m_scan_last = d_tscan + (n_kt - 1);
+    Q.m_cnt_last = d_tcnt + (n_kt - 1);
+    Q.m_max = m_max;
+    Q.rec_vstart = T.d_rec_vstart;
+    Q.rec_nv = T.d_rec_nv;
+    Q.n_rec = g->n_rec;
+    Q.w = w;
+    Q.out_j = out.d_j;
+    Q.out_key = out.d_key;
+    Q.seg_count = out.d_count;
+    Q.seg_cap = out.seg_cap;
+    Q.gap_lo = d_glo;
+    Q.gap_hi = d_ghi;
+    Q.gap_count = d_ctl + N_SEG;
+    Q.gap_cap = gap_cap;
+    {
+      ScopedTimer t(ctx, "sparse_win");
+      hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)((m_max + SPARSE_THREADS - 1) / SPARSE_THREADS)), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
+      hipLaunchKernelGGL(k_gap_records, dim3((g->n_rec + 255) / 256), dim3(256), 0, ctx->stream, Q);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    // one synchronisation: candidate counters, uncovered-range count + a first batch of ranges, minimizer counters
+    HIP_TRY(ctx, hipMemcpyAsync(ctl, d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(glo.data(), d_glo, std::min<uint64_t>(GAP_PEEK, gap_cap) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ghi.data(), d_ghi, std::min<uint64_t>(GAP_PEEK, gap_cap) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(seg_counts, out.d_count, N_SEG * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t worst = 0;
+    m = 0;
+    for (uint32_t s = 0; s < N_SEG; ++s) {
+      worst = std::max<uint64_t>(worst, ctl[s]);
+      m += ctl[s];
+    }
+    n_gap = ctl[N_SEG];
+    if (worst <= cseg_cap) break;
+    if (attempt == 1) return fail(ctx, NTS_EHIP, "candidate segments overflowed twice");
+    // candidate lists were truncated: everything downstream of them is void.  Reset the outputs and retry.
+    cseg_cap = worst + 1024;
+    HIP_TRY(ctx, hipMemsetAsync(out.d_j, 0xFF, out.seg_cap * N_SEG * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(out.d_count, 0, N_SEG * 8, ctx->stream));
+  }
+  ctx->last_candidates = m;
+  ctx->last_gaps = n_gap;
+  if (n_gap == 0) return NTS_OK;
+  if (n_gap > gap_cap) return fail(ctx, NTS_EHIP, "uncovered-range list overflowed");
+  // ---- dense evaluation of the uncovered ranges ------------------------------------------------------------
+  if (n_gap > GAP_PEEK) {
+    glo.resize(n_gap);
+    ghi.resize(n_gap);
+    HIP_TRY(ctx, hipMemcpyAsync(glo.data(), d_glo, n_gap * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ghi.data(), d_ghi, n_gap * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  std::vector<size_t> ord(n_gap);
+  for (size_t i = 0; i < n_gap; ++i) ord[i] = i;
+  std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return glo[a] < glo[b]; });
+  std::vector<uint64_t> pv(n_gap), pn(n_gap);
+  std::vector<uint32_t> tiles;
+  uint64_t covered = 0;
+  for (size_t i = 0; i < n_gap; ++i) {
+    pv[i] = glo[ord[i]];
+    pn[i] = ghi[ord[i]] - glo[ord[i]] + 1;
+    covered += pn[i];
+    for (uint64_t t = pv[i] / KEY_TILE; t <= ghi[ord[i]] / KEY_TILE; ++t)
+      if (tiles.empty() || tiles.back() != (uint32_t)t) tiles.push_back((uint32_t)t);
+  }
+  ctx->last_gap_kmers = covered;
+  PR_WS(d_keys, uint64_t*, "keys", key_buffer_elems(V) * 8);
+  const bool all_tiles = tiles.size() * 2 > n_kt;
+  uint32_t* d_tiles = nullptr;
+  int rc;
+  if (!all_tiles && (rc = ws_upload(ctx, "gap_tiles", tiles, &d_tiles))) return rc;
+  rc = launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, T, k, filter, nullptr, d_keys, all_tiles ? nullptr : d_tiles,
+                              all_tiles ? 0 : tiles.size());
+  if (rc) return rc;
+  if ((rc = run_window_dense_host(ctx, d_keys, pv, pn, w, out, "window_min"))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(seg_counts, out.d_count, N_SEG * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return NTS_OK;
+#undef PR_WS
+}
+
+// device memory of a result list: recycled through a small per-context pool (hipMalloc/hipFree synchronise)
+int alloc_result(nts_ctx* ctx, nts_mx* mx, uint64_t count)
+{
+  const uint64_t need = count * 20;
+  for (size_t i = 0; i < ctx->mx_pool.size(); ++i) {
+    if (ctx->mx_pool[i].second >= need && ctx->mx_pool[i].second <= 4 * need + (1u << 20)) {
+      mx->d_h1 = (uint64_t*)ctx->mx_pool[i].first;
+      mx->cap_bytes = ctx->mx_pool[i].second;
+      ctx->mx_pool.erase(ctx->mx_pool.begin() + i);
+      break;
+    }
+  }
+  if (!mx->d_h1) {
+    const uint64_t cap = need + need / 8 + 4096;
+    HIP_TRY(ctx, hipMalloc((void**)&mx->d_h1, cap));
+    mx->cap_bytes = cap;
+  }
+  mx->d_pos = mx->d_h1 + count;
+  mx->d_rec = (uint32_t*)(mx->d_pos + count);
+  return NTS_OK;
+}
+
+} // namespace
+
+extern "C" int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c)
+{
+  if (!ctx || mode < 0 || mode > 2) return fail(ctx, NTS_EINVAL, "nts_sketch_mode: mode must be 0 (auto), 1 (dense) or 2 (pruned)");
+  ctx->sketch_mode = mode;
+  if (prune_c) ctx->prune_c = prune_c;
+  return NTS_OK;
+}
+
+extern "C" int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers)
+{
+  if (!ctx) return NTS_EINVAL;
+  if (candidates) *candidates = ctx->last_candidates;
+  if (uncovered_ranges) *uncovered_ranges = ctx->last_gaps;
+  if (uncovered_kmers) *uncovered_kmers = ctx->last_gap_kmers;
+  return NTS_OK;
+}
+
+extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const nts_bf* filter, const nts_interval* mask,
+                          uint64_t n_mask, nts_mx** out)
 {
   if (!ctx || !g || !out || k == 0 || w == 0 || (n_mask && !mask)) return fail(ctx, NTS_EINVAL, "nts_sketch: bad arguments");
   if (w > WIN_MAX_W) return fail(ctx, NTS_ERANGE, "nts_sketch: w exceeds the LDS-resident window limit (12000)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  RunTable rt;
-  int rc = build_runs(ctx, g, k, mask, n_mask, rt);
+  GenomeTables scratch;
+  const GenomeTables* T = nullptr;
+  int rc = get_tables(ctx, g, k, mask, n_mask, scratch, &T);
   if (rc) return rc;
+  const RunTable& rt = T->rt;
   nts_mx* mx = new nts_mx();
-  // tiles per record
-  std::vector<uint64_t> tile_start(g->n_rec + 1, 0);
-  for (uint32_t r = 0; r < g->n_rec; ++r) {
-    const uint64_t nv = rt.rec_nv[r];
-    const uint64_t n_win = nv >= w ? nv - w + 1 : 0;
-    tile_start[r + 1] = tile_start[r] + (n_win + WIN_TILE - 1) / WIN_TILE;
-  }
-  const uint64_t n_tiles = tile_start[g->n_rec];
-  if (rt.n_valid == 0 || n_tiles == 0) {
+  ctx->last_candidates = ctx->last_gaps = ctx->last_gap_kmers = 0;
+  if (rt.n_valid == 0 || T->n_win_tiles(w) == 0) {
     *out = mx;
     return NTS_OK;
   }
-  if (n_tiles > 0x7FFFFFFFULL) {
-    delete mx;
-    return fail(ctx, NTS_ERANGE, "too many window tiles for one launch");
-  }
-  DevRuns dr;
   auto bail = [&](int code) {
     hipStreamSynchronize(ctx->stream);
     nts_mx_free(ctx, mx);
@@ -1302,85 +1694,64 @@ int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const 
   type ptr = (type)ws_get(ctx, name, bytes);                                                        \
   if (!ptr) return bail(NTS_ENOMEM)
 
-  SK_TRY(upload_runs(ctx, rt, dr));
-  SK_WS(d_keys, uint64_t*, "keys", key_buffer_elems(rt.n_valid) * 8);
-  SK_TRY(launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, rt, dr, k, filter, nullptr, d_keys));
-
-  uint64_t *d_rec_vstart = nullptr, *d_rec_nv = nullptr, *d_tile_start = nullptr, *d_rec_off = nullptr;
-  SK_TRY(ws_upload(ctx, "rec_vstart", rt.rec_vstart, &d_rec_vstart));
-  SK_TRY(ws_upload(ctx, "rec_nv", rt.rec_nv, &d_rec_nv));
-  SK_TRY(ws_upload(ctx, "tile_start", tile_start, &d_tile_start));
-  SK_TRY(ws_upload(ctx, "rec_off", g->rec_off, &d_rec_off));
+  const uint64_t n_tiles = T->n_win_tiles(w);
   SK_WS(d_seg, unsigned long long*, "seg_count", N_SEG * sizeof(unsigned long long));
+  const bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= 256);
 
-  WinParams P;
-  P.keys = d_keys;
-  P.rec_vstart = d_rec_vstart;
-  P.rec_nv = d_rec_nv;
-  P.tile_start = d_tile_start;
-  P.n_rec = g->n_rec;
-  P.w = w;
-  P.chunk = std::min<uint32_t>(WIN_CHUNK, w);
-  const uint32_t max_full = w / P.chunk;
-  P.levels = 1;
-  while ((1u << P.levels) <= max_full) ++P.levels;
-  const uint32_t E_max = WIN_TILE + 1 + w - 1;
-  const uint32_t chunks_max = (E_max + P.chunk - 1) / P.chunk;
-  const size_t lds = (size_t)(E_max + E_max / 32 + 2) * 8 + 16 + (size_t)(WIN_TILE + 16) * 2 + (size_t)P.levels * chunks_max * 2 + 64;
-  if (lds > 160 * 1024) SK_TRY(fail(ctx, NTS_ERANGE, "window tile does not fit LDS"));
-  SK_HIP(hipFuncSetAttribute((const void*)k_window_min, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-
-  uint64_t seg_cap = std::max<uint64_t>(256, (3 * rt.n_valid / w + 2 * n_tiles) / N_SEG + 64);
+  OutSegs segs;
+  segs.d_count = d_seg;
+  segs.seg_cap = std::max<uint64_t>(256, (3 * rt.n_valid / w + 2 * n_tiles) / N_SEG + 64);
   uint64_t count = 0;
-  uint64_t *d_oj = nullptr, *d_ok = nullptr;
   unsigned long long seg_counts[N_SEG];
   for (int attempt = 0; attempt < 2; ++attempt) {
-    const uint64_t slots = seg_cap * N_SEG;
-    d_oj = (uint64_t*)ws_get(ctx, "out_j", slots * 8);
-    d_ok = (uint64_t*)ws_get(ctx, "out_key", slots * 8);
-    if (!d_oj || !d_ok) return bail(NTS_ENOMEM);
-    SK_HIP(hipMemsetAsync(d_oj, 0xFF, slots * 8, ctx->stream));
+    const uint64_t slots = segs.seg_cap * N_SEG;
+    segs.d_j = (uint64_t*)ws_get(ctx, "out_j", slots * 8);
+    segs.d_key = (uint64_t*)ws_get(ctx, "out_key", slots * 8);
+    if (!segs.d_j || !segs.d_key) return bail(NTS_ENOMEM);
+    SK_HIP(hipMemsetAsync(segs.d_j, 0xFF, slots * 8, ctx->stream));
     SK_HIP(hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
-    P.out_j = d_oj;
-    P.out_key = d_ok;
-    P.seg_count = d_seg;
-    P.seg_cap = seg_cap;
-    {
-      ScopedTimer t(ctx, "window_min");
-      hipLaunchKernelGGL(k_window_min, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
+    if (pruned) {
+      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, segs, seg_counts));
+    } else {
+      SK_WS(d_keys, uint64_t*, "keys", key_buffer_elems(rt.n_valid) * 8);
+      SK_TRY(launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, *T, k, filter, nullptr, d_keys));
+      const uint64_t* d_ts = nullptr;
+      SK_TRY(T->win_tiles_device(ctx, w, &d_ts));
+      SK_TRY(launch_window_dense(ctx, d_keys, T->d_rec_vstart, T->d_rec_nv, d_ts, g->n_rec, n_tiles, w, segs, "window_min"));
+      SK_HIP(hipMemcpyAsync(seg_counts, d_seg, sizeof(seg_counts), hipMemcpyDeviceToHost, ctx->stream));
+      SK_HIP(hipStreamSynchronize(ctx->stream));
     }
-    SK_HIP(hipGetLastError());
-    SK_HIP(hipMemcpyAsync(seg_counts, d_seg, sizeof(seg_counts), hipMemcpyDeviceToHost, ctx->stream));
-    SK_HIP(hipStreamSynchronize(ctx->stream));
     uint64_t worst = 0;
     count = 0;
     for (uint32_t s = 0; s < N_SEG; ++s) {
       worst = std::max<uint64_t>(worst, seg_counts[s]);
       count += seg_counts[s];
     }
-    if (worst <= seg_cap) break;
-    seg_cap = worst; // exact need known now; run again
+    if (worst <= segs.seg_cap) break;
+    if (attempt == 1) return bail(fail(ctx, NTS_EHIP, "minimizer segments overflowed twice"));
+    segs.seg_cap = worst; // exact need known now; run again
   }
   mx->n = count;
   if (count) {
-    const uint64_t slots = seg_cap * N_SEG;
+    const uint64_t slots = segs.seg_cap * N_SEG;
     SK_WS(d_oj2, uint64_t*, "out_j2", slots * 8);
     SK_WS(d_ok2, uint64_t*, "out_key2", slots * 8);
     size_t tmp_bytes = 0;
-    SK_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_oj, d_oj2, d_ok, d_ok2, slots, 0, 64, ctx->stream));
+    // compact indices are < n_valid: sort only the bits that can differ (sentinel slots are all ones)
+    uint32_t bits = 1;
+    while (bits < 64 && (rt.n_valid >> bits) != 0) ++bits;
+    const uint32_t end_bit = std::min<uint32_t>(64, bits + 1);
+    SK_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, segs.d_j, d_oj2, segs.d_key, d_ok2, slots, 0, end_bit, ctx->stream));
     SK_WS(d_tmp, void*, "sort_tmp", std::max<size_t>(tmp_bytes, 16));
     {
       ScopedTimer t(ctx, "sort_minimizers");
-      SK_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_oj, d_oj2, d_ok, d_ok2, slots, 0, 64, ctx->stream));
+      SK_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, segs.d_j, d_oj2, segs.d_key, d_ok2, slots, 0, end_bit, ctx->stream));
     }
-    // one allocation for the three result arrays: h1 | pos | rec
-    SK_HIP(hipMalloc((void**)&mx->d_h1, count * 20));
-    mx->d_pos = mx->d_h1 + count;
-    mx->d_rec = (uint32_t*)(mx->d_pos + count);
+    SK_TRY(alloc_result(ctx, mx, count));
     {
       ScopedTimer t(ctx, "finalize");
       hipLaunchKernelGGL(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_oj2, d_ok2, (uint64_t)count,
-                         dr.pos, dr.vstart, dr.n, d_rec_off, g->n_rec, k, mx->d_h1, mx->d_rec, mx->d_pos);
+                         T->d_run_pos, T->d_run_vstart, T->n_runs, g->d_rec_off, g->n_rec, k, mx->d_h1, mx->d_rec, mx->d_pos);
     }
     SK_HIP(hipGetLastError());
   }
@@ -1392,6 +1763,8 @@ int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const 
 #undef SK_WS
 }
 
+extern "C" {
+
 uint64_t nts_mx_count(const nts_mx* mx)
 {
   return mx ? mx->n : 0;
@@ -1401,7 +1774,12 @@ void nts_mx_free(nts_ctx* ctx, nts_mx* mx)
 {
   if (!mx) return;
   if (ctx) hipSetDevice(ctx->device);
-  hipFree(mx->d_h1); // h1 | pos | rec share one allocation
+  if (mx->d_h1) { // h1 | pos | rec share one allocation
+    if (ctx && ctx->mx_pool.size() < 8 && mx->cap_bytes)
+      ctx->mx_pool.push_back({ mx->d_h1, mx->cap_bytes });
+    else
+      hipFree(mx->d_h1);
+  }
   delete mx;
 }
 
@@ -1451,6 +1829,7 @@ int nts_mx_upload(nts_ctx* ctx, const uint64_t* h1, const uint32_t* rec, const u
       nts_mx_free(ctx, mx);
       return fail(ctx, NTS_ENOMEM, "nts_mx_upload: hipMalloc");
     }
+    mx->cap_bytes = n * 20;
     mx->d_pos = mx->d_h1 + n;
     mx->d_rec = (uint32_t*)(mx->d_pos + n);
     hipMemcpyAsync(mx->d_h1, h1, n * 8, hipMemcpyHostToDevice, ctx->stream);

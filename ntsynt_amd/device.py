@@ -46,6 +46,18 @@ class Context:
         self.check(self.lib.nts_timing(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(n)), "nts_timing")
         return ms.value, n.value
 
+    def sketch_mode(self, mode="auto", prune_c=0):
+        """'auto' (pruned when w >= 256), 'dense' (probe the filter for every k-mer) or 'pruned'
+        (probe only k-mers whose hash is <= prune_c/w of the hash range; identical output)."""
+        code = {"auto": 0, "dense": 1, "pruned": 2}[mode]
+        self.check(self.lib.nts_sketch_mode(self.h, code, int(prune_c)), "nts_sketch_mode")
+
+    def sketch_stats(self):
+        "(accepted candidates, uncovered ranges, k-mers in them) of the last sketch call"
+        a, b, c = u64(), u64(), u64()
+        self.check(self.lib.nts_sketch_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "nts_sketch_stats")
+        return a.value, b.value, c.value
+
     def close(self):
         if self.h:
             self.lib.nts_destroy(self.h)

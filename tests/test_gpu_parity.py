@@ -202,3 +202,56 @@ def test_sketch_large_properties(ctx):
     m = (rec == 1) & (pos < 300000 - k - w)
     n = int(m.sum())
     assert np.array_equal(pos[m], exp[1][:n]) and np.array_equal(h1[m], exp[0][:n])
+
+
+@pytest.mark.parametrize("mode,c", [("dense", 0), ("pruned", 64), ("pruned", 4), ("pruned", 1), ("pruned", 100000)])
+def test_sketch_modes_identical(ctx, mode, c):
+    """dense and pruned sketches are the same function: tiny prune_c forces most windows through the
+    uncovered-range fallback, huge prune_c makes every k-mer a candidate"""
+    from ntsynt_amd.device import BloomFilter, sketch
+    k = 24
+    names, seqs = _family(4242, lengths=[150000, 700, 0, 60000, 2500], n_frac=0.004)
+    rng = np.random.default_rng(9)
+    other = []
+    for s in seqs:
+        a = np.frombuffer(s, dtype=np.uint8).copy()
+        hit = rng.random(a.size) < 0.01
+        a[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+        if a.size > 100000:
+            a[20000:45000] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=25000)]
+        other.append(a.tobytes())
+    og = [to_oracle(names, seqs), to_oracle(names, other)]
+    dg = [to_device(ctx, names, seqs), to_device(ctx, names, other)]
+    nbytes = O.bf_ctor_bytes(O.bf_approx_bytes(og[0].total_bp, 0.025))
+    obf = O.bf_build(og[1], k, nbytes, prev=O.bf_build(og[0], k, nbytes))
+    dbf = BloomFilter(ctx, nbytes, k)
+    dbf.from_numpy(obf)
+    ctx.sketch_mode(mode, c)
+    try:
+        for w in (1000, 300, 64):
+            for o, d in zip(og, dg):
+                for bf_o, bf_d in ((obf, dbf), (None, None)):
+                    exp = oracle_flat(O.minimize(o, k, w, bf_o))
+                    got = sketch(ctx, d, k, w, bf_d).to_numpy()
+                    for a, b in zip(got, exp):
+                        assert np.array_equal(a, b.astype(a.dtype)), (mode, c, w)
+                    cand, gaps, gk = ctx.sketch_stats()
+                    if mode == "dense":
+                        assert (cand, gaps, gk) == (0, 0, 0)
+                    elif c == 1 and w == 1000 and bf_o is not None:
+                        assert gaps > 0 and gk > 0
+        # masked re-sketch through the pruned path as well
+        masks = [(0, 5000, 90000), (3, 100, 30000), (0, 120000, 140000)]
+        masked = []
+        for i, s in enumerate(seqs):
+            b = bytearray(s)
+            for r, st, en in masks:
+                if r == i:
+                    b[st:min(en, len(b))] = b"N" * (min(en, len(b)) - st)
+            masked.append(bytes(b))
+        exp = oracle_flat(O.minimize(to_oracle(names, masked), k, 300, obf))
+        got = sketch(ctx, dg[0], k, 300, dbf, masks).to_numpy()
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b.astype(a.dtype))
+    finally:
+        ctx.sketch_mode("auto", 64)
