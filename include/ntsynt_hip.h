@@ -74,6 +74,13 @@ int nts_genome_upload(nts_ctx* ctx,
                       uint32_t n_rec,
                       nts_genome** out);
 void nts_genome_free(nts_ctx* ctx, nts_genome* g);
+/* Bench / scale-test utilities (no counterpart in the reference): a synthetic genome generated directly in
+ * HBM -- `n_contigs` equal records of i.i.d. bases drawn from `seed_ancestor`, with independent substitutions
+ * at `substitution_rate` keyed by `seed_genome` (genomes sharing seed_ancestor are relatives) -- and the
+ * read-back of a slice of any resident genome as upper-case ASCII (concatenated-sequence coordinates). */
+int nts_genome_synth(nts_ctx* ctx, uint64_t total_bp, uint32_t n_contigs, uint64_t seed_ancestor, uint64_t seed_genome,
+                     double substitution_rate, nts_genome** out);
+int nts_genome_download(nts_ctx* ctx, const nts_genome* g, uint64_t offset, uint64_t len, uint8_t* ascii);
 /* total bases (sum of record lengths, what approximate_bf_size() counts) */
 uint64_t nts_genome_bases(const nts_genome* g);
 /* number of k-mers made only of A/C/G/T(U), i.e. the k-mers NtHash::roll() visits */

@@ -636,6 +636,46 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
   }
 }
 
+// ---- bench/test utility: synthetic genome generated in HBM, and read-back of a slice ----------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+// base i of the ancestor = mix64(seed_anc, i) & 3; genome = ancestor with substitutions at rate thr / 2^32
+__global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ code, uint64_t n, uint64_t seed_anc, uint64_t seed_gen, uint32_t thr)
+{
+  const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i0 >= n) return;
+  uint32_t wds[4] = { 0, 0, 0, 0 };
+  for (int b = 0; b < 16; ++b) {
+    const uint64_t i = i0 + b;
+    uint32_t base = (uint32_t)(mix64(seed_anc + i * 0x9E3779B97F4A7C15ULL) & 3u);
+    const uint64_t y = mix64(seed_gen ^ (i * 0xD1B54A32D192ED03ULL));
+    if ((uint32_t)y < thr) base = (base + 1u + (uint32_t)((y >> 32) % 3u)) & 3u;
+    if (i >= n) base = CODE_INVALID;
+    wds[b >> 2] |= base << (8 * (b & 3));
+  }
+  if (i0 + 16 <= n) {
+    *reinterpret_cast<uint4*>(code + i0) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+  } else {
+    for (uint64_t i = i0; i < n; ++i) code[i] = (wds[(i - i0) >> 2] >> (8 * ((i - i0) & 3))) & 0xFF;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ code, uint64_t n, uint8_t* __restrict__ ascii)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t c = code[i];
+  ascii[i] = c == 0 ? 'A' : c == 1 ? 'C' : c == 2 ? 'G' : c == 3 ? 'T' : 'N';
+}
+
 // compact index -> (record, position in record), and the printed hash h1
 __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j_sorted,
                                                   const uint64_t* __restrict__ key_sorted,
@@ -1186,6 +1226,59 @@ void nts_genome_free(nts_ctx* ctx, nts_genome* g)
 uint64_t nts_genome_bases(const nts_genome* g)
 {
   return g ? g->total_bases : 0;
+}
+
+int nts_genome_synth(nts_ctx* ctx, uint64_t total_bp, uint32_t n_contigs, uint64_t seed_ancestor, uint64_t seed_genome,
+                     double substitution_rate, nts_genome** out)
+{
+  if (!ctx || !out || total_bp == 0 || n_contigs == 0 || substitution_rate < 0 || substitution_rate >= 1)
+    return fail(ctx, NTS_EINVAL, "nts_genome_synth: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t per = total_bp / n_contigs;
+  if (per == 0) return fail(ctx, NTS_EINVAL, "nts_genome_synth: contigs would be empty");
+  const uint64_t n = per * n_contigs;
+  nts_genome* g = new nts_genome();
+  g->n = n;
+  g->n_rec = n_contigs;
+  for (uint32_t r = 0; r < n_contigs; ++r) {
+    g->rec_off.push_back(per * r);
+    g->rec_len.push_back(per);
+    g->st_a.push_back(per * r);
+    g->st_b.push_back(per * (r + 1));
+  }
+  g->total_bases = n;
+  if (hipMalloc((void**)&g->d_code, PAD + n + PAD) != hipSuccess || hipMalloc((void**)&g->d_rec_off, n_contigs * 8) != hipSuccess) {
+    hipFree(g->d_code);
+    delete g;
+    return fail(ctx, NTS_ENOMEM, "nts_genome_synth: hipMalloc");
+  }
+  hipMemsetAsync(g->d_code, CODE_INVALID, PAD, ctx->stream);
+  hipMemsetAsync(g->d_code + PAD + n, CODE_INVALID, PAD, ctx->stream);
+  hipMemcpyAsync(g->d_rec_off, g->rec_off.data(), n_contigs * 8, hipMemcpyHostToDevice, ctx->stream);
+  const uint32_t thr = (uint32_t)(substitution_rate * 4294967296.0);
+  hipLaunchKernelGGL(k_synth, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, g->d_code + PAD, n, seed_ancestor, seed_genome, thr);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    hipFree(g->d_code);
+    hipFree(g->d_rec_off);
+    delete g;
+    return fail(ctx, NTS_EHIP, std::string("nts_genome_synth: ") + hipGetErrorString(e));
+  }
+  *out = g;
+  return NTS_OK;
+}
+
+int nts_genome_download(nts_ctx* ctx, const nts_genome* g, uint64_t offset, uint64_t len, uint8_t* ascii)
+{
+  if (!ctx || !g || !ascii || offset > g->n || len > g->n - offset) return fail(ctx, NTS_EINVAL, "nts_genome_download: range outside the genome");
+  if (len == 0) return NTS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint8_t* d = (uint8_t*)ws_get(ctx, "decode", len);
+  if (!d) return NTS_ENOMEM;
+  hipLaunchKernelGGL(k_decode, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, ctx->stream, g->d_code + PAD + offset, len, d);
+  HIP_TRY(ctx, hipMemcpyAsync(ascii, d, len, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return NTS_OK;
 }
 
 int nts_genome_valid_kmers(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t* n_valid)

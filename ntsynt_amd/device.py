@@ -95,6 +95,28 @@ class Genome:
                                             len(self.names), ctypes.byref(h)), "nts_genome_upload")
         self.h = h
 
+    @classmethod
+    def synth(cls, ctx, total_bp, n_contigs, seed_ancestor, seed_genome, substitution_rate):
+        """Synthetic genome generated in HBM (bench / scale tests): relatives share seed_ancestor."""
+        g = cls.__new__(cls)
+        g.ctx = ctx
+        per = int(total_bp) // int(n_contigs)
+        g.names = [f"chr{i + 1}" for i in range(n_contigs)]
+        g.rec_len = np.full(n_contigs, per, dtype=np.uint64)
+        g.rec_off = (np.arange(n_contigs, dtype=np.uint64) * np.uint64(per)).astype(np.uint64)
+        h = c_vp()
+        ctx.check(ctx.lib.nts_genome_synth(ctx.h, int(total_bp), int(n_contigs), int(seed_ancestor), int(seed_genome),
+                                           float(substitution_rate), ctypes.byref(h)), "nts_genome_synth")
+        g.h = h
+        return g
+
+    def download(self, offset, length):
+        "upper-case ASCII of bases [offset, offset+length) of the concatenated records"
+        out = np.empty(int(length), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.nts_genome_download(self.ctx.h, self.h, int(offset), int(length), out.ctypes.data),
+                       "nts_genome_download")
+        return out
+
     @property
     def total_bp(self):
         return int(self.ctx.lib.nts_genome_bases(self.h))

@@ -7,7 +7,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(k_[a-z_0-9]+)(<\d+>)?", name)
+    m = None if "rocprim" in name else re.search(r"(k_[a-z_0-9]+)(<\d+>)?", name)
     if m:
         mode = {"k_hash<0>": " (keys: hash+probe or hash only)", "k_hash<1>": " (bloom insert)",
                 "k_hash<2>": " (bloom cascade)"}.get(m.group(0), "")
