@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("-w", type=int, default=1000)
     ap.add_argument("--fpr", type=float, default=0.025)
     ap.add_argument("--mode", choices=["auto", "dense", "pruned"], default="auto")
-    ap.add_argument("--prune-c", type=int, default=32)
+    ap.add_argument("--prune-c", type=int, default=0, help="0 = adaptive (library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-leg", action="store_true")
     return ap.parse_args()
@@ -81,6 +81,22 @@ def cpu_baseline(args, contigs, bf_np):
     return {"value": round(done / dt / 1e9, 4), "unit": "Gbases/s", "cores": cores, "kind": "port",
             "sample": f"genome 0 ({g.total_bp / 1e6:.0f} Mbp) as {len(seqs)} records, one per thread (OpenMP), "
                       f"sketch with the same common Bloom filter, {done // g.total_bp} passes in {dt:.1f} s"}
+
+
+def pmc_traffic(args, pruned_run):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command).  FETCH_SIZE is
+    corrected by +1/2 of the sequence stream (the guide's gfx950 factor for wide coalesced reads)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    default = (args.mbp, args.genomes, args.divergence, args.k, args.w, args.fpr) == (100.0, 3, 0.01, 24, 1000, 0.025)
+    if not (default and os.path.exists(path)):
+        return None
+    k = json.load(open(path))["kernels"].get("k_hash_select" if pruned_run else "k_hash<0>")
+    if not k:
+        return None
+    raw = (k["fetch_MB_per_launch_max"] + k["write_MB_per_launch_max"]) * 1024 * 1024
+    return {"bytes_per_launch": int(raw + 0.5 * args.mbp * 1e6), "raw_fetch_plus_write_bytes": int(raw),
+            "source": "profiles/r01_pmc_traffic.json"}
 
 
 def main():
@@ -191,6 +207,7 @@ def main():
     names = ["hash_select", "cand_compact", "sparse_win", "hash_probe", "window_min", "sort_minimizers", "finalize"]
     tm = {n: ctx.timing(n) for n in names}
     cand, gaps, gap_kmers = ctx.sketch_stats()
+    c_used = getattr(ctx, "last_prune_c", 0)
     per_launch_bases = bases / len(genomes)
 
     def avg(n):
@@ -216,7 +233,7 @@ def main():
         pruned_run = tm["hash_select"][1] > 0
         if pruned_run:
             kern, a_ms = "k_hash_select (hash every k-mer, probe candidates only)", avg("hash_select")
-            probe_frac = min(1.0, args.prune_c / w)
+            probe_frac = min(1.0, c_used / w)
             # bytes the pruned kernel has to move per base: the base, one sector per probed candidate,
             # 16 B per accepted candidate written
             bpb = 1.0 + SECTOR * probe_frac + 16.0 * cand / per_launch_bases
@@ -231,12 +248,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.genomes} synthetic {args.mbp:g} Mbp genomes per GPU at "
                                    f"{args.divergence * 100:g}% divergence, k={k} w={w} fpr={args.fpr}",
-                       "sketch_mode": args.mode, "prune_c": args.prune_c,
+                       "sketch_mode": args.mode, "prune_c": c_used,
                        "genomes_per_gpu": args.genomes, "bases_per_step_per_gpu": bases,
                        "minimizers_per_step_per_gpu": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": kern,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, pruned_run),
                          "algorithmic_bytes_per_base": round(bpb, 3),
                          "avg_launch_ms": round(a_ms, 4), "launches": tm["hash_select" if pruned_run else "hash_probe"][1],
                          "other_kernels_avg_ms": {n: round(avg(n), 4) for n in names if tm[n][1]},

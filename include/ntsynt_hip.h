@@ -127,14 +127,15 @@ int nts_sketch(nts_ctx* ctx,
                const nts_interval* mask,
                uint64_t n_mask,
                nts_mx** out);
-/* Sketch policy.  mode 0 = auto (pruned when w >= 256), 1 = dense (probe the filter for every k-mer),
- * 2 = pruned: only k-mers whose hash is <= (prune_c / w) * 2^64 are probed; windows holding no accepted
- * candidate are re-evaluated densely, so the result is identical (ntsynt_amd/csrc/nts_pruned.inc).
- * prune_c = 0 keeps the current value (default 32). */
+/* Sketch policy.  mode 0 = auto (pruned when w >= 256 and the filter accepts >= 2 % of the genome's k-mers),
+ * 1 = dense (probe the filter for every k-mer), 2 = pruned: only k-mers whose hash is <= (c / w) * 2^64 are probed;
+ * windows holding no accepted candidate are re-evaluated densely, so the result is identical
+ * (ntsynt_amd/csrc/nts_pruned.inc).  prune_c = 0: c is chosen per call from the filter's occupancy
+ * (c = 12 / accepted share, clamped to [8, 128]); otherwise c = prune_c. */
 int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c);
-/* of the last nts_sketch call: accepted candidates, uncovered ranges handed to the dense kernels, and the
- * number of k-mers in them (all 0 for a dense-mode call) */
-int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers);
+/* of the last nts_sketch call: accepted candidates, uncovered ranges handed to the dense kernels, the number of
+ * k-mers in them, and the c that was used (all 0 for a dense-mode call) */
+int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers, uint32_t* prune_c_used);
 uint64_t nts_mx_count(const nts_mx* mx);
 void nts_mx_free(nts_ctx* ctx, nts_mx* mx);
 /* copy a minimizer list to caller-provided host arrays of nts_mx_count() elements */

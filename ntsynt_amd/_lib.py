@@ -62,7 +62,7 @@ SYMBOLS = [
     ("nts_sketch", ctypes.c_int, [c_vp, c_vp, u32, u32, c_vp, ctypes.POINTER(Interval), u64,
                                   ctypes.POINTER(c_vp)]),
     ("nts_sketch_mode", ctypes.c_int, [c_vp, ctypes.c_int, u32]),
-    ("nts_sketch_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u64p]),
+    ("nts_sketch_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u64p, c_u32p]),
     ("nts_mx_count", u64, [c_vp]),
     ("nts_mx_free", None, [c_vp, c_vp]),
     ("nts_mx_download", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -63,7 +63,8 @@ struct nts_ctx
   std::vector<std::pair<void*, uint64_t>> mx_pool; // recycled result allocations
   size_t win_lds_set = 0;
   int sketch_mode = 0;
-  uint32_t prune_c = 32;
+  uint32_t prune_c = 0; // 0 = adaptive (from the filter's occupancy), else fixed
+  uint32_t last_c = 0;
   uint64_t last_candidates = 0, last_gaps = 0, last_gap_kmers = 0;
 };
 
@@ -86,6 +87,7 @@ struct nts_bf
   uint64_t bytes = 0;
   uint32_t* d_words = nullptr;
   bool owned = true;
+  mutable int64_t popcnt = -1; // cached number of set bits, -1 = unknown (any write invalidates it)
 };
 
 struct nts_mx
@@ -1363,6 +1365,7 @@ void* nts_bf_device_ptr(nts_bf* bf)
 int nts_bf_clear(nts_ctx* ctx, nts_bf* bf)
 {
   if (!ctx || !bf) return fail(ctx, NTS_EINVAL, "nts_bf_clear: bad arguments");
+  bf->popcnt = 0;
   HIP_TRY(ctx, hipMemsetAsync(bf->d_words, 0, (bf->bytes + 15) / 16 * 16, ctx->stream));
   return NTS_OK;
 }
@@ -1371,6 +1374,7 @@ static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nt
 {
   if (!ctx || !next || !g || k == 0) return fail(ctx, NTS_EINVAL, "bloom pass: bad arguments");
   if (prev && prev->bytes != next->bytes) return fail(ctx, NTS_EINVAL, "bloom pass: filters differ in size");
+  next->popcnt = -1;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   GenomeTables scratch;
   const GenomeTables* T = nullptr;
@@ -1399,6 +1403,7 @@ int nts_bf_cascade(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nts_gen
 int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other)
 {
   if (!ctx || !acc || !other || acc->bytes != other->bytes) return fail(ctx, NTS_EINVAL, "nts_bf_and: filters differ in size");
+  acc->popcnt = -1;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t n16 = (acc->bytes + 15) / 16;
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
@@ -1411,6 +1416,10 @@ int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other)
 int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set)
 {
   if (!ctx || !bf || !bits_set) return fail(ctx, NTS_EINVAL, "nts_bf_popcount: bad arguments");
+  if (bf->popcnt >= 0 && bf->owned) {
+    *bits_set = (uint64_t)bf->popcnt;
+    return NTS_OK;
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   unsigned long long* d = nullptr;
   HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(unsigned long long)));
@@ -1426,6 +1435,7 @@ int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set)
   hipError_t e = hipStreamSynchronize(ctx->stream);
   hipFree(d);
   if (e != hipSuccess) return fail(ctx, NTS_EHIP, std::string("popcount: ") + hipGetErrorString(e));
+  bf->popcnt = (int64_t)h;
   *bits_set = h;
   return NTS_OK;
 }
@@ -1442,6 +1452,7 @@ int nts_bf_download(nts_ctx* ctx, const nts_bf* bf, uint8_t* host, uint64_t byte
 int nts_bf_upload(nts_ctx* ctx, nts_bf* bf, const uint8_t* host, uint64_t bytes)
 {
   if (!ctx || !bf || !host || bytes != bf->bytes) return fail(ctx, NTS_EINVAL, "nts_bf_upload: size mismatch");
+  bf->popcnt = -1;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipMemcpyAsync(bf->d_words, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1558,7 +1569,7 @@ constexpr uint32_t GAP_PEEK = 1024; // uncovered ranges fetched together with th
 // Pruned path; see nts_pruned.inc.  Fills `out` with every minimizer (sparse + dense on uncovered ranges) and
 // leaves the per-segment minimizer counts in seg_counts (the stream is synchronised on return).
 int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter, const OutSegs& out,
-               unsigned long long* seg_counts)
+               unsigned long long* seg_counts, uint32_t prune_c)
 {
   const RunTable& rt = T.rt;
   const uint64_t V = rt.n_valid;
@@ -1566,9 +1577,9 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   if (n_kt > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
   // threshold: a fraction c/w of all hashes, c = ctx->prune_c
   const unsigned __int128 full = ((unsigned __int128)1) << 64;
-  unsigned __int128 t128 = full / w * ctx->prune_c;
+  unsigned __int128 t128 = full / w * prune_c;
   const uint64_t tau = t128 >= full - 1 ? KEY_MAX - 1 : (uint64_t)t128;
-  const double frac = std::min(1.0, (double)ctx->prune_c / (double)w);
+  const double frac = std::min(1.0, (double)prune_c / (double)w);
 #define PR_WS(ptr, type, name, bytes)                                                               \
   type ptr = (type)ws_get(ctx, name, bytes);                                                        \
   if (!ptr) return NTS_ENOMEM
@@ -1735,13 +1746,14 @@ extern "C" int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c)
 {
   if (!ctx || mode < 0 || mode > 2) return fail(ctx, NTS_EINVAL, "nts_sketch_mode: mode must be 0 (auto), 1 (dense) or 2 (pruned)");
   ctx->sketch_mode = mode;
-  if (prune_c) ctx->prune_c = prune_c;
+  ctx->prune_c = prune_c;
   return NTS_OK;
 }
 
-extern "C" int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers)
+extern "C" int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers, uint32_t* prune_c_used)
 {
   if (!ctx) return NTS_EINVAL;
+  if (prune_c_used) *prune_c_used = ctx->last_c;
   if (candidates) *candidates = ctx->last_candidates;
   if (uncovered_ranges) *uncovered_ranges = ctx->last_gaps;
   if (uncovered_kmers) *uncovered_kmers = ctx->last_gap_kmers;
@@ -1789,7 +1801,25 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
 
   const uint64_t n_tiles = T->n_win_tiles(w);
   SK_WS(d_seg, unsigned long long*, "seg_count", N_SEG * sizeof(unsigned long long));
-  const bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= 256);
+  // Pruning policy.  p = share of this genome's k-mers the filter accepts, estimated from occupancies: the
+  // genome alone would set about bits*(1-exp(-V/bits)) bits, the common filter kept popcount of them.  A window
+  // of w k-mers holds ~c*p accepted candidates when hashes <= (c/w)*2^64 are kept; c = 12/p leaves ~6e-6 of the
+  // windows uncovered (they are re-evaluated densely).  Below p = 2 % the pruned pass is not worth running.
+  bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= 256);
+  uint32_t prune_c = ctx->prune_c;
+  if (pruned && prune_c == 0) {
+    double p = 1.0;
+    if (filter) {
+      uint64_t pc = 0;
+      SK_TRY(nts_bf_popcount(ctx, filter, &pc));
+      const double bits = (double)filter->bytes * 8.0;
+      const double own = bits * (1.0 - std::exp(-(double)rt.n_valid / bits));
+      p = own > 0 ? std::min(1.0, (double)pc / own) : 1.0;
+    }
+    if (p < 0.02 && ctx->sketch_mode == 0) pruned = false;
+    prune_c = (uint32_t)std::min(128.0, std::max(8.0, std::ceil(12.0 / std::max(p, 1e-3))));
+  }
+  ctx->last_c = pruned ? prune_c : 0;
 
   OutSegs segs;
   segs.d_count = d_seg;
@@ -1804,7 +1834,7 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
     SK_HIP(hipMemsetAsync(segs.d_j, 0xFF, slots * 8, ctx->stream));
     SK_HIP(hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
     if (pruned) {
-      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, segs, seg_counts));
+      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, segs, seg_counts, prune_c));
     } else {
       SK_WS(d_keys, uint64_t*, "keys", key_buffer_elems(rt.n_valid) * 8);
       SK_TRY(launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, *T, k, filter, nullptr, d_keys));

@@ -54,8 +54,10 @@ class Context:
 
     def sketch_stats(self):
         "(accepted candidates, uncovered ranges, k-mers in them) of the last sketch call"
-        a, b, c = u64(), u64(), u64()
-        self.check(self.lib.nts_sketch_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "nts_sketch_stats")
+        a, b, c, d = u64(), u64(), u64(), ctypes.c_uint32()
+        self.check(self.lib.nts_sketch_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)),
+                   "nts_sketch_stats")
+        self.last_prune_c = d.value
         return a.value, b.value, c.value
 
     def close(self):
