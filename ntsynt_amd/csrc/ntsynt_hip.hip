@@ -1566,16 +1566,113 @@ int run_window_dense_host(nts_ctx* ctx, const uint64_t* d_keys, const std::vecto
 
 constexpr uint32_t GAP_PEEK = 1024; // uncovered ranges fetched together with the counters
 
-// Pruned path; see nts_pruned.inc.  Fills `out` with every minimizer (sparse + dense on uncovered ranges) and
-// leaves the per-segment minimizer counts in seg_counts (the stream is synchronised on return).
-int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter, const OutSegs& out,
-               unsigned long long* seg_counts, uint32_t prune_c)
+struct SortedOut
+{
+  uint64_t* d_j = nullptr;   // compact indices of the minimizers, ascending
+  uint64_t* d_key = nullptr; // their keys (h0)
+  uint64_t count = 0;
+};
+
+// dense kernels over (pseudo-)records into segmented buffers, then a sort: `res` gets the ordered list.
+// tiles: optional list of key tiles to hash (uncovered ranges only); nullptr = all tiles.
+int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter,
+                     const std::vector<uint64_t>* pseudo_vstart, const std::vector<uint64_t>* pseudo_nv, const std::vector<uint32_t>* tiles,
+                     uint64_t est_kmers, const char* slot_prefix, SortedOut& res)
+{
+  const RunTable& rt = T.rt;
+#define DN_WS(ptr, type, name, bytes)                                                               \
+  type ptr = (type)ws_get(ctx, name, bytes);                                                        \
+  if (!ptr) return NTS_ENOMEM
+  const std::string pre(slot_prefix);
+  DN_WS(d_seg, unsigned long long*, "seg_count", N_SEG * sizeof(unsigned long long));
+  DN_WS(d_keys, uint64_t*, "keys", key_buffer_elems(rt.n_valid) * 8);
+  int rc;
+  uint32_t* d_tiles = nullptr;
+  uint64_t n_tile_ids = 0;
+  if (tiles && tiles->size() * 2 <= (rt.n_valid + KEY_TILE - 1) / KEY_TILE) {
+    if ((rc = ws_upload(ctx, "gap_tiles", *tiles, &d_tiles))) return rc;
+    n_tile_ids = tiles->size();
+  }
+  if ((rc = launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, T, k, filter, nullptr, d_keys, d_tiles, n_tile_ids))) return rc;
+  uint64_t n_tiles;
+  const uint64_t *d_vs, *d_nv, *d_ts;
+  uint32_t n_rec;
+  std::vector<uint64_t> tile_start;
+  if (pseudo_vstart) {
+    n_tiles = tiles_of(*pseudo_nv, w, tile_start);
+    if (pseudo_nv->size() > 0xFFFFFFF0ULL) return fail(ctx, NTS_ERANGE, "too many uncovered ranges");
+    uint64_t *a = nullptr, *b = nullptr, *c = nullptr;
+    if ((rc = ws_upload(ctx, "win_vstart", *pseudo_vstart, &a))) return rc;
+    if ((rc = ws_upload(ctx, "win_nv", *pseudo_nv, &b))) return rc;
+    if ((rc = ws_upload(ctx, "win_tiles", tile_start, &c))) return rc;
+    d_vs = a;
+    d_nv = b;
+    d_ts = c;
+    n_rec = (uint32_t)pseudo_nv->size();
+  } else {
+    n_tiles = T.n_win_tiles(w);
+    d_vs = T.d_rec_vstart;
+    d_nv = T.d_rec_nv;
+    if ((rc = T.win_tiles_device(ctx, w, &d_ts))) return rc;
+    n_rec = g->n_rec;
+  }
+  OutSegs segs;
+  segs.d_count = d_seg;
+  segs.seg_cap = std::max<uint64_t>(256, (3 * est_kmers / w + 2 * n_tiles) / N_SEG + 64);
+  unsigned long long seg_counts[N_SEG];
+  uint64_t count = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const uint64_t slots = segs.seg_cap * N_SEG;
+    segs.d_j = (uint64_t*)ws_get(ctx, (pre + "out_j").c_str(), slots * 8);
+    segs.d_key = (uint64_t*)ws_get(ctx, (pre + "out_key").c_str(), slots * 8);
+    if (!segs.d_j || !segs.d_key) return NTS_ENOMEM;
+    HIP_TRY(ctx, hipMemsetAsync(segs.d_j, 0xFF, slots * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
+    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, segs, "window_min"))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(seg_counts, d_seg, sizeof(seg_counts), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t worst = 0;
+    count = 0;
+    for (uint32_t s = 0; s < N_SEG; ++s) {
+      worst = std::max<uint64_t>(worst, seg_counts[s]);
+      count += seg_counts[s];
+    }
+    if (worst <= segs.seg_cap) break;
+    if (attempt == 1) return fail(ctx, NTS_EHIP, "minimizer segments overflowed twice");
+    segs.seg_cap = worst;
+  }
+  res.count = count;
+  if (count == 0) return NTS_OK;
+  const uint64_t slots = segs.seg_cap * N_SEG;
+  DN_WS(d_oj2, uint64_t*, (pre + "out_j2").c_str(), slots * 8);
+  DN_WS(d_ok2, uint64_t*, (pre + "out_key2").c_str(), slots * 8);
+  size_t tmp_bytes = 0;
+  // compact indices are < n_valid: sort only the bits that can differ (sentinel slots are all ones)
+  uint32_t bits = 1;
+  while (bits < 64 && (rt.n_valid >> bits) != 0) ++bits;
+  const uint32_t end_bit = std::min<uint32_t>(64, bits + 1);
+  HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, segs.d_j, d_oj2, segs.d_key, d_ok2, slots, 0, end_bit, ctx->stream));
+  DN_WS(d_tmp, void*, "sort_tmp", std::max<size_t>(tmp_bytes, 16));
+  {
+    ScopedTimer t(ctx, "sort_minimizers");
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp, tmp_bytes, segs.d_j, d_oj2, segs.d_key, d_ok2, slots, 0, end_bit, ctx->stream));
+  }
+  res.d_j = d_oj2;
+  res.d_key = d_ok2;
+  return NTS_OK;
+#undef DN_WS
+}
+
+// Pruned path; see nts_pruned.inc.  `res` gets every minimizer, ordered (sparse winners come out ordered by
+// construction; winners of uncovered ranges, if any, are sorted and merged in).
+int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter, uint32_t prune_c,
+               SortedOut& res)
 {
   const RunTable& rt = T.rt;
   const uint64_t V = rt.n_valid;
   const uint64_t n_kt = (V + KEY_TILE - 1) / KEY_TILE;
   if (n_kt > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
-  // threshold: a fraction c/w of all hashes, c = ctx->prune_c
+  // threshold: a fraction c/w of all hashes
   const unsigned __int128 full = ((unsigned __int128)1) << 64;
   unsigned __int128 t128 = full / w * prune_c;
   const uint64_t tau = t128 >= full - 1 ? KEY_MAX - 1 : (uint64_t)t128;
@@ -1595,16 +1692,24 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   uint64_t cseg_cap = (uint64_t)((double)V * frac * 1.25 / N_SEG) + 8192;
   unsigned long long ctl[N_SEG + 1];
   std::vector<uint64_t> glo(GAP_PEEK), ghi(GAP_PEEK);
-  size_t scan_bytes = 0;
-  HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, d_tcnt64, d_tscan, (uint64_t)0, n_kt, rocprim::plus<uint64_t>(), ctx->stream));
-  PR_WS(d_scan_tmp, void*, "sel_scan_tmp", std::max<size_t>(scan_bytes, 16));
-  uint64_t m = 0, n_gap = 0;
+  uint64_t m = 0, n_gap = 0, n_sparse = 0;
+  uint64_t *d_sj = nullptr, *d_sk = nullptr;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    PR_WS(d_sj, uint64_t*, "sel_seg_j", cseg_cap * N_SEG * 8);
-    PR_WS(d_sk, uint64_t*, "sel_seg_key", cseg_cap * N_SEG * 8);
     const uint64_t m_max = cseg_cap * N_SEG;
+    const uint64_t n_blk = (m_max + SPARSE_THREADS - 1) / SPARSE_THREADS;
+    d_sj = (uint64_t*)ws_get(ctx, "sel_seg_j", m_max * 8);
+    d_sk = (uint64_t*)ws_get(ctx, "sel_seg_key", m_max * 8);
     PR_WS(d_pj, uint64_t*, "cand_j", m_max * 8);
     PR_WS(d_pk, uint64_t*, "cand_key", m_max * 8);
+    PR_WS(d_stj, uint64_t*, "stage_j", n_blk * SPARSE_THREADS * 8);
+    PR_WS(d_stk, uint64_t*, "stage_k", n_blk * SPARSE_THREADS * 8);
+    PR_WS(d_bcnt, uint64_t*, "blk_cnt", n_blk * 8);
+    PR_WS(d_bscan, uint64_t*, "blk_scan", n_blk * 8);
+    if (!d_sj || !d_sk) return NTS_ENOMEM;
+    size_t scan_bytes = 0, scan_bytes2 = 0;
+    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, d_tcnt64, d_tscan, (uint64_t)0, n_kt, rocprim::plus<uint64_t>(), ctx->stream));
+    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scan_bytes2, d_bcnt, d_bscan, (uint64_t)0, n_blk, rocprim::plus<uint64_t>(), ctx->stream));
+    PR_WS(d_scan_tmp, void*, "sel_scan_tmp", std::max<size_t>(std::max(scan_bytes, scan_bytes2), 16));
     HIP_TRY(ctx, hipMemsetAsync(d_ctl, 0, (N_SEG + 1) * 8, ctx->stream));
     SelParams S;
     S.code = g->d_code + PAD;
@@ -1643,25 +1748,29 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     Q.rec_nv = T.d_rec_nv;
     Q.n_rec = g->n_rec;
     Q.w = w;
-    Q.out_j = out.d_j;
-    Q.out_key = out.d_key;
-    Q.seg_count = out.d_count;
-    Q.seg_cap = out.seg_cap;
+    Q.stage_j = d_stj;
+    Q.stage_k = d_stk;
+    Q.blk_cnt = d_bcnt;
     Q.gap_lo = d_glo;
     Q.gap_hi = d_ghi;
     Q.gap_count = d_ctl + N_SEG;
     Q.gap_cap = gap_cap;
     {
       ScopedTimer t(ctx, "sparse_win");
-      hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)((m_max + SPARSE_THREADS - 1) / SPARSE_THREADS)), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
+      hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
       hipLaunchKernelGGL(k_gap_records, dim3((g->n_rec + 255) / 256), dim3(256), 0, ctx->stream, Q);
+      // ordered output without a sort: scan the per-workgroup counts, gather (the candidate segments are free again)
+      HIP_TRY(ctx, rocprim::exclusive_scan(d_scan_tmp, scan_bytes2, d_bcnt, d_bscan, (uint64_t)0, n_blk, rocprim::plus<uint64_t>(), ctx->stream));
+      hipLaunchKernelGGL(k_gather_winners, dim3((uint32_t)n_blk), dim3(256), 0, ctx->stream, d_stj, d_stk, d_bcnt, d_bscan, d_sj, d_sk);
     }
     HIP_TRY(ctx, hipGetLastError());
-    // one synchronisation: candidate counters, uncovered-range count + a first batch of ranges, minimizer counters
+    // one synchronisation: candidate counters, uncovered-range count + a first batch of ranges, winner count
+    uint64_t last_scan = 0, last_cnt = 0;
     HIP_TRY(ctx, hipMemcpyAsync(ctl, d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(glo.data(), d_glo, std::min<uint64_t>(GAP_PEEK, gap_cap) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ghi.data(), d_ghi, std::min<uint64_t>(GAP_PEEK, gap_cap) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(seg_counts, out.d_count, N_SEG * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&last_scan, d_bscan + (n_blk - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&last_cnt, d_bcnt + (n_blk - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t worst = 0;
     m = 0;
@@ -1670,15 +1779,16 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       m += ctl[s];
     }
     n_gap = ctl[N_SEG];
+    n_sparse = last_scan + last_cnt;
     if (worst <= cseg_cap) break;
     if (attempt == 1) return fail(ctx, NTS_EHIP, "candidate segments overflowed twice");
-    // candidate lists were truncated: everything downstream of them is void.  Reset the outputs and retry.
-    cseg_cap = worst + 1024;
-    HIP_TRY(ctx, hipMemsetAsync(out.d_j, 0xFF, out.seg_cap * N_SEG * 8, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(out.d_count, 0, N_SEG * 8, ctx->stream));
+    cseg_cap = worst + 1024; // candidate lists were truncated: everything downstream of them is void; run again
   }
   ctx->last_candidates = m;
   ctx->last_gaps = n_gap;
+  res.d_j = d_sj;
+  res.d_key = d_sk;
+  res.count = n_sparse;
   if (n_gap == 0) return NTS_OK;
   if (n_gap > gap_cap) return fail(ctx, NTS_EHIP, "uncovered-range list overflowed");
   // ---- dense evaluation of the uncovered ranges ------------------------------------------------------------
@@ -1703,17 +1813,22 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       if (tiles.empty() || tiles.back() != (uint32_t)t) tiles.push_back((uint32_t)t);
   }
   ctx->last_gap_kmers = covered;
-  PR_WS(d_keys, uint64_t*, "keys", key_buffer_elems(V) * 8);
-  const bool all_tiles = tiles.size() * 2 > n_kt;
-  uint32_t* d_tiles = nullptr;
-  int rc;
-  if (!all_tiles && (rc = ws_upload(ctx, "gap_tiles", tiles, &d_tiles))) return rc;
-  rc = launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, T, k, filter, nullptr, d_keys, all_tiles ? nullptr : d_tiles,
-                              all_tiles ? 0 : tiles.size());
+  SortedOut dense;
+  int rc = run_dense_sorted(ctx, g, T, k, w, filter, &pv, &pn, &tiles, covered, "gap_", dense);
   if (rc) return rc;
-  if ((rc = run_window_dense_host(ctx, d_keys, pv, pn, w, out, "window_min"))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(seg_counts, out.d_count, N_SEG * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (dense.count == 0) return NTS_OK;
+  const uint64_t total = n_sparse + dense.count;
+  PR_WS(d_mj, uint64_t*, "merged_j", total * 8);
+  PR_WS(d_mk, uint64_t*, "merged_key", total * 8);
+  {
+    ScopedTimer t(ctx, "merge_lists");
+    hipLaunchKernelGGL(k_merge_lists, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_sj, d_sk, n_sparse, dense.d_j, dense.d_key,
+                       dense.count, d_mj, d_mk);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  res.d_j = d_mj;
+  res.d_key = d_mk;
+  res.count = total;
   return NTS_OK;
 #undef PR_WS
 }
@@ -1799,8 +1914,6 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   type ptr = (type)ws_get(ctx, name, bytes);                                                        \
   if (!ptr) return bail(NTS_ENOMEM)
 
-  const uint64_t n_tiles = T->n_win_tiles(w);
-  SK_WS(d_seg, unsigned long long*, "seg_count", N_SEG * sizeof(unsigned long long));
   // Pruning policy.  p = share of this genome's k-mers the filter accepts, estimated from occupancies: the
   // genome alone would set about bits*(1-exp(-V/bits)) bits, the common filter kept popcount of them.  A window
   // of w k-mers holds ~c*p accepted candidates when hashes <= (c/w)*2^64 are kept; c = 12/p leaves ~6e-6 of the
@@ -1821,59 +1934,18 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   }
   ctx->last_c = pruned ? prune_c : 0;
 
-  OutSegs segs;
-  segs.d_count = d_seg;
-  segs.seg_cap = std::max<uint64_t>(256, (3 * rt.n_valid / w + 2 * n_tiles) / N_SEG + 64);
-  uint64_t count = 0;
-  unsigned long long seg_counts[N_SEG];
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    const uint64_t slots = segs.seg_cap * N_SEG;
-    segs.d_j = (uint64_t*)ws_get(ctx, "out_j", slots * 8);
-    segs.d_key = (uint64_t*)ws_get(ctx, "out_key", slots * 8);
-    if (!segs.d_j || !segs.d_key) return bail(NTS_ENOMEM);
-    SK_HIP(hipMemsetAsync(segs.d_j, 0xFF, slots * 8, ctx->stream));
-    SK_HIP(hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
-    if (pruned) {
-      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, segs, seg_counts, prune_c));
-    } else {
-      SK_WS(d_keys, uint64_t*, "keys", key_buffer_elems(rt.n_valid) * 8);
-      SK_TRY(launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, *T, k, filter, nullptr, d_keys));
-      const uint64_t* d_ts = nullptr;
-      SK_TRY(T->win_tiles_device(ctx, w, &d_ts));
-      SK_TRY(launch_window_dense(ctx, d_keys, T->d_rec_vstart, T->d_rec_nv, d_ts, g->n_rec, n_tiles, w, segs, "window_min"));
-      SK_HIP(hipMemcpyAsync(seg_counts, d_seg, sizeof(seg_counts), hipMemcpyDeviceToHost, ctx->stream));
-      SK_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    uint64_t worst = 0;
-    count = 0;
-    for (uint32_t s = 0; s < N_SEG; ++s) {
-      worst = std::max<uint64_t>(worst, seg_counts[s]);
-      count += seg_counts[s];
-    }
-    if (worst <= segs.seg_cap) break;
-    if (attempt == 1) return bail(fail(ctx, NTS_EHIP, "minimizer segments overflowed twice"));
-    segs.seg_cap = worst; // exact need known now; run again
-  }
+  SortedOut res;
+  if (pruned)
+    SK_TRY(run_pruned(ctx, g, *T, k, w, filter, prune_c, res));
+  else
+    SK_TRY(run_dense_sorted(ctx, g, *T, k, w, filter, nullptr, nullptr, nullptr, rt.n_valid, "", res));
+  const uint64_t count = res.count;
   mx->n = count;
   if (count) {
-    const uint64_t slots = segs.seg_cap * N_SEG;
-    SK_WS(d_oj2, uint64_t*, "out_j2", slots * 8);
-    SK_WS(d_ok2, uint64_t*, "out_key2", slots * 8);
-    size_t tmp_bytes = 0;
-    // compact indices are < n_valid: sort only the bits that can differ (sentinel slots are all ones)
-    uint32_t bits = 1;
-    while (bits < 64 && (rt.n_valid >> bits) != 0) ++bits;
-    const uint32_t end_bit = std::min<uint32_t>(64, bits + 1);
-    SK_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, segs.d_j, d_oj2, segs.d_key, d_ok2, slots, 0, end_bit, ctx->stream));
-    SK_WS(d_tmp, void*, "sort_tmp", std::max<size_t>(tmp_bytes, 16));
-    {
-      ScopedTimer t(ctx, "sort_minimizers");
-      SK_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, segs.d_j, d_oj2, segs.d_key, d_ok2, slots, 0, end_bit, ctx->stream));
-    }
     SK_TRY(alloc_result(ctx, mx, count));
     {
       ScopedTimer t(ctx, "finalize");
-      hipLaunchKernelGGL(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_oj2, d_ok2, (uint64_t)count,
+      hipLaunchKernelGGL(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, res.d_j, res.d_key, (uint64_t)count,
                          T->d_run_pos, T->d_run_vstart, T->n_runs, g->d_rec_off, g->n_rec, k, mx->d_h1, mx->d_rec, mx->d_pos);
     }
     SK_HIP(hipGetLastError());
