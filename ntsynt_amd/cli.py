@@ -125,11 +125,27 @@ def main(argv=None):
         print("Stages (GPU, in process):", " -> ".join(plan))
         return 0
     from . import pipeline
+    # one process per GPU under `python -m torch.distributed.run --nproc-per-node N bin/ntSynt ...`:
+    # genomes are sharded over the ranks (ntsynt_amd/pipeline.py), rank 0 writes the outputs
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    device = args.device
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    quiet = (lambda *a, **k: None)
     pipeline.run(fastas, k=args.k, w=args.w, fpr=args.fpr, prefix=args.prefix, w_rounds=args.w_rounds,
                  indel=args.indel, merge=args.merge, block_size=args.block_size, common=not args.no_common,
-                 simplify=not args.no_simplify_graph, device=args.device, benchmark=args.benchmark,
-                 log=print if args.dev else (lambda *a, **k: None))
-    print("Done ntSynt!")
+                 simplify=not args.no_simplify_graph, device=device, benchmark=args.benchmark,
+                 log=print if (args.dev and int(os.environ.get("RANK", "0")) == 0) else quiet)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("Done ntSynt!")
     return 0
 
 

@@ -5,15 +5,20 @@
 
 with the same artefact names in the CWD: {basename}.fai, {prefix}.common.bf,
 {basename}.k{k}.w{w}.tsv, {prefix}.synteny_blocks.tsv, {prefix}.pre-collinear-merge.synteny_blocks.tsv.
-All sequence-scale compute runs in libntsynt_hip.so; there is no CPU fallback."""
+All sequence-scale compute runs in libntsynt_hip.so; there is no CPU fallback.
+
+Multi-GPU (one process per GPU, torch.distributed over RCCL): genome g lives on rank
+g mod N.  Exchange 1: every rank ANDs the filters of its own genomes, then a bitwise-AND all-reduce gives
+the common filter on every rank.  Exchange 2: the owner of a genome sketches it and broadcasts the
+minimizer list; the graph stage then runs replicated (identical, deterministic) on every rank and rank 0
+writes the files.  The orchestration below is written against a small `backend` object so that the
+schedule can be exercised on CPU (gloo) with test doubles; the product backend is GpuBackend."""
 import os
 import time
 
 import numpy as np
 
 from . import fasta as fa
-from .device import BloomFilter, Context, Genome, bf_size_bytes, sketch
-from .graph import build_graph_device, walk_chains
 from .synteny import SyntenyEngine
 
 
@@ -75,81 +80,225 @@ class Stages:
                 fh.write(f"{name}\t{dt:.6f}\n")
 
 
+class GpuBackend:
+    """The product backend: every call lands in libntsynt_hip.so on this rank's GPU."""
+
+    def __init__(self, device=0, ctx=None):
+        from .device import Context
+        self.own_ctx = ctx is None
+        self.ctx = ctx or Context(device)
+        self.device = self.ctx.device
+
+    # genomes
+    def load_genome(self, path):
+        from .device import Genome
+        recs = fa.read_fasta(path)
+        g = Genome(self.ctx, recs.names, recs.seq, recs.rec_off, recs.rec_len)
+        g.recs = recs
+        return g
+
+    # Bloom filters: the bit array lives in a torch tensor when collectives will run on it
+    def bf_new(self, nbytes, k, world=1, ones=False):
+        from .device import BloomFilter, wrap_bloom
+        from .dist import padded_len
+        if world == 1:
+            assert not ones
+            return BloomFilter(self.ctx, nbytes, k)
+        import torch
+        buf = torch.zeros(padded_len(nbytes, world), dtype=torch.uint8, device=f"cuda:{self.device}")
+        if ones:                      # identity of AND, for a rank that owns no genome
+            buf[:nbytes] = 0xFF
+        torch.cuda.synchronize(buf.device)
+        bf = wrap_bloom(self.ctx, buf, nbytes, k)
+        bf.tensor = buf
+        return bf
+
+    def bf_insert(self, bf, genome):
+        bf.insert(genome)
+
+    def bf_and(self, acc, other):
+        acc.and_(other)
+
+    def bf_clear(self, bf):
+        bf.clear()
+
+    def bf_fpr(self, bf):
+        return bf.get_fpr()
+
+    def bf_bits(self, bf):
+        return bf.to_numpy()
+
+    def and_into(self, a, b):
+        from .device import and_raw
+        and_raw(self.ctx, a.data_ptr(), b.data_ptr(), a.numel())
+        self.ctx.sync()
+
+    def sync(self):
+        self.ctx.sync()
+
+    # sketch + graph
+    def sketch(self, genome, k, w, bf, masks=None):
+        from .device import sketch
+        mx = sketch(self.ctx, genome, k, w, bf, masks)
+        out = mx.to_numpy()
+        mx.free()
+        return out
+
+    def graph(self, lists, keeps, list_ids):
+        from .graph import build_graph_device
+        return build_graph_device(self.ctx, lists, keeps, list_ids)
+
+    def walk(self, nv, eu, ev):
+        from .graph import walk_chains
+        return walk_chains(nv, eu, ev)
+
+    def to_comm(self, arr, dtype):
+        "numpy -> tensor on the device the collectives use"
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(arr).view(dtype)).to(f"cuda:{self.device}")
+
+    def comm_empty(self, n, dtype):
+        import torch
+        return torch.empty(n, dtype=dtype, device=f"cuda:{self.device}")
+
+    def close(self):
+        if self.own_ctx:
+            self.ctx.close()
+
+
+def _bcast_list(backend, owner, payload):
+    """Broadcast one minimizer list (h1 uint64, rec uint32, pos uint64 numpy arrays) from `owner`."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    n = backend.to_comm(np.array([len(payload[0]) if rank == owner else 0], dtype=np.int64), np.int64)
+    dist.broadcast(n, src=owner)
+    cnt = int(n.item())
+    if rank == owner:
+        h1 = backend.to_comm(payload[0].astype(np.uint64), np.int64)
+        rec = backend.to_comm(payload[1].astype(np.uint32), np.int32)
+        pos = backend.to_comm(payload[2].astype(np.uint64), np.int64)
+    else:
+        h1 = backend.comm_empty(cnt, torch.int64)
+        rec = backend.comm_empty(cnt, torch.int32)
+        pos = backend.comm_empty(cnt, torch.int64)
+    if cnt:
+        dist.broadcast(h1, src=owner)
+        dist.broadcast(rec, src=owner)
+        dist.broadcast(pos, src=owner)
+    return (h1.cpu().numpy().view(np.uint64), rec.cpu().numpy().view(np.uint32), pos.cpu().numpy().view(np.uint64))
+
+
 def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000, merge=10000,
         block_size=500, common=True, simplify=True, device=0, write_mx_tsv=True, mx_with_seq=True,
-        benchmark=False, log=print, ctx=None):
-    """FASTA paths -> {output file name: text}.  Mirrors oracle.synteny_oracle.run_pipeline's signature so the
-    parity tests read alike; every stage here runs on the GPU."""
+        benchmark=False, log=print, ctx=None, backend=None):
+    """FASTA paths -> engine (outputs in .outputs and in the CWD).  Mirrors oracle.synteny_oracle.run_pipeline's
+    signature so the parity tests read alike.  Under torch.distributed (WORLD_SIZE > 1, process group already
+    initialised by the caller) genomes are sharded over the ranks."""
     prefix = prefix or f"ntSynt.k{k}.w{w}"
+    world, rank = 1, 0
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(), dist.get_rank()
+    except ImportError:
+        dist = None
+    own_backend = backend is None
+    backend = backend or GpuBackend(device, ctx)
     st = Stages()
-    own_ctx = ctx is None
-    ctx = ctx or Context(device)
+    owner = {p: i % world for i, p in enumerate(fastas)}
+    mine = [p for p in fastas if owner[p] == rank]
+
     st.start("read_fasta+upload")
-    recs = {p: fa.read_fasta(p) for p in fastas}
-    genomes = {}
-    for p in fastas:
-        r = recs[p]
-        genomes[p] = Genome(ctx, r.names, r.seq, r.rec_off, r.rec_len)
-        fa.write_fai(f"{fa.basename(p)}.fai", r)
+    genomes = {p: backend.load_genome(p) for p in mine}
+    for p in mine:
+        fa.write_fai(f"{fa.basename(p)}.fai", genomes[p].recs)
+    # record names and sizes are needed everywhere (output text, filter sizing)
+    meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, meta)
+        meta = {p: v for part in gathered for p, v in part.items()}
     st.stop()
 
     bf = None
     if common:
         st.start("make_common_bf")
         ordered = sorted(fastas)                               # src/ntsynt_make_common_bf.cpp:105-107
-        approx, nbytes = bf_size_bytes(genomes[ordered[0]].total_bp, fpr)
-        log(f"Genome size (bp): {genomes[ordered[0]].total_bp}")
+        from .device import bf_size_bytes
+        approx, nbytes = bf_size_bytes(meta[ordered[0]][1], fpr)
+        log(f"Genome size (bp): {meta[ordered[0]][1]}")
         log(f"BF size (bytes): {approx}")
-        bf = BloomFilter(ctx, nbytes, k)
-        bf.insert(genomes[ordered[0]])
-        log(f"Bloom filter FPR: {bf.get_fpr()}")
-        if len(ordered) > 1:
-            tmp = BloomFilter(ctx, nbytes, k)
-            for p in ordered[1:]:
-                tmp.clear()
-                tmp.insert(genomes[p])                          # G_i; AND == cascade level (SURVEY.md F8)
-                bf.and_(tmp)
-                log(f"Bloom filter FPR: {bf.get_fpr()}")
-            tmp.free()
-        log(f"Final Bloom filter FPR: {bf.get_fpr()}")
-        write_bf(f"{prefix}.common.bf", bf.to_numpy(), k)
+        my_sorted = [p for p in ordered if owner[p] == rank]
+        bf = backend.bf_new(nbytes, k, world, ones=(world > 1 and not my_sorted))
+        if my_sorted:
+            backend.bf_insert(bf, genomes[my_sorted[0]])
+            if world == 1:
+                log(f"Bloom filter FPR: {backend.bf_fpr(bf)}")
+            if len(my_sorted) > 1:
+                tmp = backend.bf_new(nbytes, k)
+                for p in my_sorted[1:]:
+                    backend.bf_clear(tmp)
+                    backend.bf_insert(tmp, genomes[p])          # G_i; AND == cascade level (SURVEY.md F8)
+                    backend.bf_and(bf, tmp)
+                    if world == 1:
+                        log(f"Bloom filter FPR: {backend.bf_fpr(bf)}")
+                if hasattr(tmp, "free"):
+                    tmp.free()
+        if world > 1:
+            from .dist import allreduce_and
+            backend.sync()
+            allreduce_and(bf.tensor, backend.and_into)
+            if bf.tensor.is_cuda:
+                import torch
+                torch.cuda.synchronize(bf.tensor.device)
+        log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
+        if rank == 0:
+            write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k)
         st.stop()
 
     st.start("indexlr")
     tsv_names, initial = [], []
     for p in fastas:
-        mx = sketch(ctx, genomes[p], k, w, bf)
-        h1, rec, pos = mx.to_numpy()
-        mx.free()
+        out = backend.sketch(genomes[p], k, w, bf) if owner[p] == rank else None
         tsv = f"{fa.basename(p)}.k{k}.w{w}.tsv"
-        if write_mx_tsv:
-            write_indexlr_tsv(tsv, recs[p], h1, rec, pos, k, mx_with_seq)
+        if owner[p] == rank and write_mx_tsv:
+            write_indexlr_tsv(tsv, genomes[p].recs, out[0], out[1], out[2], k, mx_with_seq)
+        if world > 1:
+            out = _bcast_list(backend, owner[p], out)
         tsv_names.append(tsv)
-        initial.append((h1, rec, pos))
+        initial.append(out)
     st.stop()
 
     st.start("ntsynt_synteny")
 
-    def graph_fn(lists, keeps, list_ids):
-        return build_graph_device(ctx, lists, keeps, list_ids)
-
     def sketch_fn(i, masks, new_w):
-        mx = sketch(ctx, genomes[fastas[i]], k, new_w, bf, masks)
-        out = mx.to_numpy()
-        mx.free()
-        return out
+        p = fastas[i]
+        out = backend.sketch(genomes[p], k, new_w, bf, masks) if owner[p] == rank else None
+        return _bcast_list(backend, owner[p], out) if world > 1 else out
 
-    eng = SyntenyEngine(tsv_names, [recs[p].names for p in fastas], k, w, w_rounds, indel, merge, block_size, prefix,
-                        graph_fn, sketch_fn, walk_chains, simplify=simplify, log=log)
-    outputs = eng.run(initial)
+    if rank != 0:                       # replicas compute, only rank 0 leaves files behind
+        scratch = os.path.join(os.getcwd(), f".ntsynt_rank{rank}")
+        os.makedirs(scratch, exist_ok=True)
+        out_prefix = os.path.join(scratch, os.path.basename(prefix))
+    else:
+        out_prefix = prefix
+    eng = SyntenyEngine(tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size, out_prefix,
+                        backend.graph, sketch_fn, backend.walk, simplify=simplify, log=log)
+    eng.run(initial)
+    if rank != 0:
+        eng.outputs = {os.path.basename(n): t for n, t in eng.outputs.items()}
+        import shutil
+        shutil.rmtree(scratch, ignore_errors=True)
     st.stop()
-    if benchmark:
+    if benchmark and rank == 0:
         st.write(f"{prefix}.stage_times.tsv")
     for g in genomes.values():
-        g.free()
-    if bf is not None:
+        if hasattr(g, "free"):
+            g.free()
+    if bf is not None and hasattr(bf, "free"):
         bf.free()
-    if own_ctx:
-        ctx.close()
+    if own_backend:
+        backend.close()
     eng.stage_times = st.rows
     return eng

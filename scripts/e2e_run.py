@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""End-to-end wall clock of the GPU pipeline: FASTA files on disk -> final synteny TSV (stage times in
+{prefix}.stage_times.tsv).  Synthetic family written to --dir first (not timed).
+
+  python scripts/e2e_run.py --mbp 100 --genomes 3 -d 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mbp", type=float, default=100.0)
+    ap.add_argument("--genomes", type=int, default=3)
+    ap.add_argument("--contigs", type=int, default=4)
+    ap.add_argument("--divergence", type=float, default=0.01)
+    ap.add_argument("--dir", default="/tmp/e2e")
+    ap.add_argument("--oracle", action="store_true", help="also run the CPU oracle pipeline and compare the TSVs")
+    args = ap.parse_args()
+    from ntsynt_amd import cli, pipeline, synth
+    os.makedirs(args.dir, exist_ok=True)
+    t = time.time()
+    paths = synth.make_family(args.dir, args.genomes, int(args.mbp * 1e6), args.contigs, args.divergence, micro=20)
+    t_gen = time.time() - t
+    os.chdir(args.dir)
+    pct = args.divergence * 100
+    parser = cli.build_parser()
+    a = parser.parse_args(paths + ["-d", str(pct), "-p", "e2e"])
+    cli.resolve(parser, a)
+    t = time.time()
+    eng = pipeline.run(paths, k=a.k, w=a.w, fpr=a.fpr, prefix=a.prefix, w_rounds=a.w_rounds, indel=a.indel, merge=a.merge,
+                       block_size=a.block_size, benchmark=True, log=lambda *x: None)
+    wall = time.time() - t
+    out = {"workload": f"{args.genomes} x {args.mbp:g} Mbp FASTA, -d {pct:g} (w_rounds {a.w_rounds}, indel {a.indel}, merge {a.merge}, "
+                       f"block {a.block_size})", "generate_inputs_s": round(t_gen, 2), "end_to_end_s": round(wall, 3),
+           "stages_s": {n: round(s, 3) for n, s in eng.stage_times},
+           "blocks": len(eng.outputs["e2e.synteny_blocks.tsv"].splitlines()) // args.genomes, "engine_stats": eng.stats}
+    if args.oracle:
+        from oracle import synteny_oracle as SO
+        os.makedirs("ora", exist_ok=True)
+        os.chdir("ora")
+        t = time.time()
+        ora = SO.run_pipeline(paths, k=a.k, w=a.w, fpr=a.fpr, prefix="e2e", w_rounds=a.w_rounds, indel=a.indel, merge=a.merge,
+                              block_size=a.block_size, threads=os.cpu_count(), write_mx_tsv=False)
+        out["oracle_s"] = round(time.time() - t, 2)
+        out["identical_to_oracle"] = ora.outputs["e2e.synteny_blocks.tsv"] == eng.outputs["e2e.synteny_blocks.tsv"]
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
