@@ -208,6 +208,30 @@ void nts_graph_free(nts_graph* g);
 int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, const uint32_t* e_v,
                     uint64_t** off, uint32_t** verts, uint64_t* n_paths);
 
+/* ---- host-side I/O (no GPU work) ---------------------------------------------------------------------
+ * nts_fasta_read: plain or gzip FASTA, single- or multi-line, LF or CRLF -> concatenated bases + record table +
+ *   record ids (header up to the first whitespace, NUL-separated) + the `samtools faidx` columns.  Replaces
+ *   btllib::SeqReader(LONG_MODE) record streaming (src/ntsynt_make_common_bf.cpp:32-36) and rule faidx (smk:48-53).
+ * nts_write_indexlr_tsv: `indexlr --long --pos [--seq]` text (smk:81-85): "id\thash:pos[:KMER] ...\n" per record;
+ *   minimizers given in (record, position) order as nts_mx_download returns them. */
+typedef struct
+{
+  uint8_t* seq;
+  uint64_t n;
+  uint32_t n_rec;
+  uint64_t* rec_off;
+  uint64_t* rec_len;
+  char* names;
+  uint64_t names_bytes;
+  uint64_t* fai_offset;
+  uint32_t* fai_linebases;
+  uint32_t* fai_linewidth;
+} nts_fasta;
+int nts_fasta_read(const char* path, nts_fasta* out);
+void nts_fasta_free(nts_fasta* f);
+int nts_write_indexlr_tsv(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,
+                          uint64_t n, uint32_t k, int with_seq);
+
 void nts_free(void* p);
 
 #ifdef __cplusplus

@@ -24,6 +24,12 @@ class MxList(ctypes.Structure):
     _fields_ = [("h1", c_vp), ("rec", c_vp), ("pos", c_vp), ("keep", c_vp), ("list_id", c_vp), ("n", u64)]
 
 
+class Fasta(ctypes.Structure):
+    _fields_ = [("seq", c_u8p), ("n", u64), ("n_rec", u32), ("rec_off", c_u64p), ("rec_len", c_u64p),
+                ("names", ctypes.POINTER(ctypes.c_char)), ("names_bytes", u64), ("fai_offset", c_u64p),
+                ("fai_linebases", c_u32p), ("fai_linewidth", c_u32p)]
+
+
 class Graph(ctypes.Structure):
     _fields_ = [("nv", u64), ("v_hash", c_u64p), ("occ_rec", c_u32p), ("occ_pos", c_u64p),
                 ("ne", u64), ("e_u", c_u32p), ("e_v", c_u32p), ("e_w", c_u32p), ("e_first", c_u64p)]
@@ -73,6 +79,9 @@ SYMBOLS = [
     ("nts_graph_build", ctypes.c_int, [c_vp, u32, ctypes.POINTER(MxList), ctypes.POINTER(Graph)]),
     ("nts_walk_chains", ctypes.c_int, [u64, u64, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_u32p), c_u64p]),
     ("nts_graph_free", None, [ctypes.POINTER(Graph)]),
+    ("nts_fasta_read", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Fasta)]),
+    ("nts_fasta_free", None, [ctypes.POINTER(Fasta)]),
+    ("nts_write_indexlr_tsv", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Fasta), c_vp, c_vp, c_vp, u64, u32, ctypes.c_int]),
     ("nts_free", None, [c_vp]),
 ]
 

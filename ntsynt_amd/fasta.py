@@ -1,21 +1,28 @@
-"""FASTA ingest for the HIP path (plain or gzip, single- or multi-line) and the `.fai` writer.
+"""FASTA ingest for the HIP path (plain or gzip, single- or multi-line, LF or CRLF) and the `.fai` and
+minimizer-TSV writers.
 
-Stands in for btllib::SeqReader(LONG_MODE) as used at src/ntsynt_make_common_bf.cpp:32-36,125-131
-and for `samtools faidx` (bin/ntsynt_run_pipeline.smk:48-53).  Record id = header up to the first
-whitespace.  Bases are kept as written; case folding happens on the GPU (k_encode)."""
+Stands in for btllib::SeqReader(LONG_MODE) as used at src/ntsynt_make_common_bf.cpp:32-36,125-131, for
+`samtools faidx` (bin/ntsynt_run_pipeline.smk:48-53) and for indexlr's text output (smk:81-85).  Record id =
+header up to the first whitespace.  Bases are kept as written; case folding happens on the GPU (k_encode).
+The parsing and formatting run in the native library (nts_fasta_read / nts_write_indexlr_tsv in
+csrc/nts_hostio.cpp); `read_fasta_numpy` is an independent numpy statement of the same rules, kept for tests."""
+import ctypes
 import gzip
 import os
 
 import numpy as np
 
+from . import _lib
+
 
 class FastaRecords:
-    def __init__(self, names, seq, rec_off, rec_len, fai_rows=None):
+    def __init__(self, names, seq, rec_off, rec_len, fai_rows=None, native=None):
         self.names = names
         self.seq = seq            # uint8, records concatenated, no separators
         self.rec_off = rec_off    # uint64
         self.rec_len = rec_len    # uint64
         self.fai_rows = fai_rows  # [(name, length, offset, linebases, linewidth)]
+        self._native = native     # _lib.Fasta owning the buffers behind seq/rec_off/rec_len
 
     @property
     def total_bp(self):
@@ -25,6 +32,48 @@ class FastaRecords:
         o, n = int(self.rec_off[i]), int(self.rec_len[i])
         return self.seq[o:o + n]
 
+    def __del__(self):
+        if getattr(self, "_native", None) is not None:
+            try:
+                _lib.load().nts_fasta_free(ctypes.byref(self._native))
+            except Exception:
+                pass
+            self._native = None
+
+
+def read_fasta(path):
+    """Native reader (csrc/nts_hostio.cpp).  The arrays are views of the library's buffers, released with the
+    FastaRecords object."""
+    lib = _lib.load()
+    f = _lib.Fasta()
+    rc = lib.nts_fasta_read(os.fsencode(path), ctypes.byref(f))
+    if rc != 0:
+        raise OSError(f"cannot read FASTA file {path!r} (code {rc})")
+    n_rec, n = int(f.n_rec), int(f.n)
+    seq = np.ctypeslib.as_array(f.seq, shape=(max(n, 1),))[:n]
+    rec_off = np.ctypeslib.as_array(f.rec_off, shape=(max(n_rec, 1),))[:n_rec]
+    rec_len = np.ctypeslib.as_array(f.rec_len, shape=(max(n_rec, 1),))[:n_rec]
+    raw = ctypes.string_at(f.names, int(f.names_bytes))
+    names = [x.decode() for x in raw.split(b"\0")[:n_rec]]
+    fo = np.ctypeslib.as_array(f.fai_offset, shape=(max(n_rec, 1),))[:n_rec]
+    fb = np.ctypeslib.as_array(f.fai_linebases, shape=(max(n_rec, 1),))[:n_rec]
+    fw = np.ctypeslib.as_array(f.fai_linewidth, shape=(max(n_rec, 1),))[:n_rec]
+    fai = [(names[i], int(rec_len[i]), int(fo[i]), int(fb[i]), int(fw[i])) for i in range(n_rec)]
+    return FastaRecords(names, seq, rec_off, rec_len, fai, native=f)
+
+
+def write_indexlr_tsv(path, recs, h1, rec, pos, k, with_seq=True):
+    """`indexlr --long --pos [--seq]` text: one line per FASTA record."""
+    if recs._native is None:
+        raise ValueError("write_indexlr_tsv needs records read by read_fasta()")
+    h1 = np.ascontiguousarray(h1, dtype=np.uint64)
+    rec = np.ascontiguousarray(rec, dtype=np.uint32)
+    pos = np.ascontiguousarray(pos, dtype=np.uint64)
+    rc = _lib.load().nts_write_indexlr_tsv(os.fsencode(path), ctypes.byref(recs._native), h1.ctypes.data, rec.ctypes.data,
+                                           pos.ctypes.data, h1.size, int(k), 1 if with_seq else 0)
+    if rc != 0:
+        raise OSError(f"cannot write {path!r} (code {rc})")
+
 
 def _load_bytes(path):
     if path.endswith(".gz"):
@@ -33,7 +82,8 @@ def _load_bytes(path):
     return np.fromfile(path, dtype=np.uint8)
 
 
-def read_fasta(path):
+def read_fasta_numpy(path):
+    "numpy statement of the same parsing rules (tests compare it with the native reader)"
     data = _load_bytes(path)
     n = data.size
     if n == 0:
@@ -45,7 +95,6 @@ def read_fasta(path):
         at_line_start[nz] = data[gt[nz] - 1] == 10
         gt = gt[at_line_start]
     nl = np.flatnonzero(data == 10)
-    # end of each header line
     idx = np.searchsorted(nl, gt)
     hdr_end = np.full(gt.size, n, dtype=np.int64)
     has_nl = idx < nl.size
@@ -55,7 +104,6 @@ def read_fasta(path):
         fields = bytes(data[s + 1:e]).split()
         names.append(fields[0].decode() if fields else "")
     keep = (data != 10) & (data != 13)
-    # drop everything before the first header and the header lines themselves
     if gt.size == 0:
         keep[:] = False
     else:
@@ -68,7 +116,6 @@ def read_fasta(path):
     rec_off = csum[seq_start].astype(np.uint64)
     rec_len = (csum[seq_stop] - csum[seq_start]).astype(np.uint64)
     seq = data[keep]
-    # faidx columns
     fai = []
     for name, s0, s1, ln in zip(names, seq_start.tolist(), seq_stop.tolist(), rec_len.tolist()):
         j = np.searchsorted(nl, s0)

@@ -29,7 +29,7 @@ def write_bf(path, bits, k, hash_num=1):
               f"hash_num = {hash_num}\nk = {k}\n\n[HeaderEnd]\n")
     with open(path, "wb") as fh:
         fh.write(header.encode())
-        fh.write(bits.tobytes())
+        bits.tofile(fh)
 
 
 def read_bf(path):
@@ -44,20 +44,7 @@ def read_bf(path):
     return np.frombuffer(data[end:], dtype=np.uint8).copy(), int(meta["k"])
 
 
-def write_indexlr_tsv(path, recs, h1, rec, pos, k, with_seq=True):
-    """`indexlr --long --pos [--seq]` text: one line per FASTA record."""
-    n_rec = len(recs.names)
-    bounds = np.searchsorted(rec, np.arange(n_rec + 1))
-    with open(path, "w", encoding="utf-8") as out:
-        for r, name in enumerate(recs.names):
-            lo, hi = int(bounds[r]), int(bounds[r + 1])
-            hs, ps = h1[lo:hi].tolist(), pos[lo:hi].tolist()
-            if with_seq:
-                seq = recs.record_bytes(r)
-                toks = [f"{h}:{p}:{seq[p:p + k].tobytes().decode().upper()}" for h, p in zip(hs, ps)]
-            else:
-                toks = [f"{h}:{p}" for h, p in zip(hs, ps)]
-            out.write(f"{name}\t{' '.join(toks)}\n")
+write_indexlr_tsv = fa.write_indexlr_tsv      # native writer (csrc/nts_hostio.cpp)
 
 
 class Stages:
@@ -222,6 +209,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     st.stop()
 
     bf = None
+    bf_writer = None
     if common:
         st.start("make_common_bf")
         ordered = sorted(fastas)                               # src/ntsynt_make_common_bf.cpp:105-107
@@ -254,7 +242,11 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 torch.cuda.synchronize(bf.tensor.device)
         log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
         if rank == 0:
-            write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k)
+            # the filter file is an artefact nobody downstream of us reads: write it behind the next stages
+            import threading
+            bits = backend.bf_bits(bf)
+            bf_writer = threading.Thread(target=write_bf, args=(f"{prefix}.common.bf", bits, k))
+            bf_writer.start()
         st.stop()
 
     st.start("indexlr")
@@ -291,6 +283,10 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         import shutil
         shutil.rmtree(scratch, ignore_errors=True)
     st.stop()
+    if bf_writer is not None:
+        st.start("wait_for_bf_file")
+        bf_writer.join()
+        st.stop()
     if benchmark and rank == 0:
         st.write(f"{prefix}.stage_times.tsv")
     for g in genomes.values():

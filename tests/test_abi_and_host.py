@@ -66,11 +66,45 @@ def test_fasta_reader_matches_oracle_reader(tmp_path):
     from ntsynt_amd import synth
     from oracle import nts_oracle as O
     paths = synth.make_family(str(tmp_path), 2, 300_000, 3, 0.01, seed=4, n_runs=True, soft_mask=True, line_width=70)
+    paths += synth.make_family(str(tmp_path), 1, 100_000, 2, 0.0, seed=5, prefix="one")          # single-line records
     for p in paths:
-        a, b = fa.read_fasta(p), O.read_fasta(p)
-        assert a.names == b.names
-        assert a.rec_len.tolist() == b.rec_len.tolist()
-        assert bytes(a.seq) == b.blob
+        a, b, c = fa.read_fasta(p), O.read_fasta(p), fa.read_fasta_numpy(p)
+        assert a.names == b.names == c.names
+        assert a.rec_len.tolist() == b.rec_len.tolist() == c.rec_len.tolist()
+        assert a.rec_off.tolist() == c.rec_off.tolist()
+        assert bytes(a.seq) == b.blob == bytes(c.seq)
+        assert a.fai_rows == c.fai_rows
+
+
+def test_native_fasta_edge_cases(tmp_path):
+    from ntsynt_amd import fasta as fa
+    cases = [b"", b"no header at all\nACGT\n", b">only\n", b">a\nAC\n\nGT\n>b x y\n", b"junk\n>a\tdesc\r\nAC\r\nG\r\n>b\r\n\r\nT",
+             b">a\nACGT"]
+    for i, raw in enumerate(cases):
+        p = tmp_path / f"c{i}.fa"
+        p.write_bytes(raw)
+        a, c = fa.read_fasta(str(p)), fa.read_fasta_numpy(str(p))
+        assert a.names == c.names, raw
+        assert a.rec_len.tolist() == c.rec_len.tolist(), raw
+        assert bytes(a.seq) == bytes(c.seq), raw
+
+
+def test_native_tsv_writer_matches_oracle_writer(tmp_path):
+    from ntsynt_amd import fasta as fa
+    from ntsynt_amd import synth
+    from oracle import nts_oracle as O
+    from tests.helpers import oracle_flat
+    p = synth.make_family(str(tmp_path), 1, 200_000, 3, 0.0, seed=6, soft_mask=True, n_runs=True, line_width=61)[0]
+    g = O.read_fasta(p)
+    g = O.Genome(g.names + ["empty", "tiny"], [g.record(i) for i in range(3)] + [b"", b"ACGT"])
+    synth.write_fasta(str(tmp_path / "x.fa"), [np.frombuffer(g.record(i), dtype=np.uint8) for i in range(5)], names=g.names)
+    recs = fa.read_fasta(str(tmp_path / "x.fa"))
+    mins = O.minimize(g, 24, 100)
+    for with_seq in (True, False):
+        O.write_indexlr_tsv(str(tmp_path / "o.tsv"), g, mins, 24, with_seq)
+        h1, rec, pos = oracle_flat(mins)
+        fa.write_indexlr_tsv(str(tmp_path / "n.tsv"), recs, h1, rec, pos, 24, with_seq)
+        assert open(tmp_path / "n.tsv").read() == open(tmp_path / "o.tsv").read()
 
 
 def _parse(argv):
