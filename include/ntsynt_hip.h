@@ -105,6 +105,9 @@ int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other);
 int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set);
 int nts_bf_download(nts_ctx* ctx, const nts_bf* bf, uint8_t* host, uint64_t bytes);
 int nts_bf_upload(nts_ctx* ctx, nts_bf* bf, const uint8_t* host, uint64_t bytes);
+/* Microbenchmark: n_probes pseudo-random single-bit reads of the filter with the access shape of the sketch's
+ * probe batches and no hashing -- the empirical ceiling for sector-granular random reads on this GPU. */
+int nts_bench_random_probe(nts_ctx* ctx, const nts_bf* bf, uint64_t n_probes, uint32_t repeats, double* avg_ms, uint64_t* hits);
 /* Non-owning filter over caller-provided HBM (e.g. the buffer a collective runs on): `device_ptr` must be
  * 16-byte aligned and hold `bytes` rounded up to a multiple of 16, the tail zeroed.  nts_bf_free() on a
  * wrapped filter releases only the handle. */

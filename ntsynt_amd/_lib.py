@@ -62,6 +62,7 @@ SYMBOLS = [
     ("nts_bf_popcount", ctypes.c_int, [c_vp, c_vp, c_u64p]),
     ("nts_bf_download", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
     ("nts_bf_upload", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
+    ("nts_bench_random_probe", ctypes.c_int, [c_vp, c_vp, u64, u32, ctypes.POINTER(ctypes.c_double), c_u64p]),
     ("nts_bf_wrap", ctypes.c_int, [c_vp, c_vp, u64, ctypes.POINTER(c_vp)]),
     ("nts_and_raw", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
     ("nts_mx_export", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -678,6 +678,30 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ code
   ascii[i] = c == 0 ? 'A' : c == 1 ? 'C' : c == 2 ? 'G' : c == 3 ? 'T' : 'N';
 }
 
+// ---- microbenchmark: random Bloom probes without any hashing, same access shape as the probe batches of
+// k_hash (8 independent 4-byte loads per lane in flight).  Gives the empirical ceiling for sector-granular
+// random reads that the dense sketch is measured against (DESIGN.md "Rooflines").
+__global__ __launch_bounds__(256) void k_bench_probe(const uint32_t* __restrict__ words, FastMod fm, uint64_t n, uint64_t seed,
+                                                     unsigned long long* __restrict__ sink)
+{
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  for (uint32_t b = 0; b < 32; b += 8) {
+    uint32_t wd[8], bit[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint64_t q = t * 32 + b + u;
+      const uint64_t idx = fm(mix64(q * 0x9E3779B97F4A7C15ULL + seed));
+      wd[u] = q < n ? words[idx >> 5] : 0u;
+      bit[u] = (uint32_t)idx & 31u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (wd[u] >> bit[u]) & 1u;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sink, (unsigned long long)acc);
+}
+
 // compact index -> (record, position in record), and the printed hash h1
 __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j_sorted,
                                                   const uint64_t* __restrict__ key_sorted,
@@ -1437,6 +1461,37 @@ int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set)
   if (e != hipSuccess) return fail(ctx, NTS_EHIP, std::string("popcount: ") + hipGetErrorString(e));
   bf->popcnt = (int64_t)h;
   *bits_set = h;
+  return NTS_OK;
+}
+
+int nts_bench_random_probe(nts_ctx* ctx, const nts_bf* bf, uint64_t n_probes, uint32_t repeats, double* avg_ms, uint64_t* hits)
+{
+  if (!ctx || !bf || !avg_ms || n_probes == 0 || repeats == 0) return fail(ctx, NTS_EINVAL, "nts_bench_random_probe: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  unsigned long long* d = (unsigned long long*)ws_get(ctx, "bench_sink", 8);
+  if (!d) return NTS_ENOMEM;
+  HIP_TRY(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+  const FastMod fm = make_fastmod(bf->bytes * 8);
+  const uint64_t blocks = (n_probes + 8191) / 8192;
+  if (blocks > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "nts_bench_random_probe: too many probes");
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  hipLaunchKernelGGL(k_bench_probe, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, bf->d_words, fm, n_probes, (uint64_t)1, d); // warm-up
+  hipEventRecord(a, ctx->stream);
+  for (uint32_t r = 0; r < repeats; ++r)
+    hipLaunchKernelGGL(k_bench_probe, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, bf->d_words, fm, n_probes, (uint64_t)(r + 2), d);
+  hipEventRecord(b, ctx->stream);
+  unsigned long long h = 0;
+  hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  if (e != hipSuccess) return fail(ctx, NTS_EHIP, std::string("bench: ") + hipGetErrorString(e));
+  *avg_ms = ms / repeats;
+  if (hits) *hits = h;
   return NTS_OK;
 }
 

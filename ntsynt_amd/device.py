@@ -181,6 +181,13 @@ class BloomFilter:
         "occupancy (one hash function), what the reference prints at cpp:132,154,162"
         return self.popcount() / float(self.bytes * 8)
 
+    def bench_random_probe(self, n_probes, repeats=3):
+        "microbenchmark: average ms for n_probes random single-bit reads (no hashing)"
+        ms, hits = ctypes.c_double(), u64()
+        self.ctx.check(self.ctx.lib.nts_bench_random_probe(self.ctx.h, self.h, int(n_probes), int(repeats), ctypes.byref(ms),
+                                                           ctypes.byref(hits)), "nts_bench_random_probe")
+        return ms.value
+
     def device_ptr(self):
         return int(self.ctx.lib.nts_bf_device_ptr(self.h))
 

@@ -1,0 +1,71 @@
+"""Human-scale inputs (BASELINE.json configs[2] shape: 3 Gbp per genome, k=24 w=1000) generated directly in
+HBM, checked through size-independent properties and oracle spot-checks on slices read back from the device."""
+import numpy as np
+import pytest
+
+from oracle import nts_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ntsynt_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def test_three_gbp_genome_sketch_properties_and_slice_parity(ctx):
+    from ntsynt_amd.device import BloomFilter, Genome, bf_size_bytes, sketch
+    k, w, contigs, total = 24, 1000, 24, 3_000_000_000
+    g0 = Genome.synth(ctx, total, contigs, 20240207, 1, 0.005)
+    g1 = Genome.synth(ctx, total, contigs, 20240207, 2, 0.005)
+    assert g0.total_bp == total and g0.valid_kmers(k) == total - contigs * (k - 1)
+    approx, nbytes = bf_size_bytes(total, 0.025)
+    assert approx == O.bf_approx_bytes(total, 0.025) == 14811708827
+    common = BloomFilter(ctx, nbytes, k)
+    common.insert(g0)
+    occ0 = common.get_fpr()
+    assert abs(occ0 - 0.025) < 0.001                # ~ -expm1(-n/m): the sizing rule's target occupancy
+    other = BloomFilter(ctx, nbytes, k)
+    other.insert(g1)
+    common.and_(other)
+    other.free()
+    occ = common.get_fpr()
+    assert 0.015 < occ < occ0
+    res = {}
+    for mode in ("pruned", "dense"):
+        ctx.sketch_mode(mode)
+        res[mode] = sketch(ctx, g1, k, w, common).to_numpy()
+    ctx.sketch_mode("auto")
+    h1, rec, pos = res["pruned"]
+    for a, b in zip(res["pruned"], res["dense"]):       # pruning is exact
+        assert np.array_equal(a, b)
+    assert 0.9 * 2 * total / (w + 1) < h1.size < 1.3 * 2 * total / (w + 1)
+    per = total // contigs
+    for r in (0, 7, contigs - 1):
+        p = pos[rec == r].astype(np.int64)
+        assert (np.diff(p) > 0).all() and p[-1] <= per - k
+    # oracle on slices read back from HBM, with the device-built filter
+    bits = common.to_numpy()
+    n_slice = 1_500_000
+    for r in (0, contigs - 1):
+        seq = g1.download(int(g1.rec_off[r]), n_slice).tobytes()
+        exp = O.minimize(O.Genome(["s"], [seq]), k, w, bits)[0]
+        m = (rec == r) & (pos < n_slice - k - w)
+        n = int(m.sum())
+        assert n > 1000
+        assert np.array_equal(pos[m], exp[1][:n]) and np.array_equal(h1[m], exp[0][:n])
+    # spot-check of the filter itself: every k-mer of a slice of g1 that g0 also holds must be present
+    seq0 = g0.download(int(g0.rec_off[3]), 200_000).tobytes()
+    seq1 = g1.download(int(g1.rec_off[3]), 200_000).tobytes()
+    p0, h0a = O.hash_all(seq0, k)
+    p1, h0b = O.hash_all(seq1, k)
+    shared = np.intersect1d(h0a, h0b)
+    assert shared.size > 100_000
+    for h in shared[::997]:
+        assert O.bf_contains(bits, int(h))
+    for g in (g0, g1):
+        g.free()
+    common.free()
