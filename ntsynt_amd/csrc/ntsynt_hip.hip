@@ -1725,7 +1725,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
 {
   const RunTable& rt = T.rt;
   const uint64_t V = rt.n_valid;
-  const uint64_t n_kt = (V + KEY_TILE - 1) / KEY_TILE;
+  const uint64_t n_kt = (V + SEL_TILE - 1) / SEL_TILE; // tiles of the select kernel (16384 indices each)
   if (n_kt > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
   // threshold: a fraction c/w of all hashes
   const unsigned __int128 full = ((unsigned __int128)1) << 64;
@@ -1986,6 +1986,8 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
     }
     if (p < 0.02 && ctx->sketch_mode == 0) pruned = false;
     prune_c = (uint32_t)std::min(128.0, std::max(8.0, std::ceil(12.0 / std::max(p, 1e-3))));
+    // more than ~10 % of the k-mers as candidates: the select kernel's staging lists would overflow routinely
+    if (ctx->sketch_mode == 0 && (double)prune_c > 0.1 * (double)w) pruned = false;
   }
   ctx->last_c = pruned ? prune_c : 0;
 
