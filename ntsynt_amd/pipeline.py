@@ -184,12 +184,12 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     initialised by the caller) genomes are sharded over the ranks."""
     prefix = prefix or f"ntSynt.k{k}.w{w}"
     world, rank = 1, 0
-    try:
+    dist = None
+    import sys
+    if "torch" in sys.modules:       # a process group can only exist if the caller imported torch (saves ~1 s otherwise)
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             world, rank = dist.get_world_size(), dist.get_rank()
-    except ImportError:
-        dist = None
     own_backend = backend is None
     backend = backend or GpuBackend(device, ctx)
     st = Stages()
