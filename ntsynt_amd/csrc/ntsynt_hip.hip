@@ -34,10 +34,10 @@ namespace {
 constexpr uint64_t PAD = 256;          // invalid bytes before and after the sequence
 constexpr int HASH_THREADS = 256;
 constexpr int HASH_PER_THREAD = 32;    // consecutive k-mers rolled by one lane
-constexpr int WIN_THREADS = 256;
+constexpr int WIN_THREADS = 512;     // 8 waves share one tile: shorter phases, twice the waves per CU for the same LDS
 constexpr uint32_t WIN_TILE = 4096;    // windows per workgroup
 constexpr uint32_t WIN_CHUNK = 16;     // elements scanned sequentially by one lane
-constexpr uint32_t WIN_MAX_W = 12000;  // LDS bound: (WIN_TILE + w) * 12 B + tables <= 160 KiB
+constexpr uint32_t WIN_MAX_W = 12000;  // LDS bound: (WIN_TILE + w) * 8 B + tables <= 160 KiB
 
 std::string g_init_error;
 
@@ -520,35 +520,45 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
     const uint32_t r_lo = (uint32_t)(max(ja, tb) - tb);
     const uint32_t r_hi = (uint32_t)(min(jb, tb + KEY_TILE) - 1 - tb);
     const uint32_t col_lo = r_lo >> 5, col_hi = r_hi >> 5;
-    const uint32_t col = col_lo + threadIdx.x;
+    // 256 columns x 32 rows per key tile; the workgroup's WIN_THREADS / 256 thread groups split the rows
+    constexpr int ROWS = 32 / (WIN_THREADS / 256);
+    const uint32_t col = col_lo + (threadIdx.x & 255u);
+    const uint32_t row0 = (threadIdx.x >> 8) * ROWS;
     if (col <= col_hi) {
       const uint64_t* g = P.keys + tb + col;
       const int64_t e0 = (int64_t)(tb + 32ull * col) - (int64_t)ja; // element index of row 0
-      uint64_t v[32];
+      uint64_t v[ROWS];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) v[i] = g[(uint64_t)i * 256u];
+      for (int i = 0; i < ROWS; ++i) v[i] = g[(uint64_t)(row0 + i) * 256u];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const int64_t e = e0 + i;
+      for (int i = 0; i < ROWS; ++i) {
+        const int64_t e = e0 + row0 + i;
         if (e >= 0 && e < (int64_t)E) s_key[pe((uint32_t)e)] = v[i];
       }
     }
   }
   __syncthreads();
 
+  // rightmost argmin of the span [a, z) (at most 16 keys): the keys are fetched with independent LDS reads
+  // first, so the compare chain does not wait for one LDS round trip per element
+  auto span_argmin = [&](uint32_t a, uint32_t z, uint32_t best, uint64_t kb, bool have) -> uint32_t {
+    uint64_t kv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) kv[q] = (a + q < z) ? s_key[pe(a + q)] : KEY_MAX;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (a + q < z && (!have || kv[q] <= kb)) {
+        kb = kv[q];
+        best = a + q;
+        have = true;
+      }
+    }
+    return best;
+  };
   // ---- chunk argmins + sparse table ------------------------------------------------------------------
   for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += WIN_THREADS) {
     const uint32_t a = ch * c, z = min(a + c, E);
-    uint32_t cur = a;
-    uint64_t kc = s_key[pe(a)];
-    for (uint32_t e = a + 1; e < z; ++e) {
-      const uint64_t ke = s_key[pe(e)];
-      if (ke <= kc) {
-        kc = ke;
-        cur = e;
-      }
-    }
-    s_st[ch] = (uint16_t)cur;
+    s_st[ch] = (uint16_t)span_argmin(a, z, a, 0, false);
   }
   __syncthreads();
   for (uint32_t L = 1; L < P.levels; ++L) {
@@ -564,16 +574,8 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
   auto range_query = [&](uint32_t e) -> uint32_t {
     const uint32_t last = e + w - 1;
     const uint32_t ca = e / c, cb = last / c;
-    uint32_t best = e;
-    uint64_t kb = s_key[pe(e)];
     const uint32_t head_end = (cb > ca) ? (ca + 1) * c : last + 1;
-    for (uint32_t x = e + 1; x < head_end; ++x) {
-      const uint64_t kx = s_key[pe(x)];
-      if (kx <= kb) {
-        kb = kx;
-        best = x;
-      }
-    }
+    uint32_t best = span_argmin(e, head_end, e, 0, false);
     if (cb > ca) {
       if (cb - ca >= 2) {
         const uint32_t len = cb - ca - 1;
@@ -581,15 +583,8 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
         const uint16_t* lvl = s_st + (size_t)L * n_chunks;
         best = better_idx(s_key, best, lvl[ca + 1]);
         best = better_idx(s_key, best, lvl[cb - (1u << L)]);
-        kb = s_key[pe(best)];
       }
-      for (uint32_t x = cb * c; x <= last; ++x) {
-        const uint64_t kx = s_key[pe(x)];
-        if (kx <= kb) {
-          kb = kx;
-          best = x;
-        }
-      }
+      best = span_argmin(cb * c, last + 1, best, s_key[pe(best)], true);
     }
     return best;
   };
@@ -598,21 +593,33 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
   const uint32_t w_lo = threadIdx.x * per;
   const uint32_t w_hi = min(w_lo + per, n_win);
   if (w_lo < w_hi) {
-    auto emit = [&](uint32_t idx) {
-      if (s_key[pe(idx)] != KEY_MAX) s_list[atomicAdd(&s_ctl[0], 1u)] = (uint16_t)idx;
-    };
-    uint32_t e = w_lo > 0 ? w_lo - 1 : 0;
-    uint32_t cur = range_query(e);
-    if (w_lo == 0 && t0 == 0) emit(cur); // very first window of the record
-    for (++e; e < w_hi; ++e) {
-      const uint32_t incoming = e + w - 1;
-      uint32_t nxt;
-      if (cur < e)
+    // keys entering the lane's windows, fetched up front (independent LDS reads)
+    constexpr int MAX_PER = (WIN_TILE + 1 + WIN_THREADS - 1) / WIN_THREADS; // 17
+    uint64_t kin[MAX_PER];
+#pragma unroll
+    for (int i = 0; i < MAX_PER; ++i) {
+      const uint32_t x = w_lo + i;
+      kin[i] = (x < w_hi) ? s_key[pe(x + w - 1)] : KEY_MAX;
+    }
+    uint32_t cur = range_query(w_lo > 0 ? w_lo - 1 : 0);
+    uint64_t kcur = s_key[pe(cur)];
+    if (w_lo == 0 && t0 == 0 && kcur != KEY_MAX) s_list[atomicAdd(&s_ctl[0], 1u)] = (uint16_t)cur; // very first window
+#pragma unroll
+    for (int i = 0; i < MAX_PER; ++i) {
+      const uint32_t e = w_lo + i;
+      if (e == 0 || e >= w_hi) continue; // window 0 of the tile is the first window or the overlap: handled above
+      uint32_t nxt = cur;
+      uint64_t knx = kcur;
+      if (cur < e) {
         nxt = range_query(e);
-      else
-        nxt = (s_key[pe(incoming)] <= s_key[pe(cur)]) ? incoming : cur;
-      if (nxt != cur) emit(nxt); // windows e >= 1 of the tile are all owned (window 0 is the overlap)
+        knx = s_key[pe(nxt)];
+      } else if (kin[i] <= kcur) {
+        nxt = e + w - 1;
+        knx = kin[i];
+      }
+      if (nxt != cur && knx != KEY_MAX) s_list[atomicAdd(&s_ctl[0], 1u)] = (uint16_t)nxt;
       cur = nxt;
+      kcur = knx;
     }
   }
   // ---- flush: one returning atomic per workgroup, on one of N_SEG counters ---------------------------
