@@ -177,7 +177,10 @@ int nts_hash_all(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t** h0, u
  *   e_u/e_v               endpoints of each distinct edge, in the orientation of its first sighting
  *   e_w                   weight
  *   e_first               sequence number of the first sighting in the reference's traversal order
- *                         (assembly, list, index) -- lets the host rebuild ntJoin's edge order exactly
+ *                         (assembly, list, index)
+ * Edges are returned in the order ntJoin's dict of dicts iterates them, `[(s, t) for s in edges for t in
+ * edges[s]]`: sources by the time they first became a source, then by creation time (bin/ntsynt_synteny.py:573
+ * walks the edges in that order, and the order decides which bubbles are removed).
  */
 typedef struct
 {
@@ -210,6 +213,19 @@ void nts_graph_free(nts_graph* g);
  * smaller vertex id.  Paths are listed by ascending first vertex id.  Release with nts_free(). */
 int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, const uint32_t* e_v,
                     uint64_t** off, uint32_t** verts, uint64_t* n_paths);
+
+/* Host-side helper (no GPU work, host threads): one pass over the paths of a round -- path i is
+ * verts[off[i] .. off[i+1]) -- against the per-assembly vertex tables v_rec / v_pos ([a*nv + v]):
+ *   start[i]          index into verts of the first vertex kept: a path whose contig changes in any assembly
+ *                     keeps only its last run (bin/ntsynt_synteny.py:71-77);
+ *   n_up[a*n_paths+i] steps of the kept run along which the position in assembly a rises -- the orientation
+ *                     rule's input (bin/synteny_block.py:48-65);
+ *   over[j]           1 where the distance from verts[j] to verts[j+1] differs between two assemblies by more
+ *                     than bp (indel split, bin/ntsynt_synteny.py:364-409); 0 outside kept runs.
+ * All outputs are caller-allocated (n_paths, n_asm*n_paths, off[n_paths] elements). */
+int nts_path_scan(uint32_t n_asm, uint64_t nv, const int64_t* v_rec, const int64_t* v_pos, uint64_t n_paths,
+                  const uint64_t* off, const int64_t* verts, int64_t bp, uint64_t* start, uint64_t* n_up,
+                  uint8_t* over);
 
 /* ---- host-side I/O (no GPU work) ---------------------------------------------------------------------
  * nts_fasta_read: plain or gzip FASTA, single- or multi-line, LF or CRLF -> concatenated bases + record table +

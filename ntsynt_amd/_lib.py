@@ -79,6 +79,7 @@ SYMBOLS = [
     ("nts_hash_all", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_u64p), c_u64p]),
     ("nts_graph_build", ctypes.c_int, [c_vp, u32, ctypes.POINTER(MxList), ctypes.POINTER(Graph)]),
     ("nts_walk_chains", ctypes.c_int, [u64, u64, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_u32p), c_u64p]),
+    ("nts_path_scan", ctypes.c_int, [u32, u64, c_vp, c_vp, u64, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, c_vp]),
     ("nts_graph_free", None, [ctypes.POINTER(Graph)]),
     ("nts_fasta_read", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Fasta)]),
     ("nts_fasta_free", None, [ctypes.POINTER(Fasta)]),

@@ -1,5 +1,5 @@
-// Host-side I/O of libntsynt_hip.so (no GPU work): FASTA ingest, `.fai` columns, indexlr-format
-// minimizer TSV writer.  Stands in for btllib::SeqReader (src/ntsynt_make_common_bf.cpp:32-36,125-131),
+// Host side of libntsynt_hip.so (no GPU work): FASTA ingest, `.fai` columns, indexlr-format
+// minimizer TSV writer, and the chain walk over the minimizer graph (Ntjoin.find_paths).  Stands in for btllib::SeqReader (src/ntsynt_make_common_bf.cpp:32-36,125-131),
 // `samtools faidx` (bin/ntsynt_run_pipeline.smk:48-53) and indexlr's output stage (smk:81-85).
 #include <zlib.h>
 
@@ -7,7 +7,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <climits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ntsynt_hip.h"
@@ -219,4 +224,201 @@ extern "C" int nts_write_indexlr_tsv(const char* path, const nts_fasta* fa, cons
   flush();
   const bool ok = fclose(f) == 0 && i == n;
   return ok ? NTS_OK : NTS_EINVAL;
+}
+
+// ---- chain walk (row C5) ------------------------------------------------------------------------------------
+namespace {
+
+// host threads worth starting: the cgroup CPU quota when there is one (a container may see far more logical
+// CPUs than it is allowed to use), capped
+unsigned host_threads(unsigned cap)
+{
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[64];
+    long long period = 0;
+    if (fscanf(f, "%63s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+      const long long q = atoll(quota);
+      if (q > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / period));
+    }
+    fclose(f);
+  }
+  return std::max(1u, std::min(n, cap));
+}
+
+template <typename F>
+void parallel_ranges(uint64_t n, unsigned n_threads, F&& body)
+{
+  if (n_threads <= 1 || n < 4096) {
+    body(0u, (uint64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const uint64_t per = (n + n_threads - 1) / n_threads;
+  for (unsigned t = 0; t < n_threads; ++t) {
+    const uint64_t lo = std::min<uint64_t>(n, t * per), hi = std::min<uint64_t>(n, lo + per);
+    pool.emplace_back([&body, t, lo, hi]() { body(t, lo, hi); });
+  }
+  for (auto& th : pool) th.join();
+}
+
+} // namespace
+
+// Components that are simple paths (Ntjoin.find_paths keeps exactly those).  Every step of a walk is a dependent
+// cache miss on a multi-million-vertex graph, so the walks are spread over host threads: each degree-1 vertex walks
+// to the other end of its chain and the walk that started at the smaller vertex id is the one kept, which is the
+// path (and the order, by ascending first vertex) a sequential sweep over the vertex ids yields.
+extern "C" int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, const uint32_t* e_v, uint64_t** off, uint32_t** verts,
+                               uint64_t* n_paths)
+{
+  if (!off || !verts || !n_paths || (ne && (!e_u || !e_v)) || nv > 0xFFFFFFFEULL) return NTS_EINVAL;
+  const unsigned T = host_threads(16);
+  const uint32_t NONE = 0xFFFFFFFFu;
+  auto t_last = std::chrono::steady_clock::now();
+  const bool debug = getenv("NTS_HOST_DEBUG") != nullptr;
+  auto lap = [&](const char* what) {
+    if (!debug) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "nts_walk_chains %s %.3f s (%u threads)\n", what, std::chrono::duration<double>(now - t_last).count(), T);
+    t_last = now;
+  };
+  // degree (saturating at 3) and the first two neighbours of every vertex.  Each thread owns a range of vertex ids
+  // and streams over the whole edge list: the random accesses stay inside a cache-sized slice and need no atomics.
+  std::vector<uint8_t> deg(nv, 0);
+  std::vector<uint32_t> nb(2 * nv, NONE);
+  std::atomic<bool> bad(false);
+  parallel_ranges(nv, T, [&](unsigned, uint64_t lo, uint64_t hi) {
+    auto touch = [&](uint32_t x, uint32_t other) {
+      if (x < lo || x >= hi) return;
+      const uint8_t c = deg[x];
+      if (c < 3) deg[x] = c + 1;
+      if (c < 2) nb[2 * (uint64_t)x + c] = other;
+    };
+    for (uint64_t e = 0; e < ne; ++e) {
+      const uint32_t u = e_u[e], v = e_v[e];
+      if (u >= nv || v >= nv) {
+        bad.store(true);
+        return;
+      }
+      touch(u, v);
+      touch(v, u);
+    }
+  });
+  if (bad.load()) return NTS_EINVAL;
+  lap("neighbour table");
+  auto degree = [&](uint32_t v) { return deg[v]; };
+  // walks; per thread: (first vertex, path) in ascending order of the first vertex
+  std::vector<std::vector<uint64_t>> t_off(T);
+  std::vector<std::vector<uint32_t>> t_out(T);
+  parallel_ranges(nv, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+    std::vector<uint64_t>& o = t_off[t];
+    std::vector<uint32_t>& out = t_out[t];
+    for (uint64_t s = lo; s < hi; ++s) {
+      if (degree((uint32_t)s) != 1) continue;
+      const size_t mark = out.size();
+      uint32_t prev = NONE, cur = (uint32_t)s;
+      bool ok = true;
+      for (uint64_t steps = 0;; ++steps) {
+        out.push_back(cur);
+        if (degree(cur) > 2 || steps > nv) { // a branching vertex poisons the component
+          ok = false;
+          break;
+        }
+        const uint32_t a = nb[2 * (uint64_t)cur], b = nb[2 * (uint64_t)cur + 1];
+        uint32_t nxt = NONE;
+        if (a != NONE && a != prev)
+          nxt = a;
+        else if (b != NONE && b != prev)
+          nxt = b;
+        if (nxt == NONE) break;
+        prev = cur;
+        cur = nxt;
+      }
+      // keep the walk that started at the smaller end
+      if (ok && out.size() - mark >= 2 && degree(out.back()) == 1 && out.back() > (uint32_t)s)
+        o.push_back(out.size());
+      else
+        out.resize(mark);
+    }
+  });
+  lap("walks");
+  uint64_t total_paths = 0, total_verts = 0;
+  for (unsigned t = 0; t < T; ++t) {
+    total_paths += t_off[t].size();
+    total_verts += t_out[t].size();
+  }
+  *n_paths = total_paths;
+  *off = (uint64_t*)malloc((total_paths + 1) * sizeof(uint64_t));
+  *verts = (uint32_t*)malloc(std::max<uint64_t>(total_verts, 1) * sizeof(uint32_t));
+  if (!*off || !*verts) return NTS_ENOMEM;
+  uint64_t po = 0, vo = 0;
+  (*off)[0] = 0;
+  for (unsigned t = 0; t < T; ++t) {
+    for (uint64_t end : t_off[t]) (*off)[++po] = vo + end;
+    if (!t_out[t].empty()) memcpy(*verts + vo, t_out[t].data(), t_out[t].size() * sizeof(uint32_t));
+    vo += t_out[t].size();
+  }
+  lap("concatenate");
+  return NTS_OK;
+}
+
+// ---- per-path scan (rows C6-C8) -------------------------------------------------------------------------------
+// One pass over every path of the round, spread over host threads (each vertex costs a cache miss per table):
+//   * a path whose contig changes in any assembly keeps only its last run (bin/ntsynt_synteny.py:71-77):
+//     start[i] = index into verts of the first vertex kept;
+//   * rising steps per assembly over the kept run, for the orientation rule (bin/synteny_block.py:48-65);
+//   * over[j] = 1 where the gap to the next vertex differs between assemblies by more than `bp`
+//     (bin/ntsynt_synteny.py:364-409), inside kept runs only.
+extern "C" int nts_path_scan(uint32_t n_asm, uint64_t nv, const int64_t* v_rec, const int64_t* v_pos, uint64_t n_paths, const uint64_t* off,
+                             const int64_t* verts, int64_t bp, uint64_t* start, uint64_t* n_up, uint8_t* over)
+{
+  if (n_asm == 0 || (n_paths && (!off || !verts || !v_rec || !v_pos || !start || !n_up || !over))) return NTS_EINVAL;
+  std::atomic<uint64_t> next(0);
+  std::atomic<bool> bad(false);
+  const unsigned T = n_paths ? host_threads(16) : 1;
+  auto work = [&]() {
+    constexpr uint64_t GRAIN = 8;
+    for (;;) {
+      const uint64_t p0 = next.fetch_add(GRAIN);
+      if (p0 >= n_paths) return;
+      for (uint64_t p = p0; p < std::min(n_paths, p0 + GRAIN); ++p) {
+        const uint64_t lo = off[p], hi = off[p + 1];
+        for (uint64_t j = lo; j < hi; ++j) {
+          over[j] = 0;
+          if (verts[j] < 0 || (uint64_t)verts[j] >= nv) {
+            bad.store(true);
+            return;
+          }
+        }
+        uint64_t st = lo;
+        for (uint64_t j = lo; j + 1 < hi; ++j) {
+          const uint64_t x = (uint64_t)verts[j], y = (uint64_t)verts[j + 1];
+          for (uint32_t a = 0; a < n_asm; ++a)
+            if (v_rec[(uint64_t)a * nv + x] != v_rec[(uint64_t)a * nv + y]) st = j + 1;
+        }
+        start[p] = st;
+        for (uint32_t a = 0; a < n_asm; ++a) n_up[(uint64_t)a * n_paths + p] = 0;
+        for (uint64_t j = st; j + 1 < hi; ++j) {
+          const uint64_t x = (uint64_t)verts[j], y = (uint64_t)verts[j + 1];
+          int64_t g_min = INT64_MAX, g_max = INT64_MIN;
+          for (uint32_t a = 0; a < n_asm; ++a) {
+            const int64_t px = v_pos[(uint64_t)a * nv + x], py = v_pos[(uint64_t)a * nv + y];
+            if (py > px) ++n_up[(uint64_t)a * n_paths + p];
+            const int64_t g = px > py ? px - py : py - px;
+            g_min = std::min(g_min, g);
+            g_max = std::max(g_max, g);
+          }
+          over[j] = (g_max - g_min > bp) ? 1 : 0;
+        }
+      }
+    }
+  };
+  if (T <= 1 || n_paths < 64) {
+    work();
+  } else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t) pool.emplace_back(work);
+    for (auto& th : pool) th.join();
+  }
+  return bad.load() ? NTS_EINVAL : NTS_OK;
 }

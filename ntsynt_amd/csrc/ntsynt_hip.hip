@@ -878,15 +878,6 @@ int build_runs(nts_ctx* ctx, const nts_genome* g, uint32_t k, const nts_interval
   return NTS_OK;
 }
 
-template <typename T>
-int dev_upload(nts_ctx* ctx, const std::vector<T>& h, T** d, size_t min_elems = 1)
-{
-  const size_t n = std::max(h.size(), min_elems);
-  HIP_TRY(ctx, hipMalloc((void**)d, n * sizeof(T)));
-  if (!h.empty()) HIP_TRY(ctx, hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-  return NTS_OK;
-}
-
 // host vector -> named scratch buffer (the vector must outlive the stream work; callers sync)
 template <typename T>
 int ws_upload(nts_ctx* ctx, const char* name, const std::vector<T>& h, T** d)
@@ -895,22 +886,6 @@ int ws_upload(nts_ctx* ctx, const char* name, const std::vector<T>& h, T** d)
   if (!*d) return NTS_ENOMEM;
   if (!h.empty()) HIP_TRY(ctx, hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
   return NTS_OK;
-}
-
-struct DevRuns
-{
-  uint64_t* pos = nullptr;
-  uint64_t* vstart = nullptr;
-  uint32_t n = 0;
-};
-
-int upload_runs(nts_ctx* ctx, const RunTable& rt, DevRuns& dr)
-{
-  if (rt.pos.size() > 0xFFFFFFF0ULL) return fail(ctx, NTS_ERANGE, "too many valid runs");
-  dr.n = (uint32_t)rt.pos.size();
-  int rc = ws_upload(ctx, "run_pos", rt.pos, &dr.pos);
-  if (rc) return rc;
-  return ws_upload(ctx, "run_vstart", rt.vstart, &dr.vstart);
 }
 
 } // namespace
@@ -1611,21 +1586,6 @@ int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_
   return NTS_OK;
 }
 
-int run_window_dense_host(nts_ctx* ctx, const uint64_t* d_keys, const std::vector<uint64_t>& vstart, const std::vector<uint64_t>& nv,
-                          uint32_t w, const OutSegs& out, const char* tag)
-{
-  std::vector<uint64_t> tile_start;
-  const uint64_t n_tiles = tiles_of(nv, w, tile_start);
-  if (n_tiles == 0) return NTS_OK;
-  if (nv.size() > 0xFFFFFFF0ULL) return fail(ctx, NTS_ERANGE, "too many uncovered ranges");
-  uint64_t *d_vs = nullptr, *d_nv = nullptr, *d_ts = nullptr;
-  int rc;
-  if ((rc = ws_upload(ctx, "win_vstart", vstart, &d_vs))) return rc;
-  if ((rc = ws_upload(ctx, "win_nv", nv, &d_nv))) return rc;
-  if ((rc = ws_upload(ctx, "win_tiles", tile_start, &d_ts))) return rc;
-  return launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, (uint32_t)nv.size(), n_tiles, w, out, tag);
-}
-
 constexpr uint32_t GAP_PEEK = 1024; // uncovered ranges fetched together with the counters
 
 struct SortedOut
@@ -2232,6 +2192,39 @@ __global__ __launch_bounds__(256) void k_g_edges(const uint64_t* __restrict__ ke
   e_first[e] = s;
 }
 
+// ---- edge order of the reference: `[(s, t) for s in edges for t in edges[s]]` over ntJoin's dict of dicts ----
+// sources by the time they first became a source, then by creation time; both are sequence numbers < 2^32
+__global__ __launch_bounds__(256) void k_g_src_rank(const uint32_t* __restrict__ e_u, const uint64_t* __restrict__ e_first, uint64_t ne,
+                                                    unsigned long long* __restrict__ src_rank)
+{
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ne) atomicMin(&src_rank[e_u[e]], (unsigned long long)e_first[e]);
+}
+
+__global__ __launch_bounds__(256) void k_g_order_keys(const uint32_t* __restrict__ e_u, const uint64_t* __restrict__ e_first, uint64_t ne,
+                                                      const unsigned long long* __restrict__ src_rank, uint64_t* __restrict__ key,
+                                                      uint64_t* __restrict__ idx)
+{
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  key[e] = ((uint64_t)src_rank[e_u[e]] << 32) | e_first[e];
+  idx[e] = e;
+}
+
+__global__ __launch_bounds__(256) void k_g_permute_edges(const uint64_t* __restrict__ idx_sorted, uint64_t ne, const uint32_t* __restrict__ e_u,
+                                                         const uint32_t* __restrict__ e_v, const uint32_t* __restrict__ e_w,
+                                                         const uint64_t* __restrict__ e_first, uint32_t* __restrict__ o_u,
+                                                         uint32_t* __restrict__ o_v, uint32_t* __restrict__ o_w, uint64_t* __restrict__ o_first)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne) return;
+  const uint64_t e = idx_sorted[i];
+  o_u[i] = e_u[e];
+  o_v[i] = e_v[e];
+  o_w[i] = e_w[e];
+  o_first[i] = e_first[e];
+}
+
 template <typename T>
 T* host_copy(nts_ctx* ctx, const T* d, uint64_t n)
 {
@@ -2369,8 +2362,23 @@ extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* l
   G_WS(d_ew, uint32_t*, "g_ew", std::max<uint64_t>(ne, 1) * 4);
   G_WS(d_ef, uint64_t*, "g_ef", std::max<uint64_t>(ne, 1) * 8);
   if (ne) {
+    // the unordered edge arrays reuse buffers the pair stage is done with; d_key/d_seq become sort keys again
+    G_WS(d_eu0, uint32_t*, "g_eu0", ne * 4);
+    G_WS(d_ev0, uint32_t*, "g_ev0", ne * 4);
+    G_WS(d_ew0, uint32_t*, "g_ew0", ne * 4);
+    G_WS(d_ef0, uint64_t*, "g_ef0", ne * 8);
+    G_WS(d_srank, unsigned long long*, "g_srank", nv * 8);
+    size_t tmp_sort3 = 0;
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort3, d_key, d_key2, d_seq, d_seq2, ne, 0, 64, ctx->stream));
+    G_WS(d_tmp3, void*, "g_tmp3", std::max<size_t>(tmp_sort3, 16));
+    const uint32_t eb = (uint32_t)((ne + 255) / 256);
     ScopedTimer t(ctx, "graph_build");
-    hipLaunchKernelGGL(k_g_edges, dim3(mb), dim3(256), 0, ctx->stream, d_key2, d_seq2, d_eh, d_es, m, d_cvid, d_eu, d_ev, d_ew, d_ef);
+    hipLaunchKernelGGL(k_g_edges, dim3(mb), dim3(256), 0, ctx->stream, d_key2, d_seq2, d_eh, d_es, m, d_cvid, d_eu0, d_ev0, d_ew0, d_ef0);
+    HIP_TRY(ctx, hipMemsetAsync(d_srank, 0xFF, nv * 8, ctx->stream));
+    hipLaunchKernelGGL(k_g_src_rank, dim3(eb), dim3(256), 0, ctx->stream, d_eu0, d_ef0, ne, d_srank);
+    hipLaunchKernelGGL(k_g_order_keys, dim3(eb), dim3(256), 0, ctx->stream, d_eu0, d_ef0, ne, d_srank, d_key, d_seq);
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp3, tmp_sort3, d_key, d_key2, d_seq, d_seq2, ne, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_g_permute_edges, dim3(eb), dim3(256), 0, ctx->stream, d_seq2, ne, d_eu0, d_ev0, d_ew0, d_ef0, d_eu, d_ev, d_ew, d_ef);
   }
   HIP_TRY(ctx, hipGetLastError());
   out->v_hash = host_copy(ctx, d_vhash, nv);
@@ -2400,70 +2408,4 @@ extern "C" void nts_graph_free(nts_graph* g)
   free(g->e_w);
   free(g->e_first);
   memset(g, 0, sizeof(*g));
-}
-
-// Host-side: components that are simple paths (Ntjoin.find_paths keeps exactly those).
-extern "C" int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, const uint32_t* e_v, uint64_t** off, uint32_t** verts,
-                               uint64_t* n_paths)
-{
-  if (!off || !verts || !n_paths || (ne && (!e_u || !e_v))) return NTS_EINVAL;
-  std::vector<uint32_t> deg(nv, 0);
-  for (uint64_t e = 0; e < ne; ++e) {
-    if (e_u[e] >= nv || e_v[e] >= nv) return NTS_EINVAL;
-    ++deg[e_u[e]];
-    ++deg[e_v[e]];
-  }
-  // neighbour slots for vertices of degree <= 2; vertices of higher degree poison their component
-  const uint32_t NONE = 0xFFFFFFFFu;
-  std::vector<uint32_t> nb(2 * nv, NONE);
-  for (uint64_t e = 0; e < ne; ++e) {
-    const uint32_t u = e_u[e], v = e_v[e];
-    if (deg[u] <= 2) nb[2 * (uint64_t)u + (nb[2 * (uint64_t)u] == NONE ? 0 : 1)] = v;
-    if (deg[v] <= 2) nb[2 * (uint64_t)v + (nb[2 * (uint64_t)v] == NONE ? 0 : 1)] = u;
-  }
-  std::vector<uint64_t> o(1, 0);
-  std::vector<uint32_t> out;
-  std::vector<uint8_t> seen(nv, 0);
-  for (uint64_t s = 0; s < nv; ++s) {
-    if (deg[s] != 1 || seen[s]) continue;
-    // walk from this end; the path is kept if it ends at another degree-1 vertex through degree-2 ones
-    const size_t mark = out.size();
-    uint32_t prev = NONE, cur = (uint32_t)s;
-    bool ok = true;
-    for (;;) {
-      seen[cur] = 1;
-      out.push_back(cur);
-      uint32_t nxt = NONE;
-      if (deg[cur] > 2) {
-        ok = false;
-        break;
-      }
-      const uint32_t a = nb[2 * (uint64_t)cur], b = nb[2 * (uint64_t)cur + 1];
-      if (a != NONE && a != prev)
-        nxt = a;
-      else if (b != NONE && b != prev)
-        nxt = b;
-      else if (a != NONE && b != NONE && a == prev && b == prev)
-        nxt = NONE; // parallel edges back to prev: not a simple path
-      if (nxt == NONE) break;
-      prev = cur;
-      cur = nxt;
-      if (seen[cur]) { // ran into something already visited: not a simple path
-        ok = false;
-        break;
-      }
-    }
-    if (ok && out.size() - mark >= 2 && deg[out.back()] == 1) {
-      o.push_back(out.size());
-    } else {
-      out.resize(mark);
-    }
-  }
-  *n_paths = o.size() - 1;
-  *off = (uint64_t*)malloc(o.size() * sizeof(uint64_t));
-  *verts = (uint32_t*)malloc(std::max<size_t>(out.size(), 1) * sizeof(uint32_t));
-  if (!*off || !*verts) return NTS_ENOMEM;
-  memcpy(*off, o.data(), o.size() * sizeof(uint64_t));
-  if (!out.empty()) memcpy(*verts, out.data(), out.size() * sizeof(uint32_t));
-  return NTS_OK;
 }

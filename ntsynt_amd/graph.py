@@ -41,7 +41,7 @@ def build_graph_device(ctx, lists, keeps=None, list_ids=None):
         occ_rec=take(g.occ_rec, G * nv, np.int64).reshape(G, nv),
         occ_pos=take(g.occ_pos, G * nv, np.int64).reshape(G, nv),
         e_u=take(g.e_u, ne, np.int64), e_v=take(g.e_v, ne, np.int64), e_w=take(g.e_w, ne, np.int64),
-        e_first=take(g.e_first, ne, np.int64))
+        e_first=take(g.e_first, ne, np.int64), dict_ordered=True)
     ctx.lib.nts_graph_free(ctypes.byref(g))
     return out
 
@@ -62,3 +62,24 @@ def walk_chains(nv, e_u, e_v):
     lib.nts_free(off)
     lib.nts_free(verts)
     return o, v
+
+
+def scan_paths(v_rec, v_pos, off, verts, bp):
+    """Per-path scan (nts_path_scan, host threads): (start int64[n_paths], n_up int64[G, n_paths], over bool[len(verts)])
+    for paths verts[off[i]:off[i+1]] against the [G, nv] vertex tables."""
+    lib = _lib.load()
+    v_rec = np.ascontiguousarray(v_rec, dtype=np.int64)
+    v_pos = np.ascontiguousarray(v_pos, dtype=np.int64)
+    G, nv = v_rec.shape
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    verts = np.ascontiguousarray(verts, dtype=np.int64)
+    n_paths = off.size - 1
+    start = np.zeros(max(n_paths, 1), np.uint64)
+    n_up = np.zeros((G, max(n_paths, 1)), np.uint64)
+    over = np.zeros(max(verts.size, 1), np.uint8)
+    if n_paths > 0:
+        rc = lib.nts_path_scan(G, nv, v_rec.ctypes.data, v_pos.ctypes.data, n_paths, off.ctypes.data, verts.ctypes.data, int(bp),
+                               start.ctypes.data, n_up.ctypes.data, over.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"nts_path_scan failed ({rc})")
+    return start[:n_paths].astype(np.int64), n_up[:, :n_paths].astype(np.int64), over[:verts.size].astype(bool)

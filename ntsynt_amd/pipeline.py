@@ -77,21 +77,28 @@ class GpuBackend:
         self.device = self.ctx.device
 
     # genomes
-    def load_genome(self, path):
+    def read_host(self, path):
+        "host half of load_genome: parse the FASTA (native reader, releases the GIL: safe to run in a thread)"
+        return fa.read_fasta(path)
+
+    def upload_host(self, recs):
+        "device half of load_genome (one context, one stream: called from the main thread only)"
         from .device import Genome
-        recs = fa.read_fasta(path)
         g = Genome(self.ctx, recs.names, recs.seq, recs.rec_off, recs.rec_len)
         g.recs = recs
         return g
 
+    def load_genome(self, path):
+        return self.upload_host(self.read_host(path))
+
     # Bloom filters: the bit array lives in a torch tensor when collectives will run on it
     def bf_new(self, nbytes, k, world=1, ones=False):
         from .device import BloomFilter, wrap_bloom
-        from .dist import padded_len
         if world == 1:
             assert not ones
             return BloomFilter(self.ctx, nbytes, k)
-        import torch
+        import torch                      # multi-GPU only: a single-GPU run never pays for the import
+        from .dist import padded_len
         buf = torch.zeros(padded_len(nbytes, world), dtype=torch.uint8, device=f"cuda:{self.device}")
         if ones:                      # identity of AND, for a rank that owns no genome
             buf[:nbytes] = 0xFF
@@ -153,6 +160,18 @@ class GpuBackend:
             self.ctx.close()
 
 
+def load_genomes(backend, paths, max_threads=8):
+    """FASTA files -> resident genomes.  The files are parsed concurrently on host threads (the reference runs one
+    indexlr/faidx process per file under Snakemake); uploads happen in order on the caller's thread while later
+    files are still being read."""
+    if len(paths) < 2 or not hasattr(backend, "read_host"):
+        return {p: backend.load_genome(p) for p in paths}
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(max_threads, len(paths))) as pool:
+        pending = [pool.submit(backend.read_host, p) for p in paths]
+        return {p: backend.upload_host(f.result()) for p, f in zip(paths, pending)}
+
+
 def _bcast_list(backend, owner, payload):
     """Broadcast one minimizer list (h1 uint64, rec uint32, pos uint64 numpy arrays) from `owner`."""
     import torch
@@ -197,7 +216,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     mine = [p for p in fastas if owner[p] == rank]
 
     st.start("read_fasta+upload")
-    genomes = {p: backend.load_genome(p) for p in mine}
+    genomes = load_genomes(backend, mine)
     for p in mine:
         fa.write_fai(f"{fa.basename(p)}.fai", genomes[p].recs)
     # record names and sizes are needed everywhere (output text, filter sizing)
@@ -209,7 +228,10 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     st.stop()
 
     bf = None
-    bf_writer = None
+    # artefacts nobody downstream of us reads (the filter file, the minimizer TSVs) are written behind the next stages
+    from concurrent.futures import ThreadPoolExecutor
+    writers = ThreadPoolExecutor(max_workers=4)
+    pending_files = []
     if common:
         st.start("make_common_bf")
         ordered = sorted(fastas)                               # src/ntsynt_make_common_bf.cpp:105-107
@@ -242,11 +264,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 torch.cuda.synchronize(bf.tensor.device)
         log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
         if rank == 0:
-            # the filter file is an artefact nobody downstream of us reads: write it behind the next stages
-            import threading
-            bits = backend.bf_bits(bf)
-            bf_writer = threading.Thread(target=write_bf, args=(f"{prefix}.common.bf", bits, k))
-            bf_writer.start()
+            pending_files.append(writers.submit(write_bf, f"{prefix}.common.bf", backend.bf_bits(bf), k))
         st.stop()
 
     st.start("indexlr")
@@ -255,7 +273,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         out = backend.sketch(genomes[p], k, w, bf) if owner[p] == rank else None
         tsv = f"{fa.basename(p)}.k{k}.w{w}.tsv"
         if owner[p] == rank and write_mx_tsv:
-            write_indexlr_tsv(tsv, genomes[p].recs, out[0], out[1], out[2], k, mx_with_seq)
+            pending_files.append(writers.submit(write_indexlr_tsv, tsv, genomes[p].recs, out[0], out[1], out[2], k, mx_with_seq))
         if world > 1:
             out = _bcast_list(backend, owner[p], out)
         tsv_names.append(tsv)
@@ -283,10 +301,11 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         import shutil
         shutil.rmtree(scratch, ignore_errors=True)
     st.stop()
-    if bf_writer is not None:
-        st.start("wait_for_bf_file")
-        bf_writer.join()
-        st.stop()
+    st.start("wait_for_files")
+    for f in pending_files:
+        f.result()                      # re-raises a writer's exception
+    writers.shutdown()
+    st.stop()
     if benchmark and rank == 0:
         st.write(f"{prefix}.stage_times.tsv")
     for g in genomes.values():

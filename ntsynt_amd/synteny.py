@@ -33,6 +33,7 @@ class GraphArrays:
     e_v: np.ndarray
     e_w: np.ndarray                         # [ne] int64
     e_first: np.ndarray                     # [ne] int64 sequence number of first sighting
+    dict_ordered: bool = False              # edges already in the order dict_order() would give (nts_graph_build)
 
 
 def dict_order(e_u, e_first, nv):
@@ -61,10 +62,11 @@ class SyntenyEngine:
     """files: minimizer-TSV names identifying the assemblies (any order; sorted descending like
     S:34); contig_names[a]: record names of assembly a (indexable by record id);
     graph_fn(lists, keep, list_ids) -> GraphArrays with lists[a] = (h1, rec, pos) arrays;
-    sketch_fn(a, masks, w) -> (h1, rec, pos) of assembly a re-sketched with hard masks [(rec, s, e)]."""
+    sketch_fn(a, masks, w) -> (h1, rec, pos) of assembly a re-sketched with hard masks [(rec, s, e)];
+    walk_fn / scan_fn: chain walk and per-path scan (native host helpers nts_walk_chains / nts_path_scan)."""
 
     def __init__(self, files, contig_names, k, w, w_rounds, bp, collinear_merge, z, prefix, graph_fn, sketch_fn,
-                 walk_fn, simplify=True, m=90, n=0, log=None):
+                 walk_fn, simplify=True, m=90, n=0, log=None, scan_fn=None):
         order = sorted(range(len(files)), key=lambda i: files[i], reverse=True)
         self.input_order = order                       # engine index a -> caller's assembly index
         self.files = [files[i] for i in order]
@@ -82,6 +84,9 @@ class SyntenyEngine:
         else:
             raise ValueError("--collinear-merge must be provided with an integer value or string in the form '<num>w'")
         self.graph_fn, self.sketch_fn, self.walk_fn = graph_fn, sketch_fn, walk_fn
+        if scan_fn is None:
+            from .graph import scan_paths as scan_fn       # native host helper (nts_path_scan)
+        self.scan_fn = scan_fn
         self.log = log or (lambda *a: None)
         self.outputs = {}
         self.stats = {"bubbles": 0, "unoriented": 0, "indel_cuts": 0, "small_blocks": 0, "merged": 0, "eroded_edges": 0}
@@ -110,23 +115,25 @@ class SyntenyEngine:
         self.v_alive &= ~dead
         self.e_alive &= ~(dead[self.e_u] | dead[self.e_v])
 
-    def _edge_lookup(self):
-        "sorted (min<<32|max) keys of the live edges -> edge index"
-        idx = np.flatnonzero(self.e_alive)
-        lo = np.minimum(self.e_u[idx], self.e_v[idx])
-        hi = np.maximum(self.e_u[idx], self.e_v[idx])
-        key = (lo << 32) | hi
-        srt = np.argsort(key, kind="stable")
-        return key[srt], idx[srt]
-
-    def _find_edges(self, us, vs, lookup=None):
-        keys, idx = lookup or self._edge_lookup()
-        lo, hi = np.minimum(us, vs), np.maximum(us, vs)
-        q = (lo << 32) | hi
-        p = np.searchsorted(keys, q)
-        p = np.minimum(p, max(keys.size - 1, 0))
-        ok = (keys[p] == q) if keys.size else np.zeros(q.size, bool)
-        return idx[p][ok] if keys.size else np.zeros(0, np.int64)
+    def _find_edges(self, us, vs):
+        """Indices of the live edges {us[i], vs[i]} (queries without an edge are skipped).  Queries are few next to
+        the edge list (indel cuts, edges between re-used vertices), so the edges touching a queried vertex are
+        filtered out in one pass and only those are sorted."""
+        us, vs = np.asarray(us, np.int64), np.asarray(vs, np.int64)
+        if us.size == 0 or self.e_u.size == 0:
+            return np.zeros(0, np.int64), np.zeros(us.size, bool)
+        touched = np.zeros(self.v_hash.size, bool)
+        touched[us] = True
+        idx = np.flatnonzero((touched[self.e_u] | touched[self.e_v]) & self.e_alive)
+        if idx.size == 0:
+            return np.zeros(0, np.int64), np.zeros(us.size, bool)
+        key = (np.minimum(self.e_u[idx], self.e_v[idx]) << 32) | np.maximum(self.e_u[idx], self.e_v[idx])
+        srt = np.argsort(key)
+        key, idx = key[srt], idx[srt]
+        q = (np.minimum(us, vs) << 32) | np.maximum(us, vs)
+        p = np.minimum(np.searchsorted(key, q), key.size - 1)
+        ok = key[p] == q
+        return idx[p][ok], ok
 
     def _add_graph(self, ga, hash_to_vid=None):
         """Append the vertices/edges of one build (rows C2b): new hashes become new vertex ids, edges are
@@ -156,17 +163,22 @@ class SyntenyEngine:
             # S:282-290: positions of every hash that survived the filters are overwritten
             self.v_rec[:, local_to_global] = ga.occ_rec
             self.v_pos[:, local_to_global] = ga.occ_pos
-        order = dict_order(ga.e_u, ga.e_first, ga.v_hash.size)
-        eu, ev, ew = local_to_global[ga.e_u[order]], local_to_global[ga.e_v[order]], ga.e_w[order].astype(np.int64)
+        if ga.dict_ordered:
+            eu, ev, ew = local_to_global[ga.e_u], local_to_global[ga.e_v], ga.e_w.astype(np.int64)
+        else:
+            order = dict_order(ga.e_u, ga.e_first, ga.v_hash.size)
+            eu, ev, ew = local_to_global[ga.e_u[order]], local_to_global[ga.e_v[order]], ga.e_w[order].astype(np.int64)
         if nv0 and eu.size:
-            # an edge that already exists keeps its slot and takes the new weight (never seen in practice)
-            keys, idx = self._edge_lookup()
-            if keys.size:
-                q = (np.minimum(eu, ev) << 32) | np.maximum(eu, ev)
-                p = np.minimum(np.searchsorted(keys, q), keys.size - 1)
-                dup = keys[p] == q
-                self.e_w[idx[p][dup]] = ew[dup]
-                eu, ev, ew = eu[~dup], ev[~dup], ew[~dup]
+            # an edge that already exists keeps its slot and takes the new weight (never seen in practice); only an
+            # edge between two vertices that existed before this build can be one
+            old = np.flatnonzero((eu < nv0) & (ev < nv0))
+            if old.size:
+                hit, ok = self._find_edges(eu[old], ev[old])
+                if hit.size:
+                    dup = np.zeros(eu.size, bool)
+                    dup[old[ok]] = True
+                    self.e_w[hit] = ew[dup]
+                    eu, ev, ew = eu[~dup], ev[~dup], ew[~dup]
         self.e_u = np.concatenate((self.e_u, eu))
         self.e_v = np.concatenate((self.e_v, ev))
         self.e_w = np.concatenate((self.e_w, ew))
@@ -207,80 +219,74 @@ class SyntenyEngine:
             self._delete_vertices(doomed)
 
     # ------------------------------------------------------------------ C5/C6/C7: paths -> blocks
+    # Paths are handled as one concatenated vertex array + offsets; every rule below is a segment operation.
     def _paths(self):
         m = self.e_alive
         off, verts = self.walk_fn(self.v_hash.size, self.e_u[m], self.e_v[m])
-        paths = []
+        if off.size < 2:
+            return verts, off
+        # start at the end with the smaller position in the reference assembly (ntJoin's
+        # determine_source_vertex; two vertices never share a position in one assembly)
         ref_pos = self.v_pos[self.ref]
-        for i in range(off.size - 1):
-            p = verts[off[i]:off[i + 1]]
-            # start at the end with the smaller position in the reference assembly (ntJoin's
-            # determine_source_vertex; two vertices never share a position in one assembly)
-            if ref_pos[p[-1]] < ref_pos[p[0]]:
-                p = p[::-1]
-            paths.append(p)
-        return paths
+        flip = ref_pos[verts[off[1:] - 1]] < ref_pos[verts[off[:-1]]]
+        if flip.any():
+            seg = np.repeat(np.arange(off.size - 1), np.diff(off))
+            j = np.arange(verts.size)
+            verts = verts[np.where(flip[seg], off[seg] + off[seg + 1] - 1 - j, j)]
+        return verts, off
 
-    def _orient(self, pos):
-        if pos.size < 2:
-            return "+"
-        d = np.diff(pos)
-        if (d > 0).all():
-            return "+"
-        if (d < 0).all():
-            return "-"
-        pos_perc = int((d > 0).sum()) / float(pos.size - 1) * 100
+    def _orient_codes(self, n_up, n_d):
+        """synteny_block.py:48-65 from the number of rising steps n_up among the n_d steps of a run:
+        0 '+', 1 '-', 2 '?' (mixed, below the threshold self.m)."""
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pos_perc = n_up / n_d.astype(np.float64) * 100
         neg_perc = 100 - pos_perc
-        if pos_perc >= self.m:
-            return "+"
-        if neg_perc >= self.m:
-            return "-"
-        return "?"
+        code = np.full(n_up.size, 2, np.int8)
+        code[neg_perc >= self.m] = 1
+        code[pos_perc >= self.m] = 0
+        code[n_up == 0] = 1
+        code[n_up == n_d] = 0                                  # includes single-vertex runs
+        return code
 
     def _blocks_of_paths(self, paths):
-        out, drop = [], []
-        for p in paths:
-            if p.size > 1:
-                change = np.zeros(p.size - 1, bool)
-                for a in range(self.G):
-                    r = self.v_rec[a][p]
-                    change |= r[1:] != r[:-1]
-                nz = np.flatnonzero(change)
-                if nz.size:
-                    p = p[nz[-1] + 1:]                     # earlier runs are dropped silently (S:71-77)
-            ori = [self._orient(self.v_pos[a][p]) for a in range(self.G)]
-            if all(o in ("+", "-") for o in ori):
-                out.append(Block(p, [int(self.v_rec[a][p[0]]) for a in range(self.G)], ori))
-            else:
-                drop.append(p)
-        if drop:
-            self._delete_vertices(np.concatenate(drop))
-            self.stats["unoriented"] += len(drop)
-        return out
-
-    # ------------------------------------------------------------------ C8: indel split (S:364-409)
-    def _split_indels(self, blocks):
-        out, cut_u, cut_v = [], [], []
-        for b in blocks:
-            p = b.vids
-            if p.size < 2:
-                out.append(b)
-                continue
-            gaps = np.stack([np.abs(self.v_pos[a][p[:-1]] - self.v_pos[a][p[1:]]) for a in range(self.G)])
-            spread = gaps.max(axis=0) - gaps.min(axis=0)
-            cuts = np.flatnonzero(spread > self.bp)
-            if cuts.size == 0:
-                out.append(b)
-                continue
-            cut_u.append(p[cuts])
+        """C6-C8.  The per-vertex work (contig changes, rising steps, gap spreads) is one threaded pass in
+        nts_path_scan; the rules are applied to its per-path results."""
+        verts, off = paths
+        if off.size < 2:
+            return []
+        start, n_up, over = self.scan_fn(self.v_rec, self.v_pos, off, verts, self.bp)
+        end = off[1:]
+        codes = [self._orient_codes(n_up[a], end - start - 1) for a in range(self.G)]
+        good = np.ones(start.size, bool)
+        for c in codes:
+            good &= c != 2
+        bad = np.flatnonzero(~good)
+        if bad.size:                                           # S:499-505: blocks without an orientation are dropped
+            self._delete_vertices(np.concatenate([verts[start[i]:end[i]] for i in bad.tolist()]))
+            self.stats["unoriented"] += int(bad.size)
+            for i in bad.tolist():
+                over[start[i]:end[i]] = False
+        # C8: indel split (S:364-409): cut between verts[c] and verts[c + 1]
+        cuts = np.flatnonzero(over)
+        if cuts.size:
             self.stats["indel_cuts"] += int(cuts.size)
-            cut_v.append(p[cuts + 1])
-            bounds = np.concatenate(([0], cuts + 1, [p.size]))
-            for lo, hi in zip(bounds[:-1], bounds[1:]):
-                out.append(Block(p[lo:hi], list(b.rec), list(b.ori)))   # contig / orientation inherited (S:383)
-        if cut_u:
-            dead = self._find_edges(np.concatenate(cut_u), np.concatenate(cut_v))
+            dead, _ = self._find_edges(verts[cuts], verts[cuts + 1])
             self.e_alive[dead] = False
+        owner = np.searchsorted(end, cuts, side="right")       # path of each cut
+        out = []
+        sym = "+-?"
+        first = verts[start]
+        recs = [self.v_rec[a][first] for a in range(self.G)]
+        for i in np.flatnonzero(good).tolist():
+            rec = [int(r[i]) for r in recs]
+            ori = [sym[c[i]] for c in codes]
+            lo, hi = np.searchsorted(owner, [i, i + 1]) if cuts.size else (0, 0)
+            if lo == hi:
+                out.append(Block(verts[start[i]:end[i]], rec, ori))
+                continue
+            bounds = [int(start[i])] + (cuts[lo:hi] + 1).tolist() + [int(end[i])]
+            for x, y in zip(bounds[:-1], bounds[1:]):
+                out.append(Block(verts[x:y], list(rec), list(ori)))   # contig / orientation inherited (S:383)
         return out
 
     # ------------------------------------------------------------------ C9 (S:411-426)
@@ -507,9 +513,7 @@ class SyntenyEngine:
 
     # ------------------------------------------------------------------ drivers (S:476-530, S:593-647)
     def _round_blocks(self):
-        blocks = self._blocks_of_paths(self._paths())
-        blocks = self._split_indels(blocks)
-        return self._drop_small(blocks, 4)
+        return self._drop_small(self._blocks_of_paths(self._paths()), 4)
 
     def run(self, initial_lists):
         """initial_lists[i] = (h1, rec, pos) of assembly i in the caller's order."""

@@ -99,3 +99,102 @@ def test_walk_chains_shapes():
     off, verts = walk_chains(14, eu, ev)
     paths = [verts[off[i]:off[i + 1]].tolist() for i in range(off.size - 1)]
     assert paths == [[0, 1, 2], [3, 4]]
+
+
+def test_walk_chains_threaded_matches_sequential_sweep():
+    """Large enough for nts_walk_chains to spread the walks over host threads: random chains (shuffled vertex
+    ids), cycles and branching components; expected = the sequential sweep over ascending vertex ids."""
+    rng = np.random.default_rng(17)
+    nv = 60000
+    perm = rng.permutation(nv)
+    eu, ev, expect = [], [], []
+    at = 0
+    while at < nv - 40:
+        ln = int(rng.integers(1, 30))
+        vs = perm[at:at + ln]
+        at += ln
+        kind = rng.random()
+        for a, b in zip(vs[:-1], vs[1:]):
+            eu.append(a if rng.random() < 0.5 else b)
+            ev.append(b if eu[-1] == a else a)
+        if ln >= 3 and kind < 0.1:                      # close a cycle
+            eu.append(vs[-1])
+            ev.append(vs[0])
+        elif ln >= 3 and kind < 0.2:                    # branch: a third neighbour for a middle vertex
+            eu.append(vs[ln // 2])
+            ev.append(perm[at])
+            at += 1
+        elif ln >= 2:
+            p = vs.tolist()
+            expect.append(p if p[0] < p[-1] else p[::-1])
+    order = rng.permutation(len(eu))
+    eu, ev = np.array(eu, np.int64)[order], np.array(ev, np.int64)[order]
+    off, verts = walk_chains(nv, eu, ev)
+    paths = [verts[off[i]:off[i + 1]].tolist() for i in range(off.size - 1)]
+    assert paths == sorted(expect, key=lambda p: p[0]) and len(paths) > 2000
+
+
+def test_orientation_rule_matches_oracle_blocks():
+    """synteny_block.py:48-65 on mixed position sequences (the synthetic families never produce them): segment-wise
+    _orient_codes against the oracle's SynBlock.orient, with lengths and mixes chosen around the 90 % threshold."""
+    rng = np.random.default_rng(23)
+    eng = SyntenyEngine(["a.k24.w100.tsv", "b.k24.w100.tsv"], [["c"], ["c"]], 24, 100, [10], 500, 1000, 100, "p",
+                        None, None, None)
+    seqs = []
+    for n in list(range(1, 25)) + [40, 41, 50, 100, 101]:
+        for frac_down in (0.0, 0.05, 0.09, 0.1, 0.11, 0.5, 0.89, 0.9, 0.91, 1.0):
+            steps = np.where(rng.random(max(n - 1, 0)) < frac_down, -1, 1) * rng.integers(1, 50, max(n - 1, 0))
+            seqs.append(np.concatenate(([10_000], 10_000 + np.cumsum(steps))).astype(np.int64))
+        if n >= 11:                                        # exactly 10 % and just over it
+            for n_down in (max(1, (n - 1) // 10), (n - 1) // 10 + 1, n - 1 - (n - 1) // 10, n - 2 - (n - 1) // 10):
+                sign = np.ones(n - 1, np.int64)
+                sign[rng.permutation(n - 1)[:max(0, n_down)]] = -1
+                seqs.append(np.concatenate(([10_000], 10_000 + np.cumsum(sign * 7))).astype(np.int64))
+    pos = np.concatenate(seqs)
+    end = np.cumsum([s.size for s in seqs])
+    start = end - np.array([s.size for s in seqs])
+    # rising steps per sequence, then the rule
+    rise = np.concatenate(([0], np.cumsum(pos[1:] > pos[:-1])))
+    n_up = rise[end - 1] - rise[start]
+    got = ["+-?"[c] for c in eng._orient_codes(n_up, end - start - 1)]
+    want = []
+    for s in seqs:
+        blk = SO.SynBlock(24, 90, ["x"])
+        blk.asm["x"].minimizers = [("h", int(p)) for p in s]
+        blk.orient()
+        want.append(blk.asm["x"].ori)
+    assert got == want and {"+", "-", "?"} <= set(want)
+
+
+def test_path_scan_matches_numpy_statement():
+    "nts_path_scan (threaded) against the same three rules written with numpy, on random paths over random tables"
+    from ntsynt_amd.graph import scan_paths
+    rng = np.random.default_rng(31)
+    G, nv, n_paths = 3, 50000, 900
+    v_rec = rng.integers(0, 3, (G, nv)).astype(np.int64)
+    v_rec[:, : nv // 2] = 1                                    # long stretches without contig changes
+    v_pos = rng.integers(0, 10**9, (G, nv)).astype(np.int64)
+    base = np.sort(rng.integers(0, 10**9, nv))
+    for a in range(G):                                         # mostly collinear positions with a few large jumps
+        v_pos[a] = base + rng.integers(0, 50, nv) + (rng.random(nv) < 0.01) * 10**6
+    lens = rng.integers(1, 120, n_paths)
+    off = np.concatenate(([0], np.cumsum(lens)))
+    verts = np.concatenate([np.sort(rng.choice(nv // 2 + (nv // 2) * (i % 7 == 0), ln, replace=False)) for i, ln in enumerate(lens)])
+    for bp in (100, 10**5):
+        start, n_up, over = scan_paths(v_rec, v_pos, off, verts, bp)
+        for i in range(n_paths):
+            p = verts[off[i]:off[i + 1]]
+            change = np.zeros(max(p.size - 1, 0), bool)
+            for a in range(G):
+                change |= v_rec[a][p[1:]] != v_rec[a][p[:-1]]
+            nz = np.flatnonzero(change)
+            st = int(nz[-1]) + 1 if nz.size else 0
+            assert start[i] == off[i] + st
+            q = p[st:]
+            gaps = np.stack([np.abs(np.diff(v_pos[a][q])) for a in range(G)])
+            want_over = np.zeros(p.size, bool)
+            want_over[st:p.size - 1] = (gaps.max(axis=0) - gaps.min(axis=0)) > bp
+            assert np.array_equal(over[off[i]:off[i + 1]], want_over)
+            for a in range(G):
+                assert n_up[a, i] == int((np.diff(v_pos[a][q]) > 0).sum())
+    assert over.any() and (start > off[:-1]).any()

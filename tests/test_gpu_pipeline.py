@@ -76,8 +76,12 @@ def test_graph_build_device_vs_numpy(tmp_path):
         h = build_graph_numpy(lists, kp, li)
         assert np.array_equal(d.v_hash, h.v_hash) and d.v_hash.size > 1000
         assert np.array_equal(d.occ_rec, h.occ_rec) and np.array_equal(d.occ_pos, h.occ_pos)
+        # the device hands the edges over in ntJoin's dict-of-dicts order; the numpy twin in key order
+        from ntsynt_amd.synteny import dict_order
+        order = dict_order(h.e_u, h.e_first, h.v_hash.size)
+        assert d.dict_ordered and not h.dict_ordered
         for f in ("e_u", "e_v", "e_w", "e_first"):
-            assert np.array_equal(getattr(d, f), getattr(h, f)), f
+            assert np.array_equal(getattr(d, f), getattr(h, f)[order]), f
     ctx.close()
 
 
