@@ -93,7 +93,9 @@ int nts_genome_valid_kmers(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64
  * nts_bf_and        : acc &= other -- with one hash function the cascade equals the AND of the
  *                     per-genome filters; this is the form the multi-GPU path reduces
  * nts_bf_popcount   : numerator of bf->get_fpr(), cpp:132,154,162
- * nts_bf_download / nts_bf_upload : raw bit array for bf->save()/load (cpp:164; smk:76) */
+ * nts_bf_download / nts_bf_upload : raw bit array for bf->save()/load (cpp:164; smk:76).  The download sees
+ *                     everything queued before the call and runs on the context's copy stream: it is the one
+ *                     call that may be issued from a second host thread while the first keeps sketching. */
 int nts_bf_create(nts_ctx* ctx, uint64_t bytes, nts_bf** out);
 void nts_bf_free(nts_ctx* ctx, nts_bf* bf);
 uint64_t nts_bf_bytes(const nts_bf* bf);

@@ -1,6 +1,10 @@
 // Host side of libntsynt_hip.so (no GPU work): FASTA ingest, `.fai` columns, indexlr-format
 // minimizer TSV writer, and the chain walk over the minimizer graph (Ntjoin.find_paths).  Stands in for btllib::SeqReader (src/ntsynt_make_common_bf.cpp:32-36,125-131),
 // `samtools faidx` (bin/ntsynt_run_pipeline.smk:48-53) and indexlr's output stage (smk:81-85).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstdint>
@@ -66,6 +70,63 @@ bool slurp(const char* path, std::vector<uint8_t>& data)
   return true;
 }
 
+// Bytes of an input file: plain files are mapped (no read() copy, no second buffer to fault in), gzip files are
+// inflated into memory.
+struct FileBytes
+{
+  const uint8_t* p = nullptr;
+  size_t n = 0;
+  void* map = nullptr;
+  size_t map_len = 0;
+  std::vector<uint8_t> owned;
+  bool open(const char* path)
+  {
+    if (!ends_with(path, ".gz")) {
+      const int fd = ::open(path, O_RDONLY);
+      if (fd < 0) return false;
+      struct stat st;
+      if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        ::close(fd);
+        return slurp(path, owned) && ((p = owned.data()), (n = owned.size()), true);
+      }
+      if (st.st_size == 0) {
+        ::close(fd);
+        return true;
+      }
+      void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      ::close(fd);
+      if (m == MAP_FAILED) return slurp(path, owned) && ((p = owned.data()), (n = owned.size()), true);
+      madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+      madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+      map = m;
+      map_len = (size_t)st.st_size;
+      p = (const uint8_t*)m;
+      n = map_len;
+      return true;
+    }
+    if (!slurp(path, owned)) return false;
+    p = owned.data();
+    n = owned.size();
+    return true;
+  }
+  ~FileBytes()
+  {
+    if (map) munmap(map, map_len);
+  }
+};
+
+// Large host buffers (a genome's bases): 2 MiB-aligned and advised to use huge pages, so that first touch costs
+// thousands of page faults rather than millions.  Released with free().
+void* big_alloc(size_t bytes)
+{
+  constexpr size_t HUGE = (size_t)1 << 21;
+  if (bytes < 8 * HUGE) return malloc(std::max<size_t>(bytes, 1));
+  void* p = nullptr;
+  if (posix_memalign(&p, HUGE, (bytes + HUGE - 1) / HUGE * HUGE) != 0) return nullptr;
+  madvise(p, (bytes + HUGE - 1) / HUGE * HUGE, MADV_HUGEPAGE);
+  return p;
+}
+
 template <typename T>
 T* dup_vec(const std::vector<T>& v)
 {
@@ -92,10 +153,11 @@ extern "C" int nts_fasta_read(const char* path, nts_fasta* out)
 {
   if (!path || !out) return NTS_EINVAL;
   memset(out, 0, sizeof(*out));
-  std::vector<uint8_t> data;
-  if (!slurp(path, data)) return NTS_EINVAL;
-  const size_t n = data.size();
-  uint8_t* seq = (uint8_t*)malloc(std::max<size_t>(n, 1));
+  FileBytes file;
+  if (!file.open(path)) return NTS_EINVAL;
+  const uint8_t* const data = file.p;
+  const size_t n = file.n;
+  uint8_t* seq = (uint8_t*)big_alloc(n);
   if (!seq) return NTS_ENOMEM;
   std::vector<uint64_t> rec_off, rec_len, fai_off;
   std::vector<uint32_t> fai_bases, fai_width;
@@ -105,14 +167,14 @@ extern "C" int nts_fasta_read(const char* path, nts_fasta* out)
   bool in_record = false;
   bool first_line = false;
   while (i < n) {
-    const uint8_t* nl = (const uint8_t*)memchr(data.data() + i, '\n', n - i);
-    const size_t line_end = nl ? (size_t)(nl - data.data()) : n; // exclusive, without the newline
+    const uint8_t* nl = (const uint8_t*)memchr(data + i, '\n', n - i);
+    const size_t line_end = nl ? (size_t)(nl - data) : n; // exclusive, without the newline
     if (data[i] == '>') {
       if (in_record) rec_len.back() = w - rec_off.back();
       // record id = header up to the first whitespace
       size_t s = i + 1, e = s;
       while (e < line_end && data[e] != ' ' && data[e] != '\t' && data[e] != '\r' && data[e] != '\v' && data[e] != '\f') ++e;
-      names.append((const char*)data.data() + s, e - s);
+      names.append((const char*)data + s, e - s);
       names.push_back('\0');
       rec_off.push_back(w);
       rec_len.push_back(0);
@@ -133,8 +195,8 @@ extern "C" int nts_fasta_read(const char* path, nts_fasta* out)
         first_line = false;
       }
       // sequence bytes: everything except CR (LF is already excluded)
-      if (memchr(data.data() + i, '\r', len) == nullptr) {
-        memcpy(seq + w, data.data() + i, len);
+      if (memchr(data + i, '\r', len) == nullptr) {
+        memcpy(seq + w, data + i, len);
         w += len;
       } else {
         for (size_t q = i; q < line_end; ++q)
@@ -307,45 +369,69 @@ extern "C" int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, co
   if (bad.load()) return NTS_EINVAL;
   lap("neighbour table");
   auto degree = [&](uint32_t v) { return deg[v]; };
-  // walks; per thread: (first vertex, path) in ascending order of the first vertex
-  std::vector<std::vector<uint64_t>> t_off(T);
+  // walks, handed out dynamically: in refinement rounds almost every chain end is a freshly numbered vertex, so
+  // splitting the vertex-id range evenly would leave one thread with all the work
+  std::vector<uint32_t> ends;
+  for (uint64_t v = 0; v < nv; ++v)
+    if (deg[v] == 1) ends.push_back((uint32_t)v);
+  struct Kept
+  {
+    uint32_t thread;
+    uint64_t begin, len;
+  };
+  std::vector<Kept> kept(ends.size(), Kept{ 0, 0, 0 });
   std::vector<std::vector<uint32_t>> t_out(T);
-  parallel_ranges(nv, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
-    std::vector<uint64_t>& o = t_off[t];
+  std::vector<uint64_t> t_steps(T, 0);
+  std::atomic<uint64_t> next_end(0);
+  auto walker = [&](unsigned t) {
     std::vector<uint32_t>& out = t_out[t];
-    for (uint64_t s = lo; s < hi; ++s) {
-      if (degree((uint32_t)s) != 1) continue;
-      const size_t mark = out.size();
-      uint32_t prev = NONE, cur = (uint32_t)s;
-      bool ok = true;
-      for (uint64_t steps = 0;; ++steps) {
-        out.push_back(cur);
-        if (degree(cur) > 2 || steps > nv) { // a branching vertex poisons the component
-          ok = false;
-          break;
+    constexpr uint64_t GRAIN = 4;
+    for (;;) {
+      const uint64_t i0 = next_end.fetch_add(GRAIN);
+      if (i0 >= ends.size()) return;
+      for (uint64_t i = i0; i < std::min<uint64_t>(ends.size(), i0 + GRAIN); ++i) {
+        const uint32_t s = ends[i];
+        const size_t mark = out.size();
+        uint32_t prev = NONE, cur = s;
+        bool ok = true;
+        for (uint64_t steps = 0;; ++steps) {
+          ++t_steps[t];
+          out.push_back(cur);
+          if (degree(cur) > 2 || steps > nv) { // a branching vertex poisons the component
+            ok = false;
+            break;
+          }
+          const uint32_t a = nb[2 * (uint64_t)cur], b = nb[2 * (uint64_t)cur + 1];
+          uint32_t nxt = NONE;
+          if (a != NONE && a != prev)
+            nxt = a;
+          else if (b != NONE && b != prev)
+            nxt = b;
+          if (nxt == NONE) break;
+          prev = cur;
+          cur = nxt;
         }
-        const uint32_t a = nb[2 * (uint64_t)cur], b = nb[2 * (uint64_t)cur + 1];
-        uint32_t nxt = NONE;
-        if (a != NONE && a != prev)
-          nxt = a;
-        else if (b != NONE && b != prev)
-          nxt = b;
-        if (nxt == NONE) break;
-        prev = cur;
-        cur = nxt;
+        // keep the walk that started at the smaller end
+        if (ok && out.size() - mark >= 2 && degree(out.back()) == 1 && out.back() > s)
+          kept[i] = Kept{ t, mark, out.size() - mark };
+        else
+          out.resize(mark);
       }
-      // keep the walk that started at the smaller end
-      if (ok && out.size() - mark >= 2 && degree(out.back()) == 1 && out.back() > (uint32_t)s)
-        o.push_back(out.size());
-      else
-        out.resize(mark);
     }
-  });
+  };
+  if (T <= 1 || ends.size() < 64) {
+    walker(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t) pool.emplace_back(walker, t);
+    for (auto& th : pool) th.join();
+  }
   lap("walks");
   uint64_t total_paths = 0, total_verts = 0;
-  for (unsigned t = 0; t < T; ++t) {
-    total_paths += t_off[t].size();
-    total_verts += t_out[t].size();
+  for (const Kept& k : kept) {
+    if (!k.len) continue;
+    ++total_paths;
+    total_verts += k.len;
   }
   *n_paths = total_paths;
   *off = (uint64_t*)malloc((total_paths + 1) * sizeof(uint64_t));
@@ -353,12 +439,22 @@ extern "C" int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, co
   if (!*off || !*verts) return NTS_ENOMEM;
   uint64_t po = 0, vo = 0;
   (*off)[0] = 0;
-  for (unsigned t = 0; t < T; ++t) {
-    for (uint64_t end : t_off[t]) (*off)[++po] = vo + end;
-    if (!t_out[t].empty()) memcpy(*verts + vo, t_out[t].data(), t_out[t].size() * sizeof(uint32_t));
-    vo += t_out[t].size();
+  for (const Kept& k : kept) { // ascending first vertex
+    if (!k.len) continue;
+    memcpy(*verts + vo, t_out[k.thread].data() + k.begin, k.len * sizeof(uint32_t));
+    vo += k.len;
+    (*off)[++po] = vo;
   }
   lap("concatenate");
+  if (debug) {
+    uint64_t longest = 0, steps = 0;
+    for (uint64_t i = 0; i < total_paths; ++i) longest = std::max(longest, (*off)[i + 1] - (*off)[i]);
+    for (unsigned t = 0; t < T; ++t) steps += t_steps[t];
+    for (unsigned t = 0; t < T; ++t) fprintf(stderr, "  thread %u: %llu steps\n", t, (unsigned long long)t_steps[t]);
+    fprintf(stderr, "nts_walk_chains nv=%llu ne=%llu paths=%llu vertices on paths=%llu longest=%llu steps walked=%llu\n", (unsigned long long)nv,
+            (unsigned long long)ne, (unsigned long long)total_paths, (unsigned long long)total_verts, (unsigned long long)longest,
+            (unsigned long long)steps);
+  }
   return NTS_OK;
 }
 

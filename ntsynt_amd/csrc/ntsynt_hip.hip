@@ -53,6 +53,7 @@ struct nts_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr; // bulk device -> host copies that may run behind later kernels (nts_bf_download)
   std::string err;
   bool profiling = false;
   std::map<std::string, Timing> timings;
@@ -1040,7 +1041,8 @@ int nts_init(int device, nts_ctx** out)
   }
   nts_ctx* ctx = new nts_ctx();
   ctx->device = device;
-  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess) {
     g_init_error = std::string("hipSetDevice/hipStreamCreate: ") + hipGetErrorString(e);
     delete ctx;
     return NTS_EHIP;
@@ -1057,6 +1059,7 @@ void nts_destroy(nts_ctx* ctx)
   hipStreamSynchronize(ctx->stream);
   ws_release(ctx);
   for (auto& p : ctx->mx_pool) hipFree(p.first);
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1481,8 +1484,16 @@ int nts_bf_download(nts_ctx* ctx, const nts_bf* bf, uint8_t* host, uint64_t byte
 {
   if (!ctx || !bf || !host || bytes != bf->bytes) return fail(ctx, NTS_EINVAL, "nts_bf_download: size mismatch");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemcpyAsync(host, bf->d_words, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // The copy runs on its own stream, after everything queued on the compute stream so far: a caller may run it
+  // on a second host thread (the pipeline writes the filter file behind the sketches) without stalling later kernels.
+  hipEvent_t ready;
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ready, ctx->stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ready, 0);
+  if (e == hipSuccess) e = hipMemcpyAsync(host, bf->d_words, bytes, hipMemcpyDeviceToHost, ctx->copy_stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+  hipEventDestroy(ready);
+  HIP_TRY(ctx, e);
   return NTS_OK;
 }
 

@@ -263,8 +263,6 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 import torch
                 torch.cuda.synchronize(bf.tensor.device)
         log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
-        if rank == 0:
-            pending_files.append(writers.submit(write_bf, f"{prefix}.common.bf", backend.bf_bits(bf), k))
         st.stop()
 
     st.start("indexlr")
@@ -279,6 +277,10 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         tsv_names.append(tsv)
         initial.append(out)
     st.stop()
+    if bf is not None and rank == 0:
+        # filter file: device -> host copy on the library's copy stream + write, on a writer thread, started once the
+        # whole-genome sketches are out of the way (their small read-backs would queue behind the bulk copy)
+        pending_files.append(writers.submit(lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k)))
 
     st.start("ntsynt_synteny")
 

@@ -101,6 +101,8 @@ class SyntenyEngine:
         self.e_v = np.zeros(0, np.int64)
         self.e_w = np.zeros(0, np.int64)
         self.e_alive = np.zeros(0, bool)
+        self._hs = np.zeros(0, np.uint64)                  # live-vertex index: hashes ascending, and their ids
+        self._hid = np.zeros(0, np.int64)
 
     # ------------------------------------------------------------------ graph bookkeeping
     def _degrees(self):
@@ -114,6 +116,14 @@ class SyntenyEngine:
         dead[np.asarray(vids, dtype=np.int64)] = True
         self.v_alive &= ~dead
         self.e_alive &= ~(dead[self.e_u] | dead[self.e_v])
+
+    def _live_index(self):
+        """(hashes ascending, vertex ids) of the live vertices.  The index is kept across rounds: deleted vertices
+        drop out here, new ones are merged in by _add_graph; two live vertices never share a hash."""
+        keep = self.v_alive[self._hid]
+        if not keep.all():
+            self._hs, self._hid = self._hs[keep], self._hid[keep]
+        return self._hs, self._hid
 
     def _find_edges(self, us, vs):
         """Indices of the live edges {us[i], vs[i]} (queries without an edge are skipped).  Queries are few next to
@@ -141,19 +151,24 @@ class SyntenyEngine:
         nv0 = self.v_hash.size
         if nv0 == 0:
             local_to_global = np.arange(ga.v_hash.size, dtype=np.int64)
-            self.v_hash = ga.v_hash.copy()
+            # the first build's arrays become the engine's state (graph_fn results are not used by anyone else)
+            self.v_hash = np.ascontiguousarray(ga.v_hash, dtype=np.uint64)
             self.v_alive = np.ones(ga.v_hash.size, bool)
-            self.v_rec = ga.occ_rec.astype(np.int64).copy()
-            self.v_pos = ga.occ_pos.astype(np.int64).copy()
+            self.v_rec = np.ascontiguousarray(ga.occ_rec, dtype=np.int64)
+            self.v_pos = np.ascontiguousarray(ga.occ_pos, dtype=np.int64)
+            order = np.arange(ga.v_hash.size, dtype=np.int64)
+            if ga.v_hash.size > 1 and not (ga.v_hash[1:] > ga.v_hash[:-1]).all():
+                order = np.argsort(ga.v_hash, kind="stable")
+            self._hs, self._hid = self.v_hash[order], order
         else:
             # per hash, the live vertex carrying it (a deleted vertex may share its hash with a re-created one)
-            srt = np.lexsort((self.v_alive, self.v_hash))
-            sh = self.v_hash[srt]
-            last = np.flatnonzero(np.r_[sh[1:] != sh[:-1], True])
-            uh, uid = sh[last], srt[last]
-            p = np.minimum(np.searchsorted(uh, ga.v_hash), uh.size - 1)
-            hit = (uh[p] == ga.v_hash) & self.v_alive[uid[p]]
-            local_to_global = np.where(hit, uid[p], -1)
+            hs, hid = self._live_index()
+            if hs.size:
+                p = np.minimum(np.searchsorted(hs, ga.v_hash), hs.size - 1)
+                hit = hs[p] == ga.v_hash
+                local_to_global = np.where(hit, hid[p], -1)
+            else:
+                local_to_global = np.full(ga.v_hash.size, -1, np.int64)
             new = np.flatnonzero(local_to_global < 0)
             local_to_global[new] = nv0 + np.arange(new.size)
             self.v_hash = np.concatenate((self.v_hash, ga.v_hash[new]))
@@ -163,6 +178,15 @@ class SyntenyEngine:
             # S:282-290: positions of every hash that survived the filters are overwritten
             self.v_rec[:, local_to_global] = ga.occ_rec
             self.v_pos[:, local_to_global] = ga.occ_pos
+            # the new vertices join the index (ga.v_hash is ascending, so is its subset)
+            nh = ga.v_hash[new]
+            if nh.size > 1 and not (nh[1:] > nh[:-1]).all():
+                o = np.argsort(nh, kind="stable")
+                nh, new_ids = nh[o], (nv0 + np.arange(new.size))[o]
+            else:
+                new_ids = nv0 + np.arange(new.size)
+            at = np.searchsorted(hs, nh)
+            self._hs, self._hid = np.insert(hs, at, nh), np.insert(hid, at, new_ids)
         if ga.dict_ordered:
             eu, ev, ew = local_to_global[ga.e_u], local_to_global[ga.e_v], ga.e_w.astype(np.int64)
         else:
@@ -408,8 +432,8 @@ class SyntenyEngine:
                 hi = max(int(self.v_pos[a][b.vids[0]]), int(self.v_pos[a][b.vids[-1]]))
                 if hi - lo >= 2:
                     spans[a].setdefault(b.rec[a], []).append((lo + 1, hi))
-        uh, inv = np.unique(self.v_hash, return_inverse=True)
-        internal_h = np.bincount(inv, weights=internal & self.v_alive, minlength=uh.size) > 0
+        hs, hid = self._live_index()
+        uh = hs[internal[hid]]                             # hashes of the live internal vertices, ascending
         lists, keeps, list_ids = [], [], []
         for a in range(self.G):
             h1, rec, pos = self.sketch_fn(self.input_order[a], masks[a], new_w)
@@ -422,7 +446,7 @@ class SyntenyEngine:
             # is the hash an internal minimizer of a block?  (S:274: `mx not in black_list`)
             if uh.size:
                 p = np.minimum(np.searchsorted(uh, h1), uh.size - 1)
-                is_internal = (uh[p] == h1) & internal_h[p]
+                is_internal = uh[p] == h1
             else:
                 is_internal = np.zeros(h1.size, bool)
             inside = np.zeros(h1.size, bool)
