@@ -8,7 +8,10 @@ rows B1-B3) over the rank's batch of synthetic genomes, which are resident in HB
 the common Bloom filter) before the timed region starts; for N>1 the step ends with the all-gather
 of the minimizer lists (SURVEY.md 8(e) exchange 2).  Weak scaling: every rank holds its own
 `--genomes` genomes of one family of N*genomes genomes; the common Bloom filter is the AND over the
-whole family (exchange 1, timed separately and reported under "bloom").
+whole family (exchange 1, timed separately and reported under "bloom").  The family's pairwise divergence
+is divergence/N, which keeps the share of k-mers the common filter accepts -- and with it the candidates
+and minimizers per base each GPU handles -- at its 1-GPU value (at a fixed 1 % the AND over 24 genomes
+would accept ~6 % of the k-mers and the per-GPU work would not be the 1-GPU work any more).
 
 N=1 workload = BASELINE.json configs[1]: 3 synthetic 100 Mbp genomes at 1 % divergence, k=24 w=1000.
 The timed steps use the library's default policy (exact pruning of Bloom probes, nts_pruned.inc); the
@@ -147,7 +150,11 @@ def main():
     # ---- synthetic family: rank r owns genomes r*G .. r*G+G-1 ------------------------------------
     anc = synth.make_ancestor(total_bp, args.contigs)
     mine = list(range(rank * args.genomes, (rank + 1) * args.genomes))
-    host = [synth.derive_genome(anc, args.divergence, j) for j in mine]
+    # Weak scaling keeps the work per GPU fixed: the family grows to world x G genomes, all reduced into one common
+    # filter, so the pairwise divergence is divided by `world` -- the share of k-mers the common filter accepts
+    # ((1 - d/2)^(k x genomes)), hence candidates and minimizers per base, stays what it is on one GPU.
+    div = args.divergence / world
+    host = [synth.derive_genome(anc, div, j) for j in mine]
     genomes = [upload(ctx, g) for g in host]
     bases = sum(g.total_bp for g in genomes)
 
@@ -272,7 +279,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.genomes} synthetic {args.mbp:g} Mbp genomes per GPU at "
-                                   f"{args.divergence * 100:g}% divergence, k={k} w={w} fpr={args.fpr}",
+                                   f"{args.divergence * 100:g}% divergence, k={k} w={w} fpr={args.fpr}"
+                                   + (f" (one family of {world * args.genomes} genomes, pairwise divergence {div * 100:g}%: "
+                                      f"common-filter acceptance held at the 1-GPU value)" if world > 1 else ""),
                        "sketch_mode": args.mode, "prune_c": c_used,
                        "genomes_per_gpu": args.genomes, "bases_per_step_per_gpu": bases,
                        "minimizers_per_step_per_gpu": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)"},

@@ -38,6 +38,7 @@ constexpr int WIN_THREADS = 512;     // 8 waves share one tile: shorter phases, 
 constexpr uint32_t WIN_TILE = 4096;    // windows per workgroup
 constexpr uint32_t WIN_CHUNK = 16;     // elements scanned sequentially by one lane
 constexpr uint32_t WIN_MAX_W = 12000;  // LDS bound: (WIN_TILE + w) * 8 B + tables <= 160 KiB
+constexpr uint32_t MAIL_WORDS = 4096;  // 64-bit words of the pinned result mailbox (nts_ctx::mail)
 
 std::string g_init_error;
 
@@ -54,10 +55,17 @@ struct nts_ctx
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr; // bulk device -> host copies that may run behind later kernels (nts_bf_download)
+  // pinned host page the device writes small results into (counters, the first uncovered ranges): one stream
+  // synchronisation reads them, instead of a chain of tiny device -> host copies
+  uint64_t* mail = nullptr;     // host address
+  uint64_t* d_mail = nullptr;   // the same memory as the device sees it
+  uint8_t* stage = nullptr;     // pinned staging area for small host -> device tables (grow-only)
+  size_t stage_bytes = 0;
   std::string err;
   bool profiling = false;
   std::map<std::string, Timing> timings;
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  std::vector<hipEvent_t> spare_events; // recycled timing events (creating one costs microseconds of host time)
   // grow-only device scratch, reused across calls (a ctx serves one call at a time)
   std::map<std::string, std::pair<void*, size_t>> ws;
   // sketch policy: 0 auto (pruned when w >= 256), 1 dense, 2 pruned; prune_c/w = fraction of hashes kept as candidates
@@ -163,10 +171,21 @@ struct ScopedTimer
     , name(n)
   {
     if (ctx->profiling) {
-      hipEventCreate(&a);
-      hipEventCreate(&b);
+      a = take();
+      b = take();
       hipEventRecord(a, ctx->stream);
     }
+  }
+  hipEvent_t take()
+  {
+    hipEvent_t e = nullptr;
+    if (!ctx->spare_events.empty()) {
+      e = ctx->spare_events.back();
+      ctx->spare_events.pop_back();
+    } else {
+      hipEventCreate(&e);
+    }
+    return e;
   }
   ~ScopedTimer()
   {
@@ -186,8 +205,8 @@ void drain_timings(nts_ctx* ctx)
     auto& t = ctx->timings[p.first];
     t.ms += ms;
     t.launches += 1;
-    hipEventDestroy(p.second.first);
-    hipEventDestroy(p.second.second);
+    ctx->spare_events.push_back(p.second.first);
+    ctx->spare_events.push_back(p.second.second);
   }
   ctx->pending.clear();
 }
@@ -889,6 +908,42 @@ int ws_upload(nts_ctx* ctx, const char* name, const std::vector<T>& h, T** d)
   return NTS_OK;
 }
 
+// Several small host arrays -> one scratch buffer, through the pinned staging area and a single asynchronous copy
+// (a pageable hipMemcpyAsync per table costs ~20 us each on the host).  dev[i] receives the device address of
+// part i; parts are 16-byte aligned.  The staging area is reused by the next call: callers synchronise the
+// stream before they return, which every user of the tables does.
+struct HostPart
+{
+  const void* p;
+  size_t bytes;
+};
+
+int upload_packed(nts_ctx* ctx, const char* name, std::initializer_list<HostPart> parts, void** dev)
+{
+  size_t total = 0;
+  for (const HostPart& h : parts) total += (h.bytes + 15) & ~(size_t)15;
+  total = std::max<size_t>(total, 16);
+  if (ctx->stage_bytes < total) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stage) hipHostFree(ctx->stage);
+    ctx->stage = nullptr;
+    ctx->stage_bytes = 0;
+    const size_t want = std::max<size_t>(total + total / 4, (size_t)1 << 20);
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->stage, want, hipHostMallocDefault));
+    ctx->stage_bytes = want;
+  }
+  uint8_t* d = (uint8_t*)ws_get(ctx, name, total);
+  if (!d) return NTS_ENOMEM;
+  size_t at = 0, i = 0;
+  for (const HostPart& h : parts) {
+    if (h.bytes) memcpy(ctx->stage + at, h.p, h.bytes);
+    dev[i++] = d + at;
+    at += (h.bytes + 15) & ~(size_t)15;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(d, ctx->stage, total, hipMemcpyHostToDevice, ctx->stream));
+  return NTS_OK;
+}
+
 } // namespace
 
 // Run table and per-record tables of one (genome, k): host copy + device arrays.  Cached in the genome
@@ -1047,6 +1102,12 @@ int nts_init(int device, nts_ctx** out)
     delete ctx;
     return NTS_EHIP;
   }
+  if ((e = hipHostMalloc((void**)&ctx->mail, MAIL_WORDS * sizeof(uint64_t), hipHostMallocMapped)) != hipSuccess ||
+      (e = hipHostGetDevicePointer((void**)&ctx->d_mail, ctx->mail, 0)) != hipSuccess) {
+    g_init_error = std::string("hipHostMalloc (result mailbox): ") + hipGetErrorString(e);
+    nts_destroy(ctx);
+    return NTS_EHIP;
+  }
   *out = ctx;
   return NTS_OK;
 }
@@ -1056,9 +1117,12 @@ void nts_destroy(nts_ctx* ctx)
   if (!ctx) return;
   hipSetDevice(ctx->device);
   drain_timings(ctx);
+  for (hipEvent_t e : ctx->spare_events) hipEventDestroy(e);
   hipStreamSynchronize(ctx->stream);
   ws_release(ctx);
   for (auto& p : ctx->mx_pool) hipFree(p.first);
+  if (ctx->mail) hipHostFree(ctx->mail);
+  if (ctx->stage) hipHostFree(ctx->stage);
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1599,6 +1663,51 @@ int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_
 
 constexpr uint32_t GAP_PEEK = 1024; // uncovered ranges fetched together with the counters
 
+// small device results -> the context's pinned mailbox (up to 6 ranges of 64-bit words)
+struct MailParams
+{
+  const uint64_t* src[6];
+  uint32_t n[6];
+  uint32_t off[6];
+  uint32_t count;
+  uint64_t* mail;
+};
+
+__global__ __launch_bounds__(256) void k_mail(MailParams P)
+{
+  for (uint32_t s = 0; s < P.count; ++s)
+    for (uint32_t i = threadIdx.x; i < P.n[s]; i += 256) P.mail[P.off[s] + i] = P.src[s][i];
+}
+
+struct Mail
+{
+  MailParams P;
+  uint32_t used = 0;
+  Mail(nts_ctx* ctx)
+  {
+    P.count = 0;
+    P.mail = ctx->d_mail;
+  }
+  // returns the word offset of the range in the mailbox
+  uint32_t add(const void* dev, uint32_t n_words)
+  {
+    P.src[P.count] = (const uint64_t*)dev;
+    P.n[P.count] = n_words;
+    P.off[P.count] = used;
+    ++P.count;
+    used += n_words;
+    return used - n_words;
+  }
+  // launch + wait: afterwards ctx->mail[...] holds the values
+  int post(nts_ctx* ctx)
+  {
+    hipLaunchKernelGGL(k_mail, dim3(1), dim3(256), 0, ctx->stream, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return NTS_OK;
+  }
+};
+
 struct SortedOut
 {
   uint64_t* d_j = nullptr;   // compact indices of the minimizers, ascending
@@ -1622,25 +1731,30 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
   int rc;
   uint32_t* d_tiles = nullptr;
   uint64_t n_tile_ids = 0;
-  if (tiles && tiles->size() * 2 <= (rt.n_valid + KEY_TILE - 1) / KEY_TILE) {
-    if ((rc = ws_upload(ctx, "gap_tiles", *tiles, &d_tiles))) return rc;
-    n_tile_ids = tiles->size();
-  }
-  if ((rc = launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, T, k, filter, nullptr, d_keys, d_tiles, n_tile_ids))) return rc;
   uint64_t n_tiles;
   const uint64_t *d_vs, *d_nv, *d_ts;
   uint32_t n_rec;
   std::vector<uint64_t> tile_start;
   if (pseudo_vstart) {
+    // uncovered ranges as pseudo-records: their tables (and the list of key tiles to hash) go up in one copy
     n_tiles = tiles_of(*pseudo_nv, w, tile_start);
     if (pseudo_nv->size() > 0xFFFFFFF0ULL) return fail(ctx, NTS_ERANGE, "too many uncovered ranges");
-    uint64_t *a = nullptr, *b = nullptr, *c = nullptr;
-    if ((rc = ws_upload(ctx, "win_vstart", *pseudo_vstart, &a))) return rc;
-    if ((rc = ws_upload(ctx, "win_nv", *pseudo_nv, &b))) return rc;
-    if ((rc = ws_upload(ctx, "win_tiles", tile_start, &c))) return rc;
-    d_vs = a;
-    d_nv = b;
-    d_ts = c;
+    const bool use_tiles = tiles && tiles->size() * 2 <= (rt.n_valid + KEY_TILE - 1) / KEY_TILE;
+    void* dev[4];
+    if ((rc = upload_packed(ctx, "gap_tables",
+                            { { pseudo_vstart->data(), pseudo_vstart->size() * 8 },
+                              { pseudo_nv->data(), pseudo_nv->size() * 8 },
+                              { tile_start.data(), tile_start.size() * 8 },
+                              { use_tiles ? (const void*)tiles->data() : nullptr, use_tiles ? tiles->size() * 4 : 0 } },
+                            dev)))
+      return rc;
+    d_vs = (const uint64_t*)dev[0];
+    d_nv = (const uint64_t*)dev[1];
+    d_ts = (const uint64_t*)dev[2];
+    if (use_tiles) {
+      d_tiles = (uint32_t*)dev[3];
+      n_tile_ids = tiles->size();
+    }
     n_rec = (uint32_t)pseudo_nv->size();
   } else {
     n_tiles = T.n_win_tiles(w);
@@ -1649,6 +1763,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     if ((rc = T.win_tiles_device(ctx, w, &d_ts))) return rc;
     n_rec = g->n_rec;
   }
+  if ((rc = launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, T, k, filter, nullptr, d_keys, d_tiles, n_tile_ids))) return rc;
   OutSegs segs;
   segs.d_count = d_seg;
   segs.seg_cap = std::max<uint64_t>(256, (3 * est_kmers / w + 2 * n_tiles) / N_SEG + 64);
@@ -1662,8 +1777,12 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     HIP_TRY(ctx, hipMemsetAsync(segs.d_j, 0xFF, slots * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
     if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, segs, "window_min"))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(seg_counts, d_seg, sizeof(seg_counts), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+      Mail m(ctx);
+      const uint32_t at = m.add(d_seg, N_SEG);
+      if ((rc = m.post(ctx))) return rc;
+      for (uint32_t s = 0; s < N_SEG; ++s) seg_counts[s] = ctx->mail[at + s];
+    }
     uint64_t worst = 0;
     count = 0;
     for (uint32_t s = 0; s < N_SEG; ++s) {
@@ -1799,12 +1918,23 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     HIP_TRY(ctx, hipGetLastError());
     // one synchronisation: candidate counters, uncovered-range count + a first batch of ranges, winner count
     uint64_t last_scan = 0, last_cnt = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(ctl, d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(glo.data(), d_glo, std::min<uint64_t>(GAP_PEEK, gap_cap) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ghi.data(), d_ghi, std::min<uint64_t>(GAP_PEEK, gap_cap) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(&last_scan, d_bscan + (n_blk - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(&last_cnt, d_bcnt + (n_blk - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+      static_assert(N_SEG + 3 + 2 * GAP_PEEK <= MAIL_WORDS, "mailbox too small");
+      const uint32_t peek = (uint32_t)std::min<uint64_t>(GAP_PEEK, gap_cap);
+      Mail mb(ctx);
+      const uint32_t a_ctl = mb.add(d_ctl, N_SEG + 1);
+      const uint32_t a_scan = mb.add(d_bscan + (n_blk - 1), 1);
+      const uint32_t a_cnt = mb.add(d_bcnt + (n_blk - 1), 1);
+      const uint32_t a_lo = mb.add(d_glo, peek);
+      const uint32_t a_hi = mb.add(d_ghi, peek);
+      int rc_m = mb.post(ctx);
+      if (rc_m) return rc_m;
+      for (uint32_t i = 0; i <= N_SEG; ++i) ctl[i] = ctx->mail[a_ctl + i];
+      last_scan = ctx->mail[a_scan];
+      last_cnt = ctx->mail[a_cnt];
+      memcpy(glo.data(), ctx->mail + a_lo, (size_t)peek * 8);
+      memcpy(ghi.data(), ctx->mail + a_hi, (size_t)peek * 8);
+    }
     uint64_t worst = 0;
     m = 0;
     for (uint32_t s = 0; s < N_SEG; ++s) {
@@ -1949,7 +2079,7 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
 
   // Pruning policy.  p = share of this genome's k-mers the filter accepts, estimated from occupancies: the
   // genome alone would set about bits*(1-exp(-V/bits)) bits, the common filter kept popcount of them.  A window
-  // of w k-mers holds ~c*p accepted candidates when hashes <= (c/w)*2^64 are kept; c = 12/p leaves ~6e-6 of the
+  // of w k-mers holds ~c*p accepted candidates when hashes <= (c/w)*2^64 are kept; c*p = 12 leaves ~6e-6 of the
   // windows uncovered (they are re-evaluated densely).  Below p = 2 % the pruned pass is not worth running.
   bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= 256);
   uint32_t prune_c = ctx->prune_c;
@@ -1963,7 +2093,10 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
       p = own > 0 ? std::min(1.0, (double)pc / own) : 1.0;
     }
     if (p < 0.02 && ctx->sketch_mode == 0) pruned = false;
-    prune_c = (uint32_t)std::min(128.0, std::max(8.0, std::ceil(12.0 / std::max(p, 1e-3))));
+    // c*p = 12 accepted candidates per window on average.  (More would not empty the list of uncovered ranges:
+    // beyond the ~V*(cp/w)*exp(-cp) chance ones there are the stretches the other genomes do not share at all.)
+    const double cp = 12.0;
+    prune_c = (uint32_t)std::min(128.0, std::max(8.0, std::ceil(cp / std::max(p, 1e-3))));
     // more than ~10 % of the k-mers as candidates: the select kernel's staging lists would overflow routinely
     if (ctx->sketch_mode == 0 && (double)prune_c > 0.1 * (double)w) pruned = false;
   }
