@@ -102,6 +102,11 @@ uint64_t nts_bf_bytes(const nts_bf* bf);
 void* nts_bf_device_ptr(nts_bf* bf);
 int nts_bf_clear(nts_ctx* ctx, nts_bf* bf);
 int nts_bf_insert(nts_ctx* ctx, nts_bf* bf, const nts_genome* g, uint32_t k);
+/* How nts_bf_insert sets the bits (same filter either way): 0 = auto (large genomes: hash, partition the bit
+ * indices by filter segment in two streaming passes, set them in LDS bitmaps and OR whole segments into the
+ * filter; small ones: one atomic OR per k-mer), 1 = always one atomic OR per k-mer, 2 = partitioned build whenever
+ * the filter layout allows it (tests). */
+int nts_bf_build_mode(nts_ctx* ctx, int mode);
 int nts_bf_cascade(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nts_genome* g, uint32_t k);
 int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other);
 int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set);

@@ -71,6 +71,8 @@ struct nts_ctx
   // sketch policy: 0 auto (pruned when w >= 256), 1 dense, 2 pruned; prune_c/w = fraction of hashes kept as candidates
   std::vector<std::pair<void*, uint64_t>> mx_pool; // recycled result allocations
   size_t win_lds_set = 0;
+  bool bin_lds_set = false;
+  int bf_build_mode = 0; // 0 auto (binned build for large genomes), 1 one atomic per k-mer, 2 binned whenever it applies
   int sketch_mode = 0;
   uint32_t prune_c = 0; // 0 = adaptive (from the filter's occupancy), else fixed
   uint32_t last_c = 0;
@@ -1073,6 +1075,7 @@ int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const Genom
 }
 
 #include "nts_pruned.inc"
+#include "nts_bloom_bin.inc"
 
 } // namespace
 
@@ -1453,12 +1456,21 @@ static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nt
   const GenomeTables* T = nullptr;
   int rc = get_tables(ctx, g, k, nullptr, 0, scratch, &T);
   if (rc) return rc;
-  if (prev)
+  if (prev) {
     rc = launch_hash<MODE_CASCADE>(ctx, "bf_cascade", g, *T, k, prev, next, nullptr);
-  else
-    rc = launch_hash<MODE_INSERT>(ctx, "bf_insert", g, *T, k, nullptr, next, nullptr);
+  } else {
+    rc = ctx->bf_build_mode == 1 ? 1 : bf_insert_binned(ctx, next, g, *T, k, ctx->bf_build_mode == 2);
+    if (rc == 1) rc = launch_hash<MODE_INSERT>(ctx, "bf_insert", g, *T, k, nullptr, next, nullptr);
+  }
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // run table buffers are released on return
+  return NTS_OK;
+}
+
+int nts_bf_build_mode(nts_ctx* ctx, int mode)
+{
+  if (!ctx || mode < 0 || mode > 2) return fail(ctx, NTS_EINVAL, "nts_bf_build_mode: mode must be 0 (auto), 1 (atomic) or 2 (binned)");
+  ctx->bf_build_mode = mode;
   return NTS_OK;
 }
 

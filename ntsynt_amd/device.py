@@ -52,6 +52,11 @@ class Context:
         code = {"auto": 0, "dense": 1, "pruned": 2}[mode]
         self.check(self.lib.nts_sketch_mode(self.h, code, int(prune_c)), "nts_sketch_mode")
 
+    def bf_build_mode(self, mode="auto"):
+        """How BloomFilter.insert sets the bits: 'auto' (partitioned streaming build for large genomes), 'atomic'
+        (one atomic OR per k-mer) or 'binned' (partitioned whenever the filter layout allows); same filter."""
+        self.check(self.lib.nts_bf_build_mode(self.h, {"auto": 0, "atomic": 1, "binned": 2}[mode]), "nts_bf_build_mode")
+
     def sketch_stats(self):
         "(accepted candidates, uncovered ranges, k-mers in them) of the last sketch call"
         a, b, c, d = u64(), u64(), u64(), ctypes.c_uint32()

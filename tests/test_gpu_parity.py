@@ -94,6 +94,40 @@ def test_bloom_insert_cascade_and(ctx, k):
     assert rt.popcount() == O.bf_popcount(o_prev)
 
 
+@pytest.mark.parametrize("nbytes", [3 << 20, 100 << 20])   # 24 final buckets (one partition level) / 800 (two levels)
+def test_bloom_binned_build_equals_atomic_and_oracle(ctx, nbytes):
+    """nts_bf_insert's partitioned build (hash -> bucket passes -> LDS bitmaps) sets the same bits as one atomic OR
+    per k-mer and as the oracle: random records with N runs (tiles that cross run boundaries take the direct path),
+    a repeat that piles 300k copies of a handful of k-mers into a few buckets (capacity overflow -> direct atomics),
+    and inserting into a filter that already holds bits."""
+    from ntsynt_amd.device import BloomFilter
+    k = 24
+    names, seqs = _family(77, lengths=[400000, 0, 30, 250000, 12000, 90001], n_frac=0.0002)
+    seqs = list(seqs) + [b"ACGTTGCA" * 40000, b"A" * 300000]
+    names = [f"r{i}" for i in range(len(seqs))]
+    og, dg = to_oracle(names, seqs), to_device(ctx, names, seqs)
+    names2, seqs2 = _family(78, lengths=[150000, 70000])
+    og2, dg2 = to_oracle(names2, seqs2), to_device(ctx, names2, seqs2)
+    want = O.bf_build(og, k, nbytes)
+    want2 = want | O.bf_build(og2, k, nbytes)
+    got = {}
+    try:
+        for mode in ("atomic", "binned"):
+            ctx.bf_build_mode(mode)
+            bf = BloomFilter(ctx, nbytes, k)
+            bf.insert(dg)
+            got[mode] = bf.to_numpy()
+            assert bf.popcount() == int(np.unpackbits(want).sum())
+            bf.insert(dg2)                       # OR into a non-empty filter
+            assert np.array_equal(bf.to_numpy(), want2), mode
+            bf.free()
+    finally:
+        ctx.bf_build_mode("auto")
+    assert np.array_equal(got["atomic"], want)
+    assert np.array_equal(got["binned"], want)
+
+
+
 @pytest.mark.parametrize("k,w", [(24, 1000), (24, 100), (20, 10), (24, 1), (32, 17), (24, 16), (24, 15),
                                  (24, 4097), (20, 250)])
 def test_sketch_no_filter(ctx, k, w):
