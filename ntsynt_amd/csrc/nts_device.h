@@ -14,17 +14,34 @@ constexpr uint64_t MULTISEED = 0x90b45d39fb6da1faULL;
 constexpr uint64_t KEY_MAX = 0xFFFFFFFFFFFFFFFFULL;
 constexpr uint8_t CODE_INVALID = 4;
 
-// split rotate left by one: bits 0..32 form a 33-bit ring, bits 33..63 a 31-bit ring
+// split rotate left by one: bits 0..32 form a 33-bit ring, bits 33..63 a 31-bit ring.
+// On the device the rotation is written on the two 32-bit halves (alignbit / and-or / shift-or, six full-rate
+// instructions); 64-bit shifts issue at half rate on CDNA and the rolling loops are VALU-bound.
 __host__ __device__ __forceinline__ uint64_t srol1(uint64_t x)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  const uint32_t lo2 = (lo << 1) | (hi & 1u);                        // bit 32 wraps to bit 0
+  const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 31);          // (hi << 1) | (lo >> 31)
+  const uint32_t hi2 = (t & ~2u) | ((hi >> 30) & 2u);                // bit 63 wraps to bit 33
+  return ((uint64_t)hi2 << 32) | lo2;
+#else
   const uint64_t m = ((x & 0x8000000000000000ULL) >> 30) | ((x & 0x100000000ULL) >> 32);
   return ((x << 1) & 0xFFFFFFFDFFFFFFFFULL) | m;
+#endif
 }
 
 __host__ __device__ __forceinline__ uint64_t sror1(uint64_t x)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  const uint32_t lo2 = __builtin_amdgcn_alignbit(hi, lo, 1);         // (lo >> 1) | (hi << 31): bit 32 moves to bit 31
+  const uint32_t hi2 = ((hi >> 1) & 0x7FFFFFFEu) | ((hi & 2u) << 30) | (lo & 1u); // bit 33 -> 63, bit 0 -> 32
+  return ((uint64_t)hi2 << 32) | lo2;
+#else
   const uint64_t m = ((x & 0x200000000ULL) << 30) | ((x & 1ULL) << 32);
   return ((x >> 1) & 0xFFFFFFFEFFFFFFFFULL) | m;
+#endif
 }
 
 __host__ __device__ __forceinline__ uint64_t extend_h1(uint64_t h0, uint32_t k)
@@ -37,13 +54,38 @@ __host__ __device__ __forceinline__ uint64_t extend_h1(uint64_t h0, uint32_t k)
 // Kernel-argument block for the hashing kernels.
 //   roll_f[cin*4+cout] = seed[cin] ^ srol^k(seed[cout])             (forward strand update)
 //   roll_r[cin*4+cout] = srol^k(seed[3-cin]) ^ seed[3-cout]         (reverse strand update)
+//   init[(i*4 + b)*2 + {0,1}] = { srol^(k-1-i)(seed[b]), srol^i(seed[3-b]) }   (device memory; the hash of a
+//                                lane's first k-mer is the XOR of k such pairs: no rotations, independent loads)
 struct HashParams
 {
   uint64_t seed[4];
   uint64_t roll_f[16];
   uint64_t roll_r[16];
+  const uint64_t* init; // [k][4][2]
   uint32_t k;
 };
+
+// forward / reverse strand hashes of the k-mer whose bases are fetched by base(i), i = 0..k-1
+template <typename BaseAt>
+__device__ __forceinline__ void hash_init(const HashParams& hp, BaseAt&& base, uint64_t& f, uint64_t& r)
+{
+  f = 0;
+  r = 0;
+  const ulonglong2* tab = reinterpret_cast<const ulonglong2*>(hp.init);
+  for (uint32_t i0 = 0; i0 < hp.k; i0 += 8) { // eight table reads in flight at a time (L1-resident: k x 64 bytes)
+    ulonglong2 e[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) {
+      e[q] = make_ulonglong2(0, 0);
+      if (i0 + q < hp.k) e[q] = tab[(i0 + q) * 4u + base(i0 + q)];
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) {
+      f ^= e[q].x;
+      r ^= e[q].y;
+    }
+  }
+}
 
 // Exact h % m for a runtime m: q = mulhi(h, floor(2^64/m)) is floor(h/m) or one less.
 struct FastMod

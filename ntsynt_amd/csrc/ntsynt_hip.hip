@@ -65,6 +65,7 @@ struct nts_ctx
   bool profiling = false;
   std::map<std::string, Timing> timings;
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  std::map<uint32_t, uint64_t*> init_tabs; // per k: device table for the first k-mer of a lane (HashParams::init)
   std::vector<hipEvent_t> spare_events; // recycled timing events (creating one costs microseconds of host time)
   // grow-only device scratch, reused across calls (a ctx serves one call at a time)
   std::map<std::string, std::pair<void*, size_t>> ws;
@@ -379,12 +380,7 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
     const uint32_t n_mine = first < tile_len ? min(32u, tile_len - first) : 0u;
     uint32_t s = a + first;
     uint64_t f = 0, r = 0;
-    if (n_mine) {
-      for (uint32_t i = 0; i < k; ++i) {
-        f = srol1(f) ^ s_tab[32 + base_at(s + i)];
-        r = srol1(r) ^ s_tab[32 + 3 - base_at(s + k - 1 - i)];
-      }
-    }
+    if (n_mine) hash_init(hp, [&](uint32_t i) { return base_at(s + i); }, f, r);
     const uint64_t out_base = J0 + tid;
 #pragma unroll 1
     for (uint32_t b0 = 0; b0 < 32; b0 += 8) {
@@ -819,7 +815,41 @@ HashParams make_hash_params(uint32_t k)
       hp.roll_r[cin * 4 + cout] = rotk[3 - cin] ^ seed[3 - cout];
     }
   hp.k = k;
+  hp.init = nullptr;
   return hp;
+}
+
+// hash parameters with the device-resident init table (cached per k in the context)
+int hash_params_for(nts_ctx* ctx, uint32_t k, HashParams* out)
+{
+  *out = make_hash_params(k);
+  auto it = ctx->init_tabs.find(k);
+  if (it == ctx->init_tabs.end()) {
+    std::vector<uint64_t> tab((size_t)k * 8);
+    const uint64_t seed[4] = { SEED_A, SEED_C, SEED_G, SEED_T };
+    for (int b = 0; b < 4; ++b) {
+      uint64_t x = seed[3 - b]; // srol^i(seed[3-b]), i ascending
+      for (uint32_t i = 0; i < k; ++i) {
+        tab[((size_t)i * 4 + b) * 2 + 1] = x;
+        x = srol1(x);
+      }
+      uint64_t y = seed[b]; // srol^(k-1-i)(seed[b]): i descending
+      for (uint32_t i = k; i-- > 0;) {
+        tab[((size_t)i * 4 + b) * 2] = y;
+        y = srol1(y);
+      }
+    }
+    uint64_t* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, tab.size() * 8));
+    hipError_t e = hipMemcpy(d, tab.data(), tab.size() * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      hipFree(d);
+      HIP_TRY(ctx, e);
+    }
+    it = ctx->init_tabs.emplace(k, d).first;
+  }
+  out->init = it->second;
+  return NTS_OK;
 }
 
 FastMod make_fastmod(uint64_t m)
@@ -1060,7 +1090,11 @@ int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const Genom
   const RunTable& rt = T.rt;
   if (rt.n_valid == 0) return NTS_OK;
   if (d_tile_ids && n_tile_ids == 0) return NTS_OK;
-  const HashParams hp = make_hash_params(k);
+  HashParams hp;
+  {
+    const int rc_hp = hash_params_for(ctx, k, &hp);
+    if (rc_hp) return rc_hp;
+  }
   const uint64_t bits = (bf_in ? bf_in->bytes : (bf_out ? bf_out->bytes : 8)) * 8;
   const FastMod fm = make_fastmod(bits);
   const uint64_t per_block = (uint64_t)HASH_THREADS * HASH_PER_THREAD;
@@ -1124,6 +1158,7 @@ void nts_destroy(nts_ctx* ctx)
   hipStreamSynchronize(ctx->stream);
   ws_release(ctx);
   for (auto& p : ctx->mx_pool) hipFree(p.first);
+  for (auto& kv : ctx->init_tabs) hipFree(kv.second);
   if (ctx->mail) hipHostFree(ctx->mail);
   if (ctx->stage) hipHostFree(ctx->stage);
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
@@ -1846,6 +1881,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   if (!ptr) return NTS_ENOMEM
   PR_WS(d_toff, uint64_t*, "sel_tile_off", n_kt * 8);
   PR_WS(d_tcnt, uint32_t*, "sel_tile_cnt", n_kt * 4);
+  PR_WS(d_tord, uint8_t*, "sel_tile_ord", n_kt);
   PR_WS(d_tcnt64, uint64_t*, "sel_tile_cnt64", n_kt * 8);
   PR_WS(d_tscan, uint64_t*, "sel_tile_scan", n_kt * 8);
   // control block: [0..63] candidate segment counters, [64] uncovered-range counter
@@ -1881,7 +1917,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     S.run_vstart = T.d_run_vstart;
     S.n_runs = T.n_runs;
     S.n_valid = V;
-    S.hp = make_hash_params(k);
+    if (int rc_hp = hash_params_for(ctx, k, &S.hp)) return rc_hp;
     S.bf = filter ? filter->d_words : nullptr;
     S.fm = make_fastmod((filter ? filter->bytes : 8) * 8);
     S.tau = tau;
@@ -1891,6 +1927,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     S.seg_count = d_ctl;
     S.tile_off = d_toff;
     S.tile_cnt = d_tcnt;
+    S.tile_ordered = d_tord;
     {
       ScopedTimer t(ctx, filter ? "hash_select" : "hash_select_nofilter");
       hipLaunchKernelGGL(k_hash_select, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
@@ -1899,7 +1936,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       ScopedTimer t(ctx, "cand_compact");
       hipLaunchKernelGGL(k_cnt_to_u64, dim3((uint32_t)((n_kt + 255) / 256)), dim3(256), 0, ctx->stream, d_tcnt, n_kt, d_tcnt64);
       HIP_TRY(ctx, rocprim::exclusive_scan(d_scan_tmp, scan_bytes, d_tcnt64, d_tscan, (uint64_t)0, n_kt, rocprim::plus<uint64_t>(), ctx->stream));
-      hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)n_kt), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tscan, n_kt,
+      hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)n_kt), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tord, d_tscan, n_kt,
                          d_pj, d_pk, m_max);
     }
     SparseParams Q;

@@ -107,7 +107,8 @@ class SyntenyEngine:
     # ------------------------------------------------------------------ graph bookkeeping
     def _degrees(self):
         m = self.e_alive
-        return np.bincount(np.concatenate((self.e_u[m], self.e_v[m])), minlength=self.v_hash.size)
+        n = self.v_hash.size
+        return np.bincount(self.e_u[m], minlength=n) + np.bincount(self.e_v[m], minlength=n)
 
     def _delete_vertices(self, vids):
         if len(vids) == 0:
@@ -212,8 +213,8 @@ class SyntenyEngine:
     # ------------------------------------------------------------------ C3: bubble removal (S:548-590)
     def _simplify(self, apply_deletions):
         wmax = self.G                                      # sum of the weights, all 1 (S:32, S:571)
-        deg = self._degrees()
-        cand = np.flatnonzero(self.e_alive & (deg[self.e_u] == 3) & (deg[self.e_v] == 3))
+        is3 = self._degrees() == 3                         # one byte per vertex: the edge-wise gathers stay in cache
+        cand = np.flatnonzero(self.e_alive & is3[self.e_u] & is3[self.e_v])
         if cand.size == 0:
             return
         cv = np.unique(np.concatenate((self.e_u[cand], self.e_v[cand])))
@@ -441,14 +442,19 @@ class SyntenyEngine:
             rec = np.asarray(rec, np.int64)
             pos = np.asarray(pos, np.int64)
             # C1: hashes seen once in this (masked) assembly
-            _, inv, cnt = np.unique(h1, return_inverse=True, return_counts=True)
-            uniq = cnt[inv] == 1
+            # (one sort of the list serves both this and the look-up below: sorted queries walk `uh` in order)
+            order = np.argsort(h1, kind="stable")
+            sh = h1[order]
+            first = np.ones(sh.size, bool)
+            first[1:] = sh[1:] != sh[:-1]
+            run = np.cumsum(first) - 1
+            uniq = np.empty(h1.size, bool)
+            uniq[order] = (np.bincount(run) == 1)[run] if sh.size else np.zeros(0, bool)
             # is the hash an internal minimizer of a block?  (S:274: `mx not in black_list`)
-            if uh.size:
-                p = np.minimum(np.searchsorted(uh, h1), uh.size - 1)
-                is_internal = uh[p] == h1
-            else:
-                is_internal = np.zeros(h1.size, bool)
+            is_internal = np.zeros(h1.size, bool)
+            if uh.size and sh.size:
+                p = np.minimum(np.searchsorted(uh, sh), uh.size - 1)
+                is_internal[order] = uh[p] == sh
             inside = np.zeros(h1.size, bool)
             cut_before = np.zeros(h1.size, bool)
             for r, ivs in spans[a].items():
