@@ -73,6 +73,7 @@ struct nts_ctx
   std::vector<std::pair<void*, uint64_t>> mx_pool; // recycled result allocations
   size_t win_lds_set = 0;
   bool bin_lds_set = false;
+  bool small_gap_path = true; // uncovered ranges: device-side sort + merge when they are few (nts_pruned.inc)
   int bf_build_mode = 0; // 0 auto (binned build for large genomes), 1 one atomic per k-mer, 2 binned whenever it applies
   int sketch_mode = 0;
   uint32_t prune_c = 0; // 0 = adaptive (from the filter's occupancy), else fixed
@@ -731,6 +732,7 @@ __global__ __launch_bounds__(256) void k_bench_probe(const uint32_t* __restrict_
 __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j_sorted,
                                                   const uint64_t* __restrict__ key_sorted,
                                                   uint64_t n_out,
+                                                  const uint64_t* __restrict__ n_out_dev, // if not null: the count lives here
                                                   const uint64_t* __restrict__ run_pos,
                                                   const uint64_t* __restrict__ run_vstart,
                                                   uint32_t n_runs,
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j
                                                   uint64_t* __restrict__ pos)
 {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_out) return;
+  if (i >= (n_out_dev ? *n_out_dev : n_out)) return;
   const uint64_t j = j_sorted[i];
   uint32_t lo = 0, hi = n_runs;
   while (hi - lo > 1) {
@@ -1759,14 +1761,20 @@ struct SortedOut
 {
   uint64_t* d_j = nullptr;   // compact indices of the minimizers, ascending
   uint64_t* d_key = nullptr; // their keys (h0)
-  uint64_t count = 0;
+  uint64_t count = 0;        // their number -- or an upper bound when d_ctl is set:
+  // few uncovered ranges are merged in on the device; d_ctl[1] = number of minimizers, d_ctl[2] = 1 if that path
+  // gave up (the call is repeated with ctx->small_gap_path = false)
+  uint64_t* d_ctl = nullptr;
 };
 
 // dense kernels over (pseudo-)records into segmented buffers, then a sort: `res` gets the ordered list.
 // tiles: optional list of key tiles to hash (uncovered ranges only); nullptr = all tiles.
+// sparse: when given (the ordered winners of the pruned pass) and the uncovered ranges are few, their winners are sorted
+// and merged into that list on the device (k_gap_sort, k_merge_lists_dev): `res` is then the merged list with
+// res.d_ctl set and res.count an upper bound, and no synchronisation happens here.
 int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter,
                      const std::vector<uint64_t>* pseudo_vstart, const std::vector<uint64_t>* pseudo_nv, const std::vector<uint32_t>* tiles,
-                     uint64_t est_kmers, const char* slot_prefix, SortedOut& res)
+                     uint64_t est_kmers, const char* slot_prefix, SortedOut& res, const SortedOut* sparse = nullptr)
 {
   const RunTable& rt = T.rt;
 #define DN_WS(ptr, type, name, bytes)                                                               \
@@ -1814,6 +1822,34 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
   OutSegs segs;
   segs.d_count = d_seg;
   segs.seg_cap = std::max<uint64_t>(256, (3 * est_kmers / w + 2 * n_tiles) / N_SEG + 64);
+  if (sparse && ctx->small_gap_path && n_tiles <= 1024 && segs.seg_cap <= 512) {
+    // ---- few uncovered ranges: no host round trip --------------------------------------------------------------
+    const uint64_t slots = segs.seg_cap * N_SEG;
+    segs.d_j = (uint64_t*)ws_get(ctx, (pre + "out_j").c_str(), slots * 8);
+    segs.d_key = (uint64_t*)ws_get(ctx, (pre + "out_key").c_str(), slots * 8);
+    DN_WS(d_gj, uint64_t*, "gap_sorted_j", GAP_SORT_CAP * 8);
+    DN_WS(d_gk, uint64_t*, "gap_sorted_key", GAP_SORT_CAP * 8);
+    DN_WS(d_gctl, uint64_t*, "gap_ctl", 4 * 8);
+    const uint64_t total_max = sparse->count + GAP_SORT_CAP;
+    DN_WS(d_mj, uint64_t*, "merged_j", total_max * 8);
+    DN_WS(d_mk, uint64_t*, "merged_key", total_max * 8);
+    if (!segs.d_j || !segs.d_key) return NTS_ENOMEM;
+    HIP_TRY(ctx, hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
+    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, segs, "window_min"))) return rc;
+    {
+      ScopedTimer t(ctx, "merge_lists");
+      hipLaunchKernelGGL(k_gap_sort, dim3(1), dim3(GAP_SORT_THREADS), 0, ctx->stream, d_seg, segs.d_j, segs.d_key, segs.seg_cap, sparse->count,
+                         d_gj, d_gk, d_gctl);
+      hipLaunchKernelGGL(k_merge_lists_dev, dim3((uint32_t)((total_max + 255) / 256)), dim3(256), 0, ctx->stream, sparse->d_j, sparse->d_key,
+                         sparse->count, d_gj, d_gk, d_gctl, d_mj, d_mk);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    res.d_j = d_mj;
+    res.d_key = d_mk;
+    res.count = total_max;
+    res.d_ctl = d_gctl;
+    return NTS_OK;
+  }
   unsigned long long seg_counts[N_SEG];
   uint64_t count = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -2026,8 +2062,16 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   }
   ctx->last_gap_kmers = covered;
   SortedOut dense;
-  int rc = run_dense_sorted(ctx, g, T, k, w, filter, &pv, &pn, &tiles, covered, "gap_", dense);
+  SortedOut sparse_list;
+  sparse_list.d_j = d_sj;
+  sparse_list.d_key = d_sk;
+  sparse_list.count = n_sparse;
+  int rc = run_dense_sorted(ctx, g, T, k, w, filter, &pv, &pn, &tiles, covered, "gap_", dense, &sparse_list);
   if (rc) return rc;
+  if (dense.d_ctl) { // merged on the device: the caller reads the count after its own synchronisation
+    res = dense;
+    return NTS_OK;
+  }
   if (dense.count == 0) return NTS_OK;
   const uint64_t total = n_sparse + dense.count;
   PR_WS(d_mj, uint64_t*, "merged_j", total * 8);
@@ -2100,6 +2144,7 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   const RunTable& rt = T->rt;
   nts_mx* mx = new nts_mx();
   ctx->last_candidates = ctx->last_gaps = ctx->last_gap_kmers = 0;
+  ctx->small_gap_path = true;
   if (rt.n_valid == 0 || T->n_win_tiles(w) == 0) {
     *out = mx;
     return NTS_OK;
@@ -2151,23 +2196,44 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   }
   ctx->last_c = pruned ? prune_c : 0;
 
-  SortedOut res;
-  if (pruned)
-    SK_TRY(run_pruned(ctx, g, *T, k, w, filter, prune_c, res));
-  else
-    SK_TRY(run_dense_sorted(ctx, g, *T, k, w, filter, nullptr, nullptr, nullptr, rt.n_valid, "", res));
-  const uint64_t count = res.count;
-  mx->n = count;
-  if (count) {
-    SK_TRY(alloc_result(ctx, mx, count));
-    {
-      ScopedTimer t(ctx, "finalize");
-      hipLaunchKernelGGL(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, res.d_j, res.d_key, (uint64_t)count,
-                         T->d_run_pos, T->d_run_vstart, T->n_runs, g->d_rec_off, g->n_rec, k, mx->d_h1, mx->d_rec, mx->d_pos);
+  for (int attempt = 0;; ++attempt) {
+    SortedOut res;
+    if (pruned)
+      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, prune_c, res));
+    else
+      SK_TRY(run_dense_sorted(ctx, g, *T, k, w, filter, nullptr, nullptr, nullptr, rt.n_valid, "", res));
+    const uint64_t count = res.count; // exact, or an upper bound when the count still lives on the device
+    mx->n = count;
+    if (count) {
+      SK_TRY(alloc_result(ctx, mx, count));
+      {
+        ScopedTimer t(ctx, "finalize");
+        hipLaunchKernelGGL(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, res.d_j, res.d_key, (uint64_t)count,
+                           res.d_ctl ? res.d_ctl + 1 : nullptr, T->d_run_pos, T->d_run_vstart, T->n_runs, g->d_rec_off, g->n_rec, k, mx->d_h1,
+                           mx->d_rec, mx->d_pos);
+      }
+      SK_HIP(hipGetLastError());
     }
-    SK_HIP(hipGetLastError());
+    if (!res.d_ctl) {
+      SK_HIP(hipStreamSynchronize(ctx->stream));
+      break;
+    }
+    Mail mb(ctx);
+    const uint32_t at = mb.add(res.d_ctl, 3);
+    SK_TRY(mb.post(ctx));
+    if (ctx->mail[at + 2] == 0) {
+      mx->n = ctx->mail[at + 1];
+      break;
+    }
+    // the device-side merge of the uncovered ranges gave up (too many winners): once more on the general path
+    if (attempt == 1) return bail(fail(ctx, NTS_EHIP, "nts_sketch: uncovered ranges could not be merged"));
+    ctx->mx_pool.push_back({ mx->d_h1, mx->cap_bytes });
+    mx->d_h1 = nullptr;
+    mx->d_pos = nullptr;
+    mx->d_rec = nullptr;
+    ctx->small_gap_path = false;
   }
-  SK_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->small_gap_path = true;
   *out = mx;
   return NTS_OK;
 #undef SK_TRY
