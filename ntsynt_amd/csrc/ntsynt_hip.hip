@@ -347,6 +347,8 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
   const uint32_t k = hp.k;
   // tile_ids (optional): the key tiles to compute, for the dense fallback on uncovered ranges only
   const uint64_t J0 = (uint64_t)(tile_ids ? tile_ids[blockIdx.x] : blockIdx.x) * KEY_TILE;
+  // with a tile list, the keys of the i-th listed tile go to slot i of a compact key buffer
+  const uint64_t KB = (uint64_t)blockIdx.x * KEY_TILE;
   const uint32_t tile_len = (uint32_t)min((uint64_t)KEY_TILE, n_valid - J0);
   // run holding J0 (same for every lane: broadcast loads)
   uint32_t lo = 0, hi = n_runs;
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
     uint32_t s = a + first;
     uint64_t f = 0, r = 0;
     if (n_mine) hash_init(hp, [&](uint32_t i) { return base_at(s + i); }, f, r);
-    const uint64_t out_base = J0 + tid;
+    const uint64_t out_base = KB + tid;
 #pragma unroll 1
     for (uint32_t b0 = 0; b0 < 32; b0 += 8) {
       uint64_t h[8];
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
       r = srol1(r) ^ s_tab[32 + 3 - code[p + k - 1 - i]];
     }
     for (;;) {
-      hash_emit<MODE>(f + r, true, key_phys(j), bf_in, bf_out, fm, keys);
+      hash_emit<MODE>(f + r, true, KB + (key_phys(j) - J0), bf_in, bf_out, fm, keys);
       ++j;
       if (j >= seg_end) break;
       const uint32_t cout = code[p], cin = code[p + k];
@@ -474,6 +476,8 @@ __global__ __launch_bounds__(256) void k_keys_linear(const uint64_t* __restrict_
 struct WinParams
 {
   const uint64_t* keys;       // compact keys, tile-transposed (key_phys)
+  const uint32_t* tile_ids;   // if not null: `keys` holds only these key tiles (ascending), tile_ids[i] in slot i
+  uint32_t n_tile_ids;
   const uint64_t* rec_vstart; // [n_rec] compact index of the record's first valid k-mer
   const uint64_t* rec_nv;     // [n_rec] valid k-mers in the record
   const uint64_t* tile_start; // [n_rec+1] prefix sum of tiles per record
@@ -491,6 +495,21 @@ constexpr uint32_t N_SEG = 64;
 __device__ __forceinline__ uint32_t pe(uint32_t e)
 {
   return e + (e >> 5);
+}
+
+// slot of a key tile in the key buffer: the tile itself, or its rank in the list of tiles that were computed
+__device__ __forceinline__ uint64_t win_key_slot(const WinParams& P, uint64_t tile)
+{
+  if (P.tile_ids == nullptr) return tile;
+  uint32_t lo = 0, hi = P.n_tile_ids;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (P.tile_ids[mid] <= tile)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
 }
 
 // smaller key wins, ties to the larger index
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
     const uint32_t col = col_lo + (threadIdx.x & 255u);
     const uint32_t row0 = (threadIdx.x >> 8) * ROWS;
     if (col <= col_hi) {
-      const uint64_t* g = P.keys + tb + col;
+      const uint64_t* g = P.keys + win_key_slot(P, tile) * KEY_TILE + col;
       const int64_t e0 = (int64_t)(tb + 32ull * col) - (int64_t)ja; // element index of row 0
       uint64_t v[ROWS];
 #pragma unroll
@@ -1677,12 +1696,15 @@ uint64_t tiles_of(const std::vector<uint64_t>& nv, uint32_t w, std::vector<uint6
 
 // dense window kernel over (pseudo-)records already resident on the device; keys must be present for them
 int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vs, const uint64_t* d_nv, const uint64_t* d_ts,
-                        uint32_t n_rec, uint64_t n_tiles, uint32_t w, const OutSegs& out, const char* tag)
+                        uint32_t n_rec, uint64_t n_tiles, uint32_t w, const OutSegs& out, const char* tag,
+                        const uint32_t* d_tile_ids = nullptr, uint64_t n_tile_ids = 0)
 {
   if (n_tiles == 0) return NTS_OK;
   if (n_tiles > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "too many window tiles for one launch");
   WinParams P;
   P.keys = d_keys;
+  P.tile_ids = d_tile_ids;
+  P.n_tile_ids = (uint32_t)n_tile_ids;
   P.rec_vstart = d_vs;
   P.rec_nv = d_nv;
   P.tile_start = d_ts;
@@ -1782,7 +1804,6 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
   if (!ptr) return NTS_ENOMEM
   const std::string pre(slot_prefix);
   DN_WS(d_seg, unsigned long long*, "seg_count", N_SEG * sizeof(unsigned long long));
-  DN_WS(d_keys, uint64_t*, "keys", key_buffer_elems(rt.n_valid) * 8);
   int rc;
   uint32_t* d_tiles = nullptr;
   uint64_t n_tile_ids = 0;
@@ -1818,6 +1839,8 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     if ((rc = T.win_tiles_device(ctx, w, &d_ts))) return rc;
     n_rec = g->n_rec;
   }
+  // keys: one slot per key tile of the genome, or only the listed tiles (uncovered ranges) in a compact buffer
+  DN_WS(d_keys, uint64_t*, d_tiles ? "gap_keys" : "keys", (d_tiles ? n_tile_ids * KEY_TILE : key_buffer_elems(rt.n_valid)) * 8);
   if ((rc = launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, T, k, filter, nullptr, d_keys, d_tiles, n_tile_ids))) return rc;
   OutSegs segs;
   segs.d_count = d_seg;
@@ -1835,7 +1858,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     DN_WS(d_mk, uint64_t*, "merged_key", total_max * 8);
     if (!segs.d_j || !segs.d_key) return NTS_ENOMEM;
     HIP_TRY(ctx, hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
-    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, segs, "window_min"))) return rc;
+    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, segs, "window_min", d_tiles, n_tile_ids))) return rc;
     {
       ScopedTimer t(ctx, "merge_lists");
       hipLaunchKernelGGL(k_gap_sort, dim3(1), dim3(GAP_SORT_THREADS), 0, ctx->stream, d_seg, segs.d_j, segs.d_key, segs.seg_cap, sparse->count,
@@ -1859,7 +1882,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     if (!segs.d_j || !segs.d_key) return NTS_ENOMEM;
     HIP_TRY(ctx, hipMemsetAsync(segs.d_j, 0xFF, slots * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
-    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, segs, "window_min"))) return rc;
+    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, segs, "window_min", d_tiles, n_tile_ids))) return rc;
     {
       Mail m(ctx);
       const uint32_t at = m.add(d_seg, N_SEG);
