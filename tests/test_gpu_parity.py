@@ -26,7 +26,7 @@ def _family(seed, lengths=LENGTHS, **kw):
     return names, seqs
 
 
-@pytest.mark.parametrize("k", [20, 24, 31, 64])
+@pytest.mark.parametrize("k", [20, 24, 31, 64, 128, 129, 200])   # above 128 every kernel walks the run table (no LDS staging)
 def test_hash_all(ctx, k):
     names, seqs = _family(10 + k)
     dev = to_device(ctx, names, seqs)
@@ -289,3 +289,34 @@ def test_sketch_modes_identical(ctx, mode, c):
             assert np.array_equal(a, b.astype(a.dtype))
     finally:
         ctx.sketch_mode("auto", 64)
+
+
+@pytest.mark.parametrize("k", [1, 129, 200])
+def test_long_and_degenerate_k_end_to_end(ctx, k):
+    """k beyond the LDS-staged fast paths (and k = 1): Bloom build (both builds), pruned and dense sketch vs the oracle"""
+    from ntsynt_amd.device import BloomFilter, sketch
+    names, seqs = _family(600 + k, lengths=[90000, 150, 40000, 0, 260], n_frac=0.001)
+    og, dg = to_oracle(names, seqs), to_device(ctx, names, seqs)
+    nbytes = 1 << 20
+    want_bf = O.bf_build(og, k, nbytes)
+    try:
+        for mode in ("atomic", "binned"):
+            ctx.bf_build_mode(mode)
+            bf = BloomFilter(ctx, nbytes, k)
+            bf.insert(dg)
+            assert np.array_equal(bf.to_numpy(), want_bf), mode
+            bf.free()
+    finally:
+        ctx.bf_build_mode("auto")
+    dbf = BloomFilter(ctx, nbytes, k)
+    dbf.from_numpy(want_bf)
+    try:
+        for mode in ("dense", "pruned"):
+            ctx.sketch_mode(mode, 0)
+            for w in (300, 7):
+                exp = oracle_flat(O.minimize(og, k, w, want_bf))
+                got = sketch(ctx, dg, k, w, dbf).to_numpy()
+                for a, b in zip(got, exp):
+                    assert np.array_equal(a, b.astype(a.dtype)), (mode, k, w)
+    finally:
+        ctx.sketch_mode("auto", 0)
