@@ -292,10 +292,19 @@ def main():
                          "avg_launch_ms": round(a_ms, 4), "launches": tm["hash_select" if pruned_run else "hash_probe"][1],
                          "other_kernels_avg_ms": {n: round(avg(n), 4) for n in names if tm[n][1]},
                          "candidates_per_launch": cand, "uncovered_ranges": gaps, "uncovered_kmers": gap_kmers,
+                         # the formulation with one sector read per k-mer moves 65.03 B/base, i.e. at
+                         # most 8 TB/s / 65.03 B = 123 Gbases/s; the timed path, expressed in those bytes:
+                         "one_probe_per_kmer_equivalent": {
+                             "bytes_per_base": round(1.0 + SECTOR + 32.0 / (w + 1), 3),
+                             "GBs": round(value * (1.0 + SECTOR + 32.0 / (w + 1)) / world, 1),
+                             "frac_of_peak": round(value * (1.0 + SECTOR + 32.0 / (w + 1)) / world / HBM_PEAK_GBS, 3)},
                          "unpruned": dense},
             "bloom": {"bytes": nbytes, "build_s": round(t_build, 4), "allreduce_and_s": round(t_allreduce, 4),
                       "bf_insert_avg_ms": round(ins_ms / max(ins_n, 1), 4),
                       "bf_insert_Gbases_s": round(per_launch_bases / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 3)
+                      if ins_ms > 0 else None,
+                      # SURVEY.md 8(d) prices the build at 129 B/base (sector read + write-back per k-mer)
+                      "bf_insert_GBs_at_129B_per_base": round(129.0 * per_launch_bases / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 1)
                       if ins_ms > 0 else None,
                       "occupancy": round(fpr_final, 6)},
         }
