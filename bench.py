@@ -138,10 +138,20 @@ def main():
     from ntsynt_amd import synth
     from ntsynt_amd.device import (BloomFilter, Context, and_raw, bf_size_bytes, export_minimizers, sketch,
                                    wrap_bloom)
+    # NTS_BENCH_BACKEND=gloo is a verification mode for boxes with fewer GPUs than ranks (tests/test_gpu_multirank.py):
+    # ranks share the visible GPUs and the collectives run on host copies; the measured configuration is nccl (= RCCL).
+    backend = os.environ.get("NTS_BENCH_BACKEND", "nccl")
+    host_comm = backend != "nccl"
+    if host_comm and torch.cuda.is_available():
+        local_rank = local_rank % torch.cuda.device_count()
+    comm_dev = "cpu" if host_comm else f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if host_comm:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = Context(local_rank)
     ctx.sketch_mode(args.mode, args.prune_c)
     k, w = args.k, args.w
@@ -184,7 +194,12 @@ def main():
         def and_into(a, b):
             and_raw(ctx, a.data_ptr(), b.data_ptr(), a.numel())
             ctx.sync()
-        ndist.allreduce_and(buf, and_into)
+        if host_comm:
+            staged = buf.cpu()
+            ndist.allreduce_and(staged, lambda a, b: a.bitwise_and_(b))
+            buf.copy_(staged)
+        else:
+            ndist.allreduce_and(buf, and_into)
         torch.cuda.synchronize()
         t_allreduce = time.time() - t1
     tmp.free()
@@ -201,6 +216,8 @@ def main():
             rec = torch.empty(n, dtype=torch.int32, device=dev)
             pos = torch.empty(n, dtype=torch.int64, device=dev)
             export_minimizers(ctx, mx, h1.data_ptr(), rec.data_ptr(), pos.data_ptr())
+            if host_comm:
+                h1, rec, pos = h1.cpu(), rec.cpu(), pos.cpu()
             ndist.allgather_lists(h1, rec, pos, gi)
 
     def step():
@@ -230,7 +247,7 @@ def main():
         fence()
         el = time.time() - t_start
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local_rank}")
+            t = torch.tensor([el], dtype=torch.float64, device=comm_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, n_mx

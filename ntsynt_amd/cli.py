@@ -134,8 +134,16 @@ def main(argv=None):
         import torch.distributed as dist
         device = int(os.environ.get("LOCAL_RANK", "0"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # NTS_DIST_BACKEND=gloo: verification mode for boxes with fewer GPUs than ranks (ranks share the GPUs, the
+        # collectives run on host copies: ntsynt_amd/pipeline.py GpuBackend.host_comm); production is nccl (= RCCL)
+        backend = os.environ.get("NTS_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            device %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(device)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
     quiet = (lambda *a, **k: None)
     pipeline.run(fastas, k=args.k, w=args.w, fpr=args.fpr, prefix=args.prefix, w_rounds=args.w_rounds,
                  indel=args.indel, merge=args.merge, block_size=args.block_size, common=not args.no_common,

@@ -75,6 +75,8 @@ class GpuBackend:
         self.own_ctx = ctx is None
         self.ctx = ctx or Context(device)
         self.device = self.ctx.device
+        # collectives on host copies (gloo) instead of device buffers (RCCL): verification mode, see cli.py
+        self.host_comm = os.environ.get("NTS_DIST_BACKEND", "nccl") != "nccl"
 
     # genomes
     def read_host(self, path):
@@ -149,11 +151,25 @@ class GpuBackend:
     def to_comm(self, arr, dtype):
         "numpy -> tensor on the device the collectives use"
         import torch
-        return torch.from_numpy(np.ascontiguousarray(arr).view(dtype)).to(f"cuda:{self.device}")
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(dtype))
+        return t if self.host_comm else t.to(f"cuda:{self.device}")
 
     def comm_empty(self, n, dtype):
         import torch
-        return torch.empty(n, dtype=dtype, device=f"cuda:{self.device}")
+        return torch.empty(n, dtype=dtype, device="cpu" if self.host_comm else f"cuda:{self.device}")
+
+    def allreduce_and(self, bf):
+        "common filter = AND over the ranks' filters, in place"
+        import torch
+        from .dist import allreduce_and
+        self.ctx.sync()
+        if self.host_comm:
+            staged = bf.tensor.cpu()
+            allreduce_and(staged, lambda a, b: a.bitwise_and_(b))
+            bf.tensor.copy_(staged)
+        else:
+            allreduce_and(bf.tensor, self.and_into)
+        torch.cuda.synchronize(bf.tensor.device)
 
     def close(self):
         if self.own_ctx:
@@ -256,12 +272,12 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 if hasattr(tmp, "free"):
                     tmp.free()
         if world > 1:
-            from .dist import allreduce_and
-            backend.sync()
-            allreduce_and(bf.tensor, backend.and_into)
-            if bf.tensor.is_cuda:
-                import torch
-                torch.cuda.synchronize(bf.tensor.device)
+            if hasattr(backend, "allreduce_and"):
+                backend.allreduce_and(bf)
+            else:                                              # test doubles: CPU tensors
+                from .dist import allreduce_and
+                backend.sync()
+                allreduce_and(bf.tensor, backend.and_into)
         log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
         st.stop()
 
