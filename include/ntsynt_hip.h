@@ -52,7 +52,9 @@ void* nts_stream(nts_ctx* ctx);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg).
  * nts_profile(ctx,1) resets and enables; nts_timing() reports total ms and launch count of the
- * kernel called `name` since then ("hash_probe", "window_min", "bf_insert", ...). */
+ * kernel called `name` since then ("hash_probe", "window_min", "bf_insert", ...).  nts_profile(ctx,2) times only
+ * the dominant kernels (hash_select, hash_probe, bf_insert): every event pair costs ~10 us of bubble in the stream,
+ * which a short call feels.  0 disables. */
 int nts_profile(nts_ctx* ctx, int enable);
 int nts_timing(nts_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
 

@@ -65,7 +65,7 @@ struct nts_ctx
   uint8_t* stage = nullptr;     // pinned staging area for small host -> device tables (grow-only)
   size_t stage_bytes = 0;
   std::string err;
-  bool profiling = false;
+  int profiling = 0; // 0 off, 1 every kernel group, 2 only the dominant kernels (an event pair costs ~10 us of stream bubble)
   std::map<std::string, Timing> timings;
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::map<uint32_t, uint64_t*> init_tabs; // per k: device table for the first k-mer of a lane (HashParams::init)
@@ -173,11 +173,13 @@ struct ScopedTimer
   nts_ctx* ctx;
   const char* name;
   hipEvent_t a = nullptr, b = nullptr;
-  ScopedTimer(nts_ctx* c, const char* n)
+  bool on;
+  ScopedTimer(nts_ctx* c, const char* n, bool major = false)
     : ctx(c)
     , name(n)
+    , on(c->profiling == 1 || (c->profiling == 2 && major))
   {
-    if (ctx->profiling) {
+    if (on) {
       a = take();
       b = take();
       hipEventRecord(a, ctx->stream);
@@ -196,7 +198,7 @@ struct ScopedTimer
   }
   ~ScopedTimer()
   {
-    if (ctx->profiling) {
+    if (on) {
       hipEventRecord(b, ctx->stream);
       ctx->pending.push_back({ name, { a, b } });
     }
@@ -1124,7 +1126,7 @@ int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const Genom
   const uint64_t per_block = (uint64_t)HASH_THREADS * HASH_PER_THREAD;
   const uint64_t blocks = d_tile_ids ? n_tile_ids : (rt.n_valid + per_block - 1) / per_block;
   if (blocks > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
-  ScopedTimer t(ctx, name);
+  ScopedTimer t(ctx, name, true);
   hipLaunchKernelGGL(k_hash<MODE>, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, T.d_run_pos,
                      T.d_run_vstart, T.n_runs, rt.n_valid, hp, bf_in ? bf_in->d_words : nullptr, bf_out ? bf_out->d_words : nullptr,
                      fm, keys, d_tile_ids);
@@ -1212,7 +1214,7 @@ int nts_profile(nts_ctx* ctx, int enable)
   if (!ctx) return NTS_EINVAL;
   drain_timings(ctx);
   ctx->timings.clear();
-  ctx->profiling = enable != 0;
+  ctx->profiling = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
   return NTS_OK;
 }
 
@@ -2010,7 +2012,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     S.tile_cnt = d_tcnt;
     S.tile_ordered = d_tord;
     {
-      ScopedTimer t(ctx, filter ? "hash_select" : "hash_select_nofilter");
+      ScopedTimer t(ctx, filter ? "hash_select" : "hash_select_nofilter", true);
       hipLaunchKernelGGL(k_hash_select, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
     }
     {

@@ -39,7 +39,9 @@ class Context:
         self.check(self.lib.nts_sync(self.h), "nts_sync")
 
     def profile(self, enable=True):
-        self.check(self.lib.nts_profile(self.h, 1 if enable else 0), "nts_profile")
+        "True/1: time every kernel group; 2: only the dominant kernels (cheaper for short calls); False/0: off"
+        level = int(enable) if not isinstance(enable, bool) else (1 if enable else 0)
+        self.check(self.lib.nts_profile(self.h, level), "nts_profile")
 
     def timing(self, name):
         ms, n = ctypes.c_double(), u64()
