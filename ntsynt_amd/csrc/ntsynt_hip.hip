@@ -1945,6 +1945,30 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
 #undef DN_WS
 }
 
+// exclusive scan of per-tile / per-workgroup counts: one single-workgroup kernel while the list is short (one launch,
+// ~4 us), the library's two-kernel scan beyond (a single workgroup would take ~0.1 ms over 2*10^5 counts)
+constexpr uint64_t SCAN1_MAX = 32768;
+
+template <typename T>
+int scan_counts(nts_ctx* ctx, const T* d_in, uint64_t n, uint64_t* d_out, uint64_t* d_in64)
+{
+  if (n <= SCAN1_MAX) {
+    hipLaunchKernelGGL(k_scan_excl<T>, dim3(1), dim3(SCAN1_THREADS), 0, ctx->stream, d_in, n, d_out);
+    return NTS_OK;
+  }
+  const uint64_t* src = reinterpret_cast<const uint64_t*>(d_in);
+  if (sizeof(T) != 8) {
+    hipLaunchKernelGGL(k_widen_u64<T>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, d_in64);
+    src = d_in64;
+  }
+  size_t bytes = 0;
+  HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, bytes, src, d_out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
+  void* tmp = ws_get(ctx, "sel_scan_tmp", std::max<size_t>(bytes, 16));
+  if (!tmp) return NTS_ENOMEM;
+  HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, src, d_out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
+  return NTS_OK;
+}
+
 // Pruned path; see nts_pruned.inc.  `res` gets every minimizer, ordered (sparse winners come out ordered by
 // construction; winners of uncovered ranges, if any, are sorted and merged in).
 int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter, uint32_t prune_c,
@@ -1965,8 +1989,8 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   PR_WS(d_toff, uint64_t*, "sel_tile_off", n_kt * 8);
   PR_WS(d_tcnt, uint32_t*, "sel_tile_cnt", n_kt * 4);
   PR_WS(d_tord, uint8_t*, "sel_tile_ord", n_kt);
-  PR_WS(d_tcnt64, uint64_t*, "sel_tile_cnt64", n_kt * 8);
   PR_WS(d_tscan, uint64_t*, "sel_tile_scan", n_kt * 8);
+  PR_WS(d_tcnt64, uint64_t*, "sel_tile_cnt64", (n_kt > SCAN1_MAX ? n_kt : 2) * 8);
   // control block: [0..63] candidate segment counters, [64] uncovered-range counter
   PR_WS(d_ctl, unsigned long long*, "sel_ctl", (N_SEG + 1) * 8);
   const uint64_t gap_cap = V / w + g->n_rec + 16;
@@ -1989,10 +2013,6 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     PR_WS(d_bcnt, uint64_t*, "blk_cnt", n_blk * 8);
     PR_WS(d_bscan, uint64_t*, "blk_scan", n_blk * 8);
     if (!d_sj || !d_sk) return NTS_ENOMEM;
-    size_t scan_bytes = 0, scan_bytes2 = 0;
-    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, d_tcnt64, d_tscan, (uint64_t)0, n_kt, rocprim::plus<uint64_t>(), ctx->stream));
-    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scan_bytes2, d_bcnt, d_bscan, (uint64_t)0, n_blk, rocprim::plus<uint64_t>(), ctx->stream));
-    PR_WS(d_scan_tmp, void*, "sel_scan_tmp", std::max<size_t>(std::max(scan_bytes, scan_bytes2), 16));
     HIP_TRY(ctx, hipMemsetAsync(d_ctl, 0, (N_SEG + 1) * 8, ctx->stream));
     SelParams S;
     S.code = g->d_code + PAD;
@@ -2017,8 +2037,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     }
     {
       ScopedTimer t(ctx, "cand_compact");
-      hipLaunchKernelGGL(k_cnt_to_u64, dim3((uint32_t)((n_kt + 255) / 256)), dim3(256), 0, ctx->stream, d_tcnt, n_kt, d_tcnt64);
-      HIP_TRY(ctx, rocprim::exclusive_scan(d_scan_tmp, scan_bytes, d_tcnt64, d_tscan, (uint64_t)0, n_kt, rocprim::plus<uint64_t>(), ctx->stream));
+      if (int rc_s = scan_counts<uint32_t>(ctx, d_tcnt, n_kt, d_tscan, d_tcnt64)) return rc_s;
       hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)n_kt), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tord, d_tscan, n_kt,
                          d_pj, d_pk, m_max);
     }
@@ -2044,7 +2063,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
       hipLaunchKernelGGL(k_gap_records, dim3((g->n_rec + 255) / 256), dim3(256), 0, ctx->stream, Q);
       // ordered output without a sort: scan the per-workgroup counts, gather (the candidate segments are free again)
-      HIP_TRY(ctx, rocprim::exclusive_scan(d_scan_tmp, scan_bytes2, d_bcnt, d_bscan, (uint64_t)0, n_blk, rocprim::plus<uint64_t>(), ctx->stream));
+      if (int rc_s = scan_counts<uint64_t>(ctx, d_bcnt, n_blk, d_bscan, nullptr)) return rc_s;
       hipLaunchKernelGGL(k_gather_winners, dim3((uint32_t)n_blk), dim3(256), 0, ctx->stream, d_stj, d_stk, d_bcnt, d_bscan, d_sj, d_sk);
     }
     HIP_TRY(ctx, hipGetLastError());
