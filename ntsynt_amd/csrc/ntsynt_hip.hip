@@ -2038,7 +2038,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     {
       ScopedTimer t(ctx, "cand_compact");
       if (int rc_s = scan_counts<uint32_t>(ctx, d_tcnt, n_kt, d_tscan, d_tcnt64)) return rc_s;
-      hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)n_kt), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tord, d_tscan, n_kt,
+      hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)((n_kt + CC_TILES - 1) / CC_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tord, d_tscan, n_kt,
                          d_pj, d_pk, m_max);
     }
     SparseParams Q;
