@@ -89,6 +89,9 @@ struct nts_genome
   uint64_t n = 0; // bytes of concatenated sequence
   uint32_t n_rec = 0;
   uint8_t* d_code = nullptr; // PAD + n + PAD bytes; base i at d_code[PAD + i]
+  // the same bases, 2 bits each, 16 per word (base i in word i/16 at bit 2*(i%16); invalid bases read as 0): the
+  // register-resident base streams of k_hash_select.  Built on first use.
+  mutable uint32_t* d_pack = nullptr;
   std::vector<uint64_t> rec_off, rec_len;
   uint64_t total_bases = 0;
   // maximal stretches [a,b) of valid bases, clipped to records, ascending
@@ -251,6 +254,21 @@ __global__ __launch_bounds__(256) void k_encode(uint8_t* __restrict__ buf, uint6
       buf[j] = (c == 'A') ? 0 : (c == 'C') ? 1 : (c == 'G') ? 2 : (c == 'T' || c == 'U') ? 3 : 4;
     }
   }
+}
+
+// codes (one byte per base) -> 2 bits per base, 16 bases per word; a lane packs 16 bases
+__global__ __launch_bounds__(256) void k_pack2(const uint8_t* __restrict__ code, uint64_t n_words, uint32_t* __restrict__ pack)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_words) return;
+  const uint4 v = *reinterpret_cast<const uint4*>(code + 16 * i);
+  auto pack4 = [](uint32_t x) -> uint32_t { // bytes b0..b3 (2 significant bits each) -> b0 | b1<<2 | b2<<4 | b3<<6
+    x &= 0x03030303u;
+    x |= x >> 6;
+    x |= x >> 12;
+    return x & 0xFFu;
+  };
+  pack[i] = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
 }
 
 // Boundaries of maximal valid stretches.  code points at base 0 (PAD bytes before it are invalid).
@@ -1359,6 +1377,7 @@ void nts_genome_free(nts_ctx* ctx, nts_genome* g)
   }
   if (g->d_rec_off) hipFree(g->d_rec_off);
   if (g->d_code) hipFree(g->d_code);
+  if (g->d_pack) hipFree(g->d_pack);
   delete g;
 }
 
@@ -1945,6 +1964,23 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
 #undef DN_WS
 }
 
+// 2-bit image of the genome for k_hash_select (built once per genome)
+int ensure_pack(nts_ctx* ctx, const nts_genome* g)
+{
+  if (g->d_pack) return NTS_OK;
+  const uint64_t n_words = (g->n + PAD) / 16; // the trailing pad is readable: look-ahead past the last base stays in bounds
+  uint32_t* p = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&p, std::max<uint64_t>(n_words, 1) * 4));
+  if (n_words) hipLaunchKernelGGL(k_pack2, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, g->d_code + PAD, n_words, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    hipFree(p);
+    HIP_TRY(ctx, e);
+  }
+  g->d_pack = p;
+  return NTS_OK;
+}
+
 // exclusive scan of per-tile / per-workgroup counts: one single-workgroup kernel while the list is short (one launch,
 // ~4 us), the library's two-kernel scan beyond (a single workgroup would take ~0.1 ms over 2*10^5 counts)
 constexpr uint64_t SCAN1_MAX = 32768;
@@ -2016,6 +2052,8 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     HIP_TRY(ctx, hipMemsetAsync(d_ctl, 0, (N_SEG + 1) * 8, ctx->stream));
     SelParams S;
     S.code = g->d_code + PAD;
+    if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
+    S.pack = g->d_pack;
     S.run_pos = T.d_run_pos;
     S.run_vstart = T.d_run_vstart;
     S.n_runs = T.n_runs;
