@@ -2017,7 +2017,9 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   // threshold: a fraction c/w of all hashes
   const unsigned __int128 full = ((unsigned __int128)1) << 64;
   unsigned __int128 t128 = full / w * prune_c;
-  const uint64_t tau = t128 >= full - 1 ? KEY_MAX - 1 : (uint64_t)t128;
+  // low 32 bits set: "h0 <= tau" is then a test of the high word alone (k_hash_select's rolling loop relies on it)
+  uint64_t tau = t128 >= full - 1 ? KEY_MAX - 1 : ((uint64_t)t128 | 0xFFFFFFFFULL);
+  if (tau == KEY_MAX) tau = KEY_MAX - 1;
   const double frac = std::min(1.0, (double)prune_c / (double)w);
 #define PR_WS(ptr, type, name, bytes)                                                               \
   type ptr = (type)ws_get(ctx, name, bytes);                                                        \
