@@ -114,7 +114,7 @@ def cpu_baseline(args, contigs, bf_np):
 def pmc_traffic(args, pruned_run):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command).  FETCH_SIZE is
-    corrected by +1/2 of the sequence stream (the guide's gfx950 factor for wide coalesced reads)."""
+    corrected by +1/2 of the sequence stream where the kernel reads it with wide loads (the guide's gfx950 factor)."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     default = (args.mbp, args.genomes, args.divergence, args.k, args.w, args.fpr) == (100.0, 3, 0.01, 24, 1000, 0.025)
     if not (default and os.path.exists(path)):
@@ -123,7 +123,10 @@ def pmc_traffic(args, pruned_run):
     if not k:
         return None
     raw = (k["fetch_MB_per_launch_max"] + k["write_MB_per_launch_max"]) * 1024 * 1024
-    return {"bytes_per_launch": int(raw + 0.5 * args.mbp * 1e6), "raw_fetch_plus_write_bytes": int(raw),
+    # the dense kernel streams the bases with 16-byte loads (FETCH_SIZE counts half of such a stream on gfx950); the
+    # pruned kernel reads the 2-bit image with dword loads, to which that correction does not apply
+    corr = 0.0 if pruned_run else 0.5 * args.mbp * 1e6
+    return {"bytes_per_launch": int(raw + corr), "raw_fetch_plus_write_bytes": int(raw),
             "source": "profiles/r01_pmc_traffic.json"}
 
 
@@ -289,9 +292,9 @@ def main():
         if pruned_run:
             kern, a_ms = "k_hash_select (hash every k-mer, probe candidates only)", avg("hash_select")
             probe_frac = min(1.0, c_used / w)
-            # bytes the pruned kernel has to move per base: the base, one sector per probed candidate,
-            # 16 B per accepted candidate written
-            bpb = 1.0 + SECTOR * probe_frac + 16.0 * cand / per_launch_bases
+            # bytes the pruned kernel has to move per base: the base (2 bits, from the packed image of the genome),
+            # one sector per probed candidate, 16 B per accepted candidate written
+            bpb = 0.25 + SECTOR * probe_frac + 16.0 * cand / per_launch_bases
         else:
             kern, a_ms = "k_hash<MODE_KEYS> (every k-mer probed)", avg("hash_probe")
             bpb = 1.0 + SECTOR + 32.0 / (w + 1)
