@@ -14,6 +14,7 @@ Reference behaviours reproduced on purpose (cited as S:<line> = bin/ntsynt_synte
   * a path whose contig changes keeps only its last run (S:71-77);
   * vertex names compare as decimal strings when normalising flagged pairs (S:351).
 """
+import os
 import re
 import sys
 from dataclasses import dataclass, field
@@ -87,6 +88,9 @@ class SyntenyEngine:
         if scan_fn is None:
             from .graph import scan_paths as scan_fn       # native host helper (nts_path_scan)
         self.scan_fn = scan_fn
+        self.times = {}
+        if os.environ.get("NTS_ENGINE_TIMES"):             # wall clock per step, for scripts/e2e_run.py
+            self._instrument()
         self.log = log or (lambda *a: None)
         self.outputs = {}
         self.stats = {"bubbles": 0, "unoriented": 0, "indel_cuts": 0, "small_blocks": 0, "merged": 0, "eroded_edges": 0}
@@ -103,6 +107,23 @@ class SyntenyEngine:
         self.e_alive = np.zeros(0, bool)
         self._hs = np.zeros(0, np.uint64)                  # live-vertex index: hashes ascending, and their ids
         self._hid = np.zeros(0, np.int64)
+
+    def _instrument(self):
+        import time
+
+        def wrap(name, fn):
+            def timed(*a, **k):
+                t0 = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    self.times[name] = self.times.get(name, 0.0) + time.perf_counter() - t0
+            return timed
+        for name in ("graph_fn", "sketch_fn", "walk_fn", "scan_fn"):
+            setattr(self, name, wrap(name, getattr(self, name)))
+        for name in ("_add_graph", "_simplify", "_degrees", "_paths", "_blocks_of_paths", "_drop_small", "_new_round_graph",
+                     "_refine_graph", "_sorted", "_emit", "_merge", "_find_edges", "_live_index", "_delete_vertices"):
+            setattr(self, name, wrap(name, getattr(self, name)))
 
     # ------------------------------------------------------------------ graph bookkeeping
     def _degrees(self):

@@ -65,6 +65,8 @@ def main():
         out.update({"end_to_end_s": round(wall, 3), "stages_s": {n: round(s, 3) for n, s in eng.stage_times},
                     "blocks": len(tsv.splitlines()) // args.genomes, "engine_stats": eng.stats,
                     "tsv_md5": hashlib.md5(tsv.encode()).hexdigest()})
+        if eng.times:
+            out["engine_times_s"] = {n: round(v, 3) for n, v in sorted(eng.times.items(), key=lambda kv: -kv[1])}
     if args.out:
         with open(args.out, "w") as fh:
             json.dump(out, fh, indent=1)
