@@ -209,30 +209,33 @@ def main():
     ins_ms, ins_n = ctx.timing("bf_insert")
     fpr_final = common.get_fpr()
 
-    def gather(mxs):
-        if world == 1:
-            return
-        for gi, mx in zip(mine, mxs):
-            n = len(mx)
-            dev = f"cuda:{local_rank}"
-            h1 = torch.empty(n, dtype=torch.int64, device=dev)
-            rec = torch.empty(n, dtype=torch.int32, device=dev)
-            pos = torch.empty(n, dtype=torch.int64, device=dev)
-            export_minimizers(ctx, mx, h1.data_ptr(), rec.data_ptr(), pos.data_ptr())
-            if host_comm:
-                h1, rec, pos = h1.cpu(), rec.cpu(), pos.cpu()
-            ndist.allgather_lists(h1, rec, pos, gi)
+    # exchange 2: the rank's lists of a step go out in one all-gather, which runs behind the next
+    # step's kernels (ntsynt_amd/dist.py PackedListGather); slots sized from the minimizer density 2/(w+1)
+    gatherer = None
+    if world > 1:
+        cap = int(3.3 * total_bp / (w + 1)) + 4096    # from the nominal genome size: identical on every rank
+        gatherer = ndist.PackedListGather(len(genomes), cap, f"cuda:{local_rank}", comm_dev)
 
     def step():
-        mxs = [sketch(ctx, g, k, w, common) for g in genomes]
-        gather(mxs)
-        n = sum(len(m) for m in mxs)
-        for m in mxs:
-            m.free()
+        if gatherer is not None:
+            gatherer.begin()
+        n = 0
+        for i, g in enumerate(genomes):
+            mx = sketch(ctx, g, k, w, common)
+            n += len(mx)
+            if gatherer is not None:
+                h1p, recp, posp = gatherer.slot_ptrs(i)
+                export_minimizers(ctx, mx, h1p, recp, posp)
+                gatherer.set_count(i, len(mx), mine[i])
+            mx.free()
+        if gatherer is not None:
+            gatherer.post()
         return n
 
     def fence():
         ctx.sync()
+        if gatherer is not None:
+            gatherer.drain()
         if world > 1:
             dist.barrier()
         if torch.cuda.is_available():

@@ -83,3 +83,78 @@ def allgather_lists(h1, rec, pos, genome_id, group=None):
         sl = slice(r * cap, r * cap + counts[r])
         res.append((gids[r], gh[sl], gr[sl], gp[sl]))
     return res
+
+
+class PackedListGather:
+    """Exchange 2 for a steady stream of steps (bench.py): every rank's minimizer lists travel in ONE all-gather per
+    step -- fixed-capacity slots in a single buffer, counts in a header, no size exchange -- and the collective of
+    step i runs behind the sketch kernels of step i+1 (async on the collective's own stream, two buffer sets).
+
+    Buffer (int64 words): [2 * n_lists header: count, genome id] then per list a slot of h1[cap] | pos[cap] |
+    rec[cap] (int32, packed two per word)."""
+
+    def __init__(self, n_lists, cap, device, comm_device=None, group=None):
+        self.n_lists, self.cap, self.group = int(n_lists), int(cap), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.slot_words = 2 * self.cap + (self.cap + 1) // 2
+        self.words = 2 * self.n_lists + self.n_lists * self.slot_words
+        self.device = torch.device(device)
+        self.comm_device = torch.device(comm_device or device)
+        self.send = [torch.zeros(self.words, dtype=torch.int64, device=self.device) for _ in range(2)]
+        self.stage = [None, None]
+        if self.comm_device != self.device:                # verification mode: collectives on host copies
+            self.stage = [torch.zeros(self.words, dtype=torch.int64, device=self.comm_device) for _ in range(2)]
+        self.recv = [torch.empty(self.world * self.words, dtype=torch.int64, device=self.comm_device) for _ in range(2)]
+        self.pending = [None, None]
+        self.header = torch.zeros(2 * self.n_lists, dtype=torch.int64)
+        self.turn = 0
+
+    def slot_ptrs(self, i):
+        "device addresses (h1, rec, pos) of list i's slot in the buffer being filled"
+        base = self.send[self.turn].data_ptr() + (2 * self.n_lists + i * self.slot_words) * 8
+        return base, base + 2 * self.cap * 8, base + self.cap * 8
+
+    def begin(self):
+        "before filling the next buffer: its previous collective (two steps back) must be over"
+        self._wait(self.turn)
+
+    def set_count(self, i, count, genome_id):
+        if count > self.cap:
+            raise RuntimeError(f"minimizer list of {count} entries exceeds the exchange slot ({self.cap})")
+        self.header[2 * i], self.header[2 * i + 1] = int(count), int(genome_id)
+
+    def post(self):
+        "header in, collective out (asynchronous); returns at once"
+        t = self.turn
+        self.send[t][:2 * self.n_lists].copy_(self.header)
+        src = self.send[t]
+        if self.stage[t] is not None:
+            self.stage[t].copy_(src)
+            src = self.stage[t]
+        if self.world > 1:
+            self.pending[t] = dist.all_gather_into_tensor(self.recv[t], src, group=self.group, async_op=True)
+        self.turn ^= 1
+
+    def _wait(self, t):
+        if self.pending[t] is not None:
+            self.pending[t].wait()
+            self.pending[t] = None
+            if self.comm_device.type == "cuda":
+                torch.cuda.current_stream(self.comm_device).synchronize()
+
+    def drain(self):
+        self._wait(0)
+        self._wait(1)
+
+    def lists_of(self, t):
+        "decode buffer set t after drain(): [(genome id, h1, rec, pos)] of every rank, as views"
+        out = []
+        buf = self.recv[t] if self.world > 1 else self.send[t]
+        for r in range(self.world):
+            b = buf[r * self.words:(r + 1) * self.words]
+            for i in range(self.n_lists):
+                n, gid = int(b[2 * i]), int(b[2 * i + 1])
+                s = b[2 * self.n_lists + i * self.slot_words:][:self.slot_words]
+                rec = s[2 * self.cap:].view(torch.int32)[:n]
+                out.append((gid, s[:n], rec, s[self.cap:self.cap + n]))
+        return out

@@ -85,3 +85,59 @@ def test_partition_and_padding():
         for world in (1, 2, 4, 8):
             n = ndist.padded_len(nbytes, world)
             assert n >= nbytes and n % (16 * world) == 0 and n - nbytes < 16 * world
+
+
+def _packed_worker(rank, world, port, q):
+    import ctypes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_lists, cap = 2, 40
+        pg = ndist.PackedListGather(n_lists, cap, "cpu")
+        seen = []
+        for step in range(3):                       # three steps over two buffer sets: the third reuses the first
+            pg.begin()
+            for i in range(n_lists):
+                cnt = 3 + 5 * rank + 2 * i + step
+                h1p, recp, posp = pg.slot_ptrs(i)   # what nts_mx_export would fill on the device
+                h1 = np.arange(cnt, dtype=np.int64) + 1000 * rank + 100 * i + step
+                rec = np.full(cnt, 10 * rank + i, dtype=np.int32)
+                pos = np.arange(cnt, dtype=np.int64) * (7 + step)
+                ctypes.memmove(h1p, h1.ctypes.data, h1.nbytes)
+                ctypes.memmove(recp, rec.ctypes.data, rec.nbytes)
+                ctypes.memmove(posp, pos.ctypes.data, pos.nbytes)
+                pg.set_count(i, cnt, genome_id=rank * n_lists + i)
+            t = pg.turn
+            pg.post()
+            pg.drain()
+            seen.append([(g, a.numpy().copy(), b.numpy().copy(), c.numpy().copy()) for g, a, b, c in pg.lists_of(t)])
+        q.put((rank, seen))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_packed_list_gather(world):
+    "one all-gather per step carries every rank's lists (fixed slots + header), double-buffered"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_packed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        for step in range(3):
+            got = res[rank][step]
+            assert [g for g, *_ in got] == list(range(2 * world))
+            for r in range(world):
+                for i in range(2):
+                    g, h1, rec, pos = got[2 * r + i]
+                    cnt = 3 + 5 * r + 2 * i + step
+                    assert np.array_equal(h1, np.arange(cnt) + 1000 * r + 100 * i + step)
+                    assert np.array_equal(rec, np.full(cnt, 10 * r + i)) and np.array_equal(pos, np.arange(cnt) * (7 + step))
