@@ -213,7 +213,8 @@ def main():
     # step's kernels (ntsynt_amd/dist.py PackedListGather); slots sized from the minimizer density 2/(w+1)
     gatherer = None
     if world > 1:
-        cap = int(3.3 * total_bp / (w + 1)) + 4096    # from the nominal genome size: identical on every rank
+        # density 2/(w+1) of the nominal genome size + 25 %: identical on every rank, and little padding to ship
+        cap = int(2.5 * total_bp * 1.05 / (w + 1)) + 4096
         gatherer = ndist.PackedListGather(len(genomes), cap, f"cuda:{local_rank}", comm_dev)
 
     def step():
