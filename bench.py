@@ -221,15 +221,21 @@ def main():
         if gatherer is not None:
             gatherer.begin()
         n = 0
+        held = []
         for i, g in enumerate(genomes):
             mx = sketch(ctx, g, k, w, common)
             n += len(mx)
             if gatherer is not None:
                 h1p, recp, posp = gatherer.slot_ptrs(i)
-                export_minimizers(ctx, mx, h1p, recp, posp)
+                export_minimizers(ctx, mx, h1p, recp, posp, wait=False)
                 gatherer.set_count(i, len(mx), mine[i])
-            mx.free()
+                held.append(mx)
+            else:
+                mx.free()
         if gatherer is not None:
+            ctx.sync()                  # the three queued copies: one wait
+            for mx in held:
+                mx.free()
             gatherer.post()
         return n
 

@@ -156,6 +156,9 @@ int nts_mx_download(nts_ctx* ctx, const nts_mx* mx, uint64_t* h1, uint32_t* rec,
 int nts_mx_device_ptrs(const nts_mx* mx, void** h1, void** rec, void** pos);
 /* device-to-device copy into caller buffers of nts_mx_count() elements (send side of the all-gather) */
 int nts_mx_export(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, void* pos_dev);
+/* the same without waiting: the copies are queued on the context's stream; nts_sync() before the buffers are read
+ * by another stream and before the list is freed (several lists, one wait) */
+int nts_mx_export_async(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, void* pos_dev);
 /* build a device list from host arrays (receiving side of the all-gather, tests) */
 int nts_mx_upload(nts_ctx* ctx,
                   const uint64_t* h1,

@@ -67,6 +67,7 @@ SYMBOLS = [
     ("nts_bf_wrap", ctypes.c_int, [c_vp, c_vp, u64, ctypes.POINTER(c_vp)]),
     ("nts_and_raw", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
     ("nts_mx_export", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("nts_mx_export_async", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("nts_sketch", ctypes.c_int, [c_vp, c_vp, u32, u32, c_vp, ctypes.POINTER(Interval), u64,
                                   ctypes.POINTER(c_vp)]),
     ("nts_sketch_mode", ctypes.c_int, [c_vp, ctypes.c_int, u32]),

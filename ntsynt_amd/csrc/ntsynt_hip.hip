@@ -2381,7 +2381,7 @@ int nts_mx_download(nts_ctx* ctx, const nts_mx* mx, uint64_t* h1, uint32_t* rec,
   return NTS_OK;
 }
 
-int nts_mx_export(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, void* pos_dev)
+int nts_mx_export_async(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, void* pos_dev)
 {
   if (!ctx || !mx) return fail(ctx, NTS_EINVAL, "nts_mx_export: bad arguments");
   if (mx->n == 0) return NTS_OK;
@@ -2390,6 +2390,13 @@ int nts_mx_export(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, v
   HIP_TRY(ctx, hipMemcpyAsync(h1_dev, mx->d_h1, mx->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(rec_dev, mx->d_rec, mx->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(pos_dev, mx->d_pos, mx->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  return NTS_OK;
+}
+
+int nts_mx_export(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, void* pos_dev)
+{
+  const int rc = nts_mx_export_async(ctx, mx, h1_dev, rec_dev, pos_dev);
+  if (rc != NTS_OK || mx->n == 0) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return NTS_OK;
 }

@@ -297,6 +297,7 @@ def and_raw(ctx, acc_ptr, other_ptr, nbytes):
     ctx.check(ctx.lib.nts_and_raw(ctx.h, ctypes.c_void_p(acc_ptr), ctypes.c_void_p(other_ptr), int(nbytes)), "nts_and_raw")
 
 
-def export_minimizers(ctx, mx, h1_ptr, rec_ptr, pos_ptr):
-    ctx.check(ctx.lib.nts_mx_export(ctx.h, mx.h, ctypes.c_void_p(h1_ptr), ctypes.c_void_p(rec_ptr),
-                                    ctypes.c_void_p(pos_ptr)), "nts_mx_export")
+def export_minimizers(ctx, mx, h1_ptr, rec_ptr, pos_ptr, wait=True):
+    "device-to-device copy of a list into caller buffers; wait=False: queued only, ctx.sync() before use / mx.free()"
+    fn = ctx.lib.nts_mx_export if wait else ctx.lib.nts_mx_export_async
+    ctx.check(fn(ctx.h, mx.h, ctypes.c_void_p(h1_ptr), ctypes.c_void_p(rec_ptr), ctypes.c_void_p(pos_ptr)), "nts_mx_export")
