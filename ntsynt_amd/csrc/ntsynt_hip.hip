@@ -2073,7 +2073,12 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     S.tile_ordered = d_tord;
     {
       ScopedTimer t(ctx, filter ? "hash_select" : "hash_select_nofilter", true);
-      hipLaunchKernelGGL(k_hash_select, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
+      // a lane rolls 64 k-mers and keeps 64*c/w candidates on average: 8 private slots while that is small, 16 beyond
+      // (a lane that runs out sends its tile through the general path, i.e. hashes it twice)
+      if (64.0 * frac > 2.5)
+        hipLaunchKernelGGL(k_hash_select<16>, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
+      else
+        hipLaunchKernelGGL(k_hash_select<8>, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
     }
     {
       ScopedTimer t(ctx, "cand_compact");
