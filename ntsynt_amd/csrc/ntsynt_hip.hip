@@ -2008,7 +2008,7 @@ int scan_counts(nts_ctx* ctx, const T* d_in, uint64_t n, uint64_t* d_out, uint64
 // Pruned path; see nts_pruned.inc.  `res` gets every minimizer, ordered (sparse winners come out ordered by
 // construction; winners of uncovered ranges, if any, are sorted and merged in).
 int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter, uint32_t prune_c,
-               SortedOut& res)
+               double p_accept, SortedOut& res)
 {
   const RunTable& rt = T.rt;
   const uint64_t V = rt.n_valid;
@@ -2034,7 +2034,8 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   const uint64_t gap_cap = V / w + g->n_rec + 16;
   PR_WS(d_glo, uint64_t*, "gap_lo", gap_cap * 8);
   PR_WS(d_ghi, uint64_t*, "gap_hi", gap_cap * 8);
-  uint64_t cseg_cap = (uint64_t)((double)V * frac * 1.25 / N_SEG) + 8192;
+  // room for the ACCEPTED candidates (share p_accept of the candidates, 1 if unknown); too little is seen and retried
+  uint64_t cseg_cap = (uint64_t)((double)V * frac * std::min(1.0, 1.5 * p_accept + 0.02) * 1.25 / N_SEG) + 8192;
   unsigned long long ctl[N_SEG + 1];
   std::vector<uint64_t> glo(GAP_PEEK), ghi(GAP_PEEK);
   uint64_t m = 0, n_gap = 0, n_sparse = 0;
@@ -2285,11 +2286,13 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   // Pruning policy.  p = share of this genome's k-mers the filter accepts, estimated from occupancies: the
   // genome alone would set about bits*(1-exp(-V/bits)) bits, the common filter kept popcount of them.  A window
   // of w k-mers holds ~c*p accepted candidates when hashes <= (c/w)*2^64 are kept; c*p = 12 leaves ~6e-6 of the
-  // windows uncovered (they are re-evaluated densely).  Below p = 2 % the pruned pass is not worth running.
+  // windows uncovered (they are re-evaluated densely).  The select kernel probes its candidates in batches and keeps
+  // only the accepted ones, so c may grow until a quarter of the k-mers are candidates (p down to 48/w); below that
+  // the dense kernels take over.
   bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= 256);
   uint32_t prune_c = ctx->prune_c;
+  double p = 1.0; // accepted share of the candidates (1 when unknown: sizes the candidate arrays)
   if (pruned && prune_c == 0) {
-    double p = 1.0;
     if (filter) {
       uint64_t pc = 0;
       SK_TRY(nts_bf_popcount(ctx, filter, &pc));
@@ -2297,20 +2300,21 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
       const double own = bits * (1.0 - std::exp(-(double)rt.n_valid / bits));
       p = own > 0 ? std::min(1.0, (double)pc / own) : 1.0;
     }
-    if (p < 0.02 && ctx->sketch_mode == 0) pruned = false;
     // c*p = 12 accepted candidates per window on average.  (More would not empty the list of uncovered ranges:
     // beyond the ~V*(cp/w)*exp(-cp) chance ones there are the stretches the other genomes do not share at all.)
     const double cp = 12.0;
-    prune_c = (uint32_t)std::min(128.0, std::max(8.0, std::ceil(cp / std::max(p, 1e-3))));
-    // more than ~10 % of the k-mers as candidates: the select kernel's staging lists would overflow routinely
-    if (ctx->sketch_mode == 0 && (double)prune_c > 0.1 * (double)w) pruned = false;
+    const double want = std::max(8.0, std::ceil(cp / std::max(p, 1e-4)));
+    // (measured: at a quarter of the k-mers as candidates the pruned pass is still twice as fast as the dense one;
+    // at 40 % single lanes run out of slots in most tiles and it is half as fast)
+    prune_c = (uint32_t)std::min(want, 0.25 * (double)w);
+    if (ctx->sketch_mode == 0 && want > 0.25 * (double)w) pruned = false;
   }
   ctx->last_c = pruned ? prune_c : 0;
 
   for (int attempt = 0;; ++attempt) {
     SortedOut res;
     if (pruned)
-      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, prune_c, res));
+      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, prune_c, p, res));
     else
       SK_TRY(run_dense_sorted(ctx, g, *T, k, w, filter, nullptr, nullptr, nullptr, rt.n_valid, "", res));
     const uint64_t count = res.count; // exact, or an upper bound when the count still lives on the device
