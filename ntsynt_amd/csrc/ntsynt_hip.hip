@@ -2076,6 +2076,12 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       ScopedTimer t(ctx, filter ? "hash_select" : "hash_select_nofilter", true);
       // a lane rolls 64 k-mers and keeps 64*c/w candidates on average: 8 private slots while that is small, 16 beyond
       // (a lane that runs out sends its tile through the general path, i.e. hashes it twice)
+      {
+        const uint32_t slots = 64.0 * frac > 2.5 ? 16u : 8u;
+        // a block of 16 steps adds 16*c/w candidates on average; leave room for three times that plus four
+        const uint32_t need = (uint32_t)std::min(16.0, std::ceil(48.0 * frac + 4.0));
+        S.flush_at = slots == 8 ? 8u : slots - need;
+      }
       if (64.0 * frac > 2.5)
         hipLaunchKernelGGL(k_hash_select<16>, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
       else
