@@ -21,7 +21,9 @@ KMERS = 100.06e6
 
 def short(n):
     m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", n)
-    return m.group(0) if (m and "rocprim" not in n) else None
+    if not m or "rocprim" in n:
+        return None
+    return m.group(1) if m.group(1) == "k_hash_select" else m.group(0)   # (slot-count template: one row)
 
 
 def main():
