@@ -28,6 +28,16 @@ def test_three_gbp_genome_sketch_properties_and_slice_parity(ctx):
     common.insert(g0)
     occ0 = common.get_fpr()
     assert abs(occ0 - 0.025) < 0.001                # ~ -expm1(-n/m): the sizing rule's target occupancy
+    # the partitioned build (two bucket levels at this size) and one atomic per k-mer set the same 14.8 GB of bits
+    ctx.bf_build_mode("atomic")
+    atomic = BloomFilter(ctx, nbytes, k)
+    atomic.insert(g0)
+    ctx.bf_build_mode("auto")
+    n_bits = common.popcount()
+    assert atomic.popcount() == n_bits
+    atomic.and_(common)
+    assert atomic.popcount() == n_bits              # same count and a full intersection: the same set
+    atomic.free()
     other = BloomFilter(ctx, nbytes, k)
     other.insert(g1)
     common.and_(other)
