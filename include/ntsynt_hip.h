@@ -226,6 +226,18 @@ void nts_graph_free(nts_graph* g);
 int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, const uint32_t* e_v,
                     uint64_t** off, uint32_t** verts, uint64_t* n_paths);
 
+/* The same walk on the engine's own arrays: 64-bit edge ends, an optional liveness byte per edge (NULL = all
+ * live) and an optional per-vertex key: with a key, each path is written starting at the end with the smaller
+ * key (row C5: ntJoin's find_paths, called at bin/ntsynt_synteny.py:620, starts a path at the end with the
+ * smaller position in the reference assembly) while the paths keep the order above (ascending smaller-id end). */
+int nts_walk_paths(uint64_t nv, uint64_t ne, const int64_t* e_u, const int64_t* e_v, const uint8_t* e_alive,
+                   const int64_t* key, uint64_t** off, int64_t** verts, uint64_t* n_paths);
+
+/* Host-side helper: deg[v] = number of live edge ends at v, saturating at 255 (bubble detection asks
+ * "degree 3", bin/ntsynt_synteny.py:548-590; path ends ask "degree 1"). */
+int nts_edge_degrees(uint64_t nv, uint64_t ne, const int64_t* e_u, const int64_t* e_v, const uint8_t* e_alive,
+                     uint8_t* deg);
+
 /* Host-side helper (no GPU work, host threads): one pass over the paths of a round -- path i is
  * verts[off[i] .. off[i+1]) -- against the per-assembly vertex tables v_rec / v_pos ([a*nv + v]):
  *   start[i]          index into verts of the first vertex kept: a path whose contig changes in any assembly

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libntsynt_hip.so")
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
 c_u64p = ctypes.POINTER(ctypes.c_uint64)
 c_vp = ctypes.c_void_p
 u32, u64 = ctypes.c_uint32, ctypes.c_uint64
@@ -81,6 +82,8 @@ SYMBOLS = [
     ("nts_hash_all", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_u64p), c_u64p]),
     ("nts_graph_build", ctypes.c_int, [c_vp, u32, ctypes.POINTER(MxList), ctypes.POINTER(Graph)]),
     ("nts_walk_chains", ctypes.c_int, [u64, u64, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_u32p), c_u64p]),
+    ("nts_walk_paths", ctypes.c_int, [u64, u64, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_i64p), c_u64p]),
+    ("nts_edge_degrees", ctypes.c_int, [u64, u64, c_vp, c_vp, c_vp, c_vp]),
     ("nts_path_scan", ctypes.c_int, [u32, u64, c_vp, c_vp, u64, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, c_vp]),
     ("nts_graph_free", None, [ctypes.POINTER(Graph)]),
     ("nts_fasta_read", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Fasta)]),

@@ -330,8 +330,13 @@ void parallel_ranges(uint64_t n, unsigned n_threads, F&& body)
 // cache miss on a multi-million-vertex graph, so the walks are spread over host threads: each degree-1 vertex walks
 // to the other end of its chain and the walk that started at the smaller vertex id is the one kept, which is the
 // path (and the order, by ascending first vertex) a sequential sweep over the vertex ids yields.
-extern "C" int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, const uint32_t* e_v, uint64_t** off, uint32_t** verts,
-                               uint64_t* n_paths)
+//
+// EdgeT/OutT let the engine hand over its int64 edge arrays and liveness mask as they are and get int64 vertex ids
+// back (no conversion passes); `key`, when given, orients each path to start at the end with the smaller key
+// (ntJoin's determine_source_vertex on reference positions) without changing the order of the paths.
+template <typename EdgeT, typename OutT>
+static int walk_impl(uint64_t nv, uint64_t ne, const EdgeT* e_u, const EdgeT* e_v, const uint8_t* e_alive, const int64_t* key, uint64_t** off,
+                     OutT** verts, uint64_t* n_paths)
 {
   if (!off || !verts || !n_paths || (ne && (!e_u || !e_v)) || nv > 0xFFFFFFFEULL) return NTS_EINVAL;
   const unsigned T = host_threads(16);
@@ -357,13 +362,14 @@ extern "C" int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, co
       if (c < 2) nb[2 * (uint64_t)x + c] = other;
     };
     for (uint64_t e = 0; e < ne; ++e) {
-      const uint32_t u = e_u[e], v = e_v[e];
+      if (e_alive && !e_alive[e]) continue;
+      const uint64_t u = (uint64_t)e_u[e], v = (uint64_t)e_v[e];
       if (u >= nv || v >= nv) {
         bad.store(true);
         return;
       }
-      touch(u, v);
-      touch(v, u);
+      touch((uint32_t)u, (uint32_t)v);
+      touch((uint32_t)v, (uint32_t)u);
     }
   });
   if (bad.load()) return NTS_EINVAL;
@@ -435,16 +441,29 @@ extern "C" int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, co
   }
   *n_paths = total_paths;
   *off = (uint64_t*)malloc((total_paths + 1) * sizeof(uint64_t));
-  *verts = (uint32_t*)malloc(std::max<uint64_t>(total_verts, 1) * sizeof(uint32_t));
+  *verts = (OutT*)malloc(std::max<uint64_t>(total_verts, 1) * sizeof(OutT));
   if (!*off || !*verts) return NTS_ENOMEM;
+  std::vector<uint64_t> kept_at; // output offset of every kept walk, ascending first vertex
+  kept_at.reserve(total_paths);
   uint64_t po = 0, vo = 0;
   (*off)[0] = 0;
-  for (const Kept& k : kept) { // ascending first vertex
-    if (!k.len) continue;
-    memcpy(*verts + vo, t_out[k.thread].data() + k.begin, k.len * sizeof(uint32_t));
-    vo += k.len;
+  for (uint64_t i = 0; i < kept.size(); ++i) {
+    if (!kept[i].len) continue;
+    kept_at.push_back(i);
+    vo += kept[i].len;
     (*off)[++po] = vo;
   }
+  parallel_ranges(total_paths, T, [&](unsigned, uint64_t lo, uint64_t hi) {
+    for (uint64_t p = lo; p < hi; ++p) {
+      const Kept& k = kept[kept_at[p]];
+      const uint32_t* src = t_out[k.thread].data() + k.begin;
+      OutT* dst = *verts + (*off)[p];
+      if (key && key[src[k.len - 1]] < key[src[0]])
+        for (uint64_t j = 0; j < k.len; ++j) dst[j] = (OutT)src[k.len - 1 - j];
+      else
+        for (uint64_t j = 0; j < k.len; ++j) dst[j] = (OutT)src[j];
+    }
+  });
   lap("concatenate");
   if (debug) {
     uint64_t longest = 0, steps = 0;
@@ -456,6 +475,42 @@ extern "C" int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, co
             (unsigned long long)steps);
   }
   return NTS_OK;
+}
+
+extern "C" int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, const uint32_t* e_v, uint64_t** off, uint32_t** verts,
+                               uint64_t* n_paths)
+{
+  return walk_impl<uint32_t, uint32_t>(nv, ne, e_u, e_v, nullptr, nullptr, off, verts, n_paths);
+}
+
+extern "C" int nts_walk_paths(uint64_t nv, uint64_t ne, const int64_t* e_u, const int64_t* e_v, const uint8_t* e_alive, const int64_t* key,
+                              uint64_t** off, int64_t** verts, uint64_t* n_paths)
+{
+  return walk_impl<int64_t, int64_t>(nv, ne, e_u, e_v, e_alive, key, off, verts, n_paths);
+}
+
+// Degree of every vertex over the live edges, saturating at 255 (the engine asks "== 1" and "== 3").
+extern "C" int nts_edge_degrees(uint64_t nv, uint64_t ne, const int64_t* e_u, const int64_t* e_v, const uint8_t* e_alive, uint8_t* deg)
+{
+  if ((nv && !deg) || (ne && (!e_u || !e_v))) return NTS_EINVAL;
+  std::atomic<bool> bad(false);
+  parallel_ranges(nv, host_threads(16), [&](unsigned, uint64_t lo, uint64_t hi) {
+    memset(deg + lo, 0, hi - lo);
+    auto touch = [&](uint64_t x) {
+      if (x >= lo && x < hi && deg[x] != 255) ++deg[x];
+    };
+    for (uint64_t e = 0; e < ne; ++e) {
+      if (e_alive && !e_alive[e]) continue;
+      const uint64_t u = (uint64_t)e_u[e], v = (uint64_t)e_v[e];
+      if (u >= nv || v >= nv) {
+        bad.store(true);
+        return;
+      }
+      touch(u);
+      touch(v);
+    }
+  });
+  return bad.load() ? NTS_EINVAL : NTS_OK;
 }
 
 // ---- per-path scan (rows C6-C8) -------------------------------------------------------------------------------

@@ -64,6 +64,47 @@ def walk_chains(nv, e_u, e_v):
     return o, v
 
 
+def walk_paths(nv, e_u, e_v, e_alive=None, key=None):
+    """walk_chains on the engine's own arrays (nts_walk_paths): int64 edge ends, optional liveness mask, optional
+    per-vertex key that orients each path (smaller key first).  -> (offsets int64[n_paths+1], vertices int64[])."""
+    lib = _lib.load()
+    eu = np.ascontiguousarray(e_u, dtype=np.int64)
+    ev = np.ascontiguousarray(e_v, dtype=np.int64)
+    al = None if e_alive is None else np.ascontiguousarray(e_alive, dtype=np.uint8 if e_alive.dtype != np.bool_ else np.bool_)
+    ky = None if key is None else np.ascontiguousarray(key, dtype=np.int64)
+    if (al is not None and al.size != eu.size) or (ky is not None and ky.size != int(nv)) or ev.size != eu.size:
+        raise ValueError("walk_paths: array sizes disagree")
+    off, verts, n = _lib.c_u64p(), _lib.c_i64p(), _lib.u64()
+    rc = lib.nts_walk_paths(int(nv), eu.size, eu.ctypes.data, ev.ctypes.data, al.ctypes.data if al is not None else None,
+                            ky.ctypes.data if ky is not None else None, ctypes.byref(off), ctypes.byref(verts), ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"nts_walk_paths failed ({rc})")
+    o = np.ctypeslib.as_array(off, shape=(n.value + 1,)).astype(np.int64, copy=True)
+    v = np.ctypeslib.as_array(verts, shape=(max(int(o[-1]), 1),))[:int(o[-1])].copy()
+    lib.nts_free(off)
+    lib.nts_free(verts)
+    return o, v
+
+
+walk_paths.oriented = True      # tells SyntenyEngine._paths to hand over the mask and the orientation key
+
+
+def edge_degrees(nv, e_u, e_v, e_alive=None):
+    """uint8[nv] live degree of every vertex, saturating at 255 (nts_edge_degrees, host threads)."""
+    lib = _lib.load()
+    eu = np.ascontiguousarray(e_u, dtype=np.int64)
+    ev = np.ascontiguousarray(e_v, dtype=np.int64)
+    al = None if e_alive is None else np.ascontiguousarray(e_alive, dtype=np.uint8 if e_alive.dtype != np.bool_ else np.bool_)
+    if (al is not None and al.size != eu.size) or ev.size != eu.size:
+        raise ValueError("edge_degrees: array sizes disagree")
+    deg = np.empty(int(nv), np.uint8)
+    rc = lib.nts_edge_degrees(int(nv), eu.size, eu.ctypes.data, ev.ctypes.data, al.ctypes.data if al is not None else None,
+                              deg.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"nts_edge_degrees failed ({rc})")
+    return deg
+
+
 def scan_paths(v_rec, v_pos, off, verts, bp):
     """Per-path scan (nts_path_scan, host threads): (start int64[n_paths], n_up int64[G, n_paths], over bool[len(verts)])
     for paths verts[off[i]:off[i+1]] against the [G, nv] vertex tables."""

@@ -19,6 +19,7 @@ import time
 import numpy as np
 
 from . import fasta as fa
+from .graph import edge_degrees
 from .synteny import SyntenyEngine
 
 
@@ -144,9 +145,10 @@ class GpuBackend:
         from .graph import build_graph_device
         return build_graph_device(self.ctx, lists, keeps, list_ids)
 
-    def walk(self, nv, eu, ev):
-        from .graph import walk_chains
-        return walk_chains(nv, eu, ev)
+    def walk(self, nv, eu, ev, e_alive=None, key=None):
+        from .graph import walk_paths
+        return walk_paths(nv, eu, ev, e_alive, key)
+    walk.oriented = True
 
     def to_comm(self, arr, dtype):
         "numpy -> tensor on the device the collectives use"
@@ -312,7 +314,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     else:
         out_prefix = prefix
     eng = SyntenyEngine(tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size, out_prefix,
-                        backend.graph, sketch_fn, backend.walk, simplify=simplify, log=log)
+                        backend.graph, sketch_fn, backend.walk, simplify=simplify, log=log, degree_fn=edge_degrees)
     eng.run(initial)
     if rank != 0:
         eng.outputs = {os.path.basename(n): t for n, t in eng.outputs.items()}

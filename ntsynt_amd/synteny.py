@@ -67,7 +67,7 @@ class SyntenyEngine:
     walk_fn / scan_fn: chain walk and per-path scan (native host helpers nts_walk_chains / nts_path_scan)."""
 
     def __init__(self, files, contig_names, k, w, w_rounds, bp, collinear_merge, z, prefix, graph_fn, sketch_fn,
-                 walk_fn, simplify=True, m=90, n=0, log=None, scan_fn=None):
+                 walk_fn, simplify=True, m=90, n=0, log=None, scan_fn=None, degree_fn=None):
         order = sorted(range(len(files)), key=lambda i: files[i], reverse=True)
         self.input_order = order                       # engine index a -> caller's assembly index
         self.files = [files[i] for i in order]
@@ -88,6 +88,7 @@ class SyntenyEngine:
         if scan_fn is None:
             from .graph import scan_paths as scan_fn       # native host helper (nts_path_scan)
         self.scan_fn = scan_fn
+        self.degree_fn = degree_fn
         self.times = {}
         if os.environ.get("NTS_ENGINE_TIMES"):             # wall clock per step, for scripts/e2e_run.py
             self._instrument()
@@ -118,8 +119,9 @@ class SyntenyEngine:
                     return fn(*a, **k)
                 finally:
                     self.times[name] = self.times.get(name, 0.0) + time.perf_counter() - t0
+            timed.oriented = getattr(fn, "oriented", False)
             return timed
-        for name in ("graph_fn", "sketch_fn", "walk_fn", "scan_fn"):
+        for name in ("graph_fn", "sketch_fn", "walk_fn", "scan_fn") + (("degree_fn",) if self.degree_fn else ()):
             setattr(self, name, wrap(name, getattr(self, name)))
         for name in ("_add_graph", "_simplify", "_degrees", "_paths", "_blocks_of_paths", "_drop_small", "_new_round_graph",
                      "_refine_graph", "_sorted", "_emit", "_merge", "_find_edges", "_live_index", "_delete_vertices"):
@@ -127,6 +129,8 @@ class SyntenyEngine:
 
     # ------------------------------------------------------------------ graph bookkeeping
     def _degrees(self):
+        if self.degree_fn is not None:                         # nts_edge_degrees (saturates at 255; users ask == 1 / == 3)
+            return self.degree_fn(self.v_hash.size, self.e_u, self.e_v, self.e_alive)
         m = self.e_alive
         n = self.v_hash.size
         return np.bincount(self.e_u[m], minlength=n) + np.bincount(self.e_v[m], minlength=n)
@@ -178,10 +182,11 @@ class SyntenyEngine:
             self.v_alive = np.ones(ga.v_hash.size, bool)
             self.v_rec = np.ascontiguousarray(ga.occ_rec, dtype=np.int64)
             self.v_pos = np.ascontiguousarray(ga.occ_pos, dtype=np.int64)
-            order = np.arange(ga.v_hash.size, dtype=np.int64)
             if ga.v_hash.size > 1 and not (ga.v_hash[1:] > ga.v_hash[:-1]).all():
                 order = np.argsort(ga.v_hash, kind="stable")
-            self._hs, self._hid = self.v_hash[order], order
+                self._hs, self._hid = self.v_hash[order], order
+            else:                                              # (neither array is ever written in place)
+                self._hs, self._hid = self.v_hash, local_to_global
         else:
             # per hash, the live vertex carrying it (a deleted vertex may share its hash with a re-created one)
             hs, hid = self._live_index()
@@ -209,7 +214,9 @@ class SyntenyEngine:
                 new_ids = nv0 + np.arange(new.size)
             at = np.searchsorted(hs, nh)
             self._hs, self._hid = np.insert(hs, at, nh), np.insert(hid, at, new_ids)
-        if ga.dict_ordered:
+        if ga.dict_ordered and nv0 == 0:                       # first build: local ids are the global ids
+            eu, ev, ew = ga.e_u.astype(np.int64), ga.e_v.astype(np.int64), ga.e_w.astype(np.int64)
+        elif ga.dict_ordered:
             eu, ev, ew = local_to_global[ga.e_u], local_to_global[ga.e_v], ga.e_w.astype(np.int64)
         else:
             order = dict_order(ga.e_u, ga.e_first, ga.v_hash.size)
@@ -225,9 +232,12 @@ class SyntenyEngine:
                     dup[old[ok]] = True
                     self.e_w[hit] = ew[dup]
                     eu, ev, ew = eu[~dup], ev[~dup], ew[~dup]
-        self.e_u = np.concatenate((self.e_u, eu))
-        self.e_v = np.concatenate((self.e_v, ev))
-        self.e_w = np.concatenate((self.e_w, ew))
+        if self.e_u.size == 0:
+            self.e_u, self.e_v, self.e_w = eu, ev, ew
+        else:
+            self.e_u = np.concatenate((self.e_u, eu))
+            self.e_v = np.concatenate((self.e_v, ev))
+            self.e_w = np.concatenate((self.e_w, ew))
         self.e_alive = np.concatenate((self.e_alive, np.ones(eu.size, bool)))
         return local_to_global
 
@@ -268,12 +278,15 @@ class SyntenyEngine:
     # Paths are handled as one concatenated vertex array + offsets; every rule below is a segment operation.
     def _paths(self):
         m = self.e_alive
-        off, verts = self.walk_fn(self.v_hash.size, self.e_u[m], self.e_v[m])
-        if off.size < 2:
-            return verts, off
         # start at the end with the smaller position in the reference assembly (ntJoin's
         # determine_source_vertex; two vertices never share a position in one assembly)
         ref_pos = self.v_pos[self.ref]
+        if getattr(self.walk_fn, "oriented", False):           # nts_walk_paths: mask and orientation handled natively
+            off, verts = self.walk_fn(self.v_hash.size, self.e_u, self.e_v, e_alive=m, key=ref_pos)
+            return verts, off
+        off, verts = self.walk_fn(self.v_hash.size, self.e_u[m], self.e_v[m])
+        if off.size < 2:
+            return verts, off
         flip = ref_pos[verts[off[1:] - 1]] < ref_pos[verts[off[:-1]]]
         if flip.any():
             seg = np.repeat(np.arange(off.size - 1), np.diff(off))

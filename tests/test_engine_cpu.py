@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from ntsynt_amd import synth
-from ntsynt_amd.graph import walk_chains
+from ntsynt_amd.graph import edge_degrees, walk_chains, walk_paths
 from ntsynt_amd.synteny import SyntenyEngine
 from oracle import nts_oracle as O
 from oracle import synteny_oracle as SO
@@ -18,7 +18,7 @@ from tests.graph_ref import build_graph_numpy
 from tests.helpers import oracle_flat
 
 
-def run_both(tmp_path, paths, k, w, w_rounds, indel, merge, block_size, simplify=True, common=True):
+def run_both(tmp_path, paths, k, w, w_rounds, indel, merge, block_size, simplify=True, common=True, native=True):
     os.makedirs(tmp_path / "ora", exist_ok=True)
     os.makedirs(tmp_path / "eng", exist_ok=True)
     os.chdir(tmp_path / "ora")
@@ -44,7 +44,8 @@ def run_both(tmp_path, paths, k, w, w_rounds, indel, merge, block_size, simplify
         return oracle_flat(O.minimize(O.Genome(g.names, seqs), k, new_w, bf))
 
     eng = SyntenyEngine(tsvs, [g.names for g in genomes], k, w, w_rounds, indel, merge, block_size, "p",
-                        build_graph_numpy, sketch_fn, walk_chains, simplify=simplify)
+                        build_graph_numpy, sketch_fn, walk_paths if native else walk_chains, simplify=simplify,
+                        degree_fn=edge_degrees if native else None)
     out = eng.run(initial)
     return ora.outputs, out
 
@@ -77,6 +78,62 @@ def test_engine_matches_oracle(tmp_path, case):
     for name in got:
         assert got[name] == exp[name], name
     assert len(got["p.synteny_blocks.tsv"].splitlines()) >= 2 * n
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[5]], ids=["case0", "case2", "case5"])
+def test_engine_with_plain_walk_and_numpy_degrees(tmp_path, case):
+    """The engine's numpy orientation / degree code (used when walk_fn is nts_walk_chains and no degree_fn is given)
+    against the oracle; the product configuration (nts_walk_paths + nts_edge_degrees) is the test above."""
+    n, bp, ctg, div, seed, k, w, rounds, indel, merge, block = case
+    cwd = os.getcwd()
+    try:
+        paths = synth.make_family(str(tmp_path), n, bp, ctg, div, seed=seed, n_runs=(seed % 2 == 0),
+                                  micro=(12 if seed % 3 == 0 else 0))
+        exp, got = run_both(tmp_path, paths, k, w, rounds, indel, merge, block, native=False)
+    finally:
+        os.chdir(cwd)
+    for name in got:
+        assert got[name] == exp[name], name
+
+
+def test_walk_paths_mask_and_orientation():
+    """nts_walk_paths (int64 edges, liveness mask, orientation key) == nts_walk_chains on the live edges followed by
+    the flip rule; nts_edge_degrees == bincount."""
+    rng = np.random.default_rng(5)
+    nv = 150_000
+    perm = rng.permutation(nv)
+    brk = np.zeros(nv, bool)
+    brk[rng.choice(np.arange(1, nv), size=nv // 9, replace=False)] = True
+    eu, ev = perm[:-1][~brk[1:]], perm[1:][~brk[1:]]
+    xu, xv = rng.integers(0, nv, eu.size // 4), rng.integers(0, nv, eu.size // 4)
+    EU, EV = np.concatenate((eu, xu)).astype(np.int64), np.concatenate((ev, xv)).astype(np.int64)
+    alive = np.concatenate((np.ones(eu.size, bool), np.zeros(xu.size, bool)))
+    sh = rng.permutation(EU.size)
+    EU, EV, alive = EU[sh], EV[sh], alive[sh]
+    key = rng.permutation(nv).astype(np.int64)
+    o1, v1 = walk_chains(nv, EU[alive], EV[alive])
+    flip = key[v1[o1[1:] - 1]] < key[v1[o1[:-1]]]
+    assert 0.3 < flip.mean() < 0.7
+    seg = np.repeat(np.arange(o1.size - 1), np.diff(o1))
+    j = np.arange(v1.size)
+    want = v1[np.where(flip[seg], o1[seg] + o1[seg + 1] - 1 - j, j)]
+    o2, v2 = walk_paths(nv, EU, EV, alive, key)
+    assert np.array_equal(o1, o2) and np.array_equal(want, v2) and v2.dtype == np.int64
+    o3, v3 = walk_paths(nv, EU[alive], EV[alive])
+    assert np.array_equal(o3, o1) and np.array_equal(v3, v1)
+    # dead edges that would branch a chain must not matter; live ones must
+    o4, v4 = walk_paths(nv, EU, EV)
+    assert o4.size < o1.size
+    deg = edge_degrees(nv, EU, EV, alive)
+    ref = np.bincount(EU[alive], minlength=nv) + np.bincount(EV[alive], minlength=nv)
+    assert deg.dtype == np.uint8 and np.array_equal(deg, np.minimum(ref, 255))
+    hub_u = np.concatenate((EU, np.zeros(400, np.int64)))
+    hub_v = np.concatenate((EV, np.arange(1, 401, dtype=np.int64)))
+    assert edge_degrees(nv, hub_u, hub_v)[0] == 255
+    with pytest.raises(RuntimeError):
+        edge_degrees(10, np.array([11], np.int64), np.array([0], np.int64))
+    with pytest.raises(RuntimeError):
+        walk_paths(10, np.array([11], np.int64), np.array([0], np.int64))
 
 
 def test_engine_without_simplification(tmp_path):
