@@ -36,7 +36,11 @@ __host__ __device__ __forceinline__ uint64_t sror1(uint64_t x)
 #if defined(__HIP_DEVICE_COMPILE__)
   const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
   const uint32_t lo2 = __builtin_amdgcn_alignbit(hi, lo, 1);         // (lo >> 1) | (hi << 31): bit 32 moves to bit 31
-  const uint32_t hi2 = ((hi >> 1) & 0x7FFFFFFEu) | ((hi & 2u) << 30) | (lo & 1u); // bit 33 -> 63, bit 0 -> 32
+  // bit 0 -> 32, bits 34..63 move down, bit 33 -> 63: four operations (written with the bit-field insert spelled out;
+  // left to itself the optimiser rewrites it as three masks and a three-way or)
+  uint32_t low;
+  asm("v_bfi_b32 %0, 1, %1, %2" : "=v"(low) : "v"(lo), "v"(hi >> 1)); // (lo & 1) | ((hi >> 1) & ~1)
+  const uint32_t hi2 = ((hi & 2u) << 30) | low;
   return ((uint64_t)hi2 << 32) | lo2;
 #else
   const uint64_t m = ((x & 0x200000000ULL) << 30) | ((x & 1ULL) << 32);
@@ -56,12 +60,15 @@ __host__ __device__ __forceinline__ uint64_t extend_h1(uint64_t h0, uint32_t k)
 //   roll_r[cin*4+cout] = srol^k(seed[3-cin]) ^ seed[3-cout]         (reverse strand update)
 //   init[(i*4 + b)*2 + {0,1}] = { srol^(k-1-i)(seed[b]), srol^i(seed[3-b]) }   (device memory; the hash of a
 //                                lane's first k-mer is the XOR of k such pairs: no rotations, independent loads)
+//   init4[(g*256 + v)*2 + {0,1}] = XOR over j < 4, 4g+j < k of init[4g+j][(v >> 2j) & 3]: the same sum taken four
+//                                bases (one byte of the 2-bit genome image) at a time, ceil(k/4) table reads per k-mer
 struct HashParams
 {
   uint64_t seed[4];
   uint64_t roll_f[16];
   uint64_t roll_r[16];
-  const uint64_t* init; // [k][4][2]
+  const uint64_t* init;  // [k][4][2]
+  const uint64_t* init4; // [ceil(k/4)][256][2]
   uint32_t k;
 };
 
@@ -78,6 +85,32 @@ __device__ __forceinline__ void hash_init(const HashParams& hp, BaseAt&& base, u
     for (uint32_t q = 0; q < 8; ++q) {
       e[q] = make_ulonglong2(0, 0);
       if (i0 + q < hp.k) e[q] = tab[(i0 + q) * 4u + base(i0 + q)];
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) {
+      f ^= e[q].x;
+      r ^= e[q].y;
+    }
+  }
+}
+
+// The same for a k-mer of at most 64 bases held 2 bits per base in four words (base i = bits 2i.. of the 128-bit
+// string): one table read per four bases.
+__device__ __forceinline__ void hash_init_packed(const HashParams& hp, const uint32_t (&bases)[4], uint64_t& f, uint64_t& r)
+{
+  f = 0;
+  r = 0;
+  const ulonglong2* tab = reinterpret_cast<const ulonglong2*>(hp.init4);
+  const uint32_t ng = (hp.k + 3u) >> 2;
+#pragma unroll
+  for (uint32_t g0 = 0; g0 < 16; g0 += 8) {
+    if (g0 >= ng) break;
+    ulonglong2 e[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) {
+      const uint32_t g = g0 + q;
+      e[q] = make_ulonglong2(0, 0);
+      if (g < ng) e[q] = tab[g * 256u + ((bases[g >> 2] >> (8u * (g & 3u))) & 255u)];
     }
 #pragma unroll
     for (uint32_t q = 0; q < 8; ++q) {

@@ -860,6 +860,7 @@ HashParams make_hash_params(uint32_t k)
     }
   hp.k = k;
   hp.init = nullptr;
+  hp.init4 = nullptr;
   return hp;
 }
 
@@ -869,7 +870,8 @@ int hash_params_for(nts_ctx* ctx, uint32_t k, HashParams* out)
   *out = make_hash_params(k);
   auto it = ctx->init_tabs.find(k);
   if (it == ctx->init_tabs.end()) {
-    std::vector<uint64_t> tab((size_t)k * 8);
+    const uint32_t ng = (k + 3) / 4;
+    std::vector<uint64_t> tab((size_t)k * 8 + (size_t)ng * 512);
     const uint64_t seed[4] = { SEED_A, SEED_C, SEED_G, SEED_T };
     for (int b = 0; b < 4; ++b) {
       uint64_t x = seed[3 - b]; // srol^i(seed[3-b]), i ascending
@@ -883,6 +885,18 @@ int hash_params_for(nts_ctx* ctx, uint32_t k, HashParams* out)
         y = srol1(y);
       }
     }
+    uint64_t* tab4 = tab.data() + (size_t)k * 8; // four bases at a time (bases past k do not count)
+    for (uint32_t g = 0; g < ng; ++g)
+      for (uint32_t v = 0; v < 256; ++v) {
+        uint64_t f = 0, r = 0;
+        for (uint32_t j = 0; j < 4 && 4 * g + j < k; ++j) {
+          const uint32_t b = (v >> (2 * j)) & 3u;
+          f ^= tab[((size_t)(4 * g + j) * 4 + b) * 2];
+          r ^= tab[((size_t)(4 * g + j) * 4 + b) * 2 + 1];
+        }
+        tab4[((size_t)g * 256 + v) * 2] = f;
+        tab4[((size_t)g * 256 + v) * 2 + 1] = r;
+      }
     uint64_t* d = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d, tab.size() * 8));
     hipError_t e = hipMemcpy(d, tab.data(), tab.size() * 8, hipMemcpyHostToDevice);
@@ -893,6 +907,7 @@ int hash_params_for(nts_ctx* ctx, uint32_t k, HashParams* out)
     it = ctx->init_tabs.emplace(k, d).first;
   }
   out->init = it->second;
+  out->init4 = it->second + (size_t)k * 8;
   return NTS_OK;
 }
 
