@@ -5,7 +5,9 @@
 
 A "step" is one pass of the sketch (canonical ntHash + common-Bloom probe + window-of-w argmin,
 rows B1-B3) over the rank's batch of synthetic genomes, which are resident in HBM (together with
-the common Bloom filter) before the timed region starts; for N>1 the step ends with the all-gather
+the common Bloom filter) before the timed region starts -- as one resident genome whose records are
+those of genome 0, then 1, ... (nts_genome_concat), so that one sequence of launches sketches the batch
+(--no-batch: one sequence per genome); for N>1 the step ends with the all-gather
 of the minimizer lists (SURVEY.md 8(e) exchange 2).  Weak scaling: every rank holds its own
 `--genomes` genomes of one family of N*genomes genomes; the common Bloom filter is the AND over the
 whole family (exchange 1, timed separately and reported under "bloom").  The family's pairwise divergence
@@ -49,6 +51,7 @@ def parse():
     ap.add_argument("--prune-c", type=int, default=0, help="0 = adaptive (library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-leg", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="one launch sequence per genome instead of one per step")
     return ap.parse_args()
 
 
@@ -116,7 +119,7 @@ def pmc_traffic(args, pruned_run):
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command).  FETCH_SIZE is
     corrected by +1/2 of the sequence stream where the kernel reads it with wide loads (the guide's gfx950 factor)."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    default = (args.mbp, args.genomes, args.divergence, args.k, args.w, args.fpr) == (100.0, 3, 0.01, 24, 1000, 0.025)
+    default = (args.mbp, args.genomes, args.divergence, args.k, args.w, args.fpr, args.no_batch) == (100.0, 3, 0.01, 24, 1000, 0.025, False)
     if not (default and os.path.exists(path)):
         return None
     k = json.load(open(path))["kernels"].get("k_hash_select" if pruned_run else "k_hash<0>")
@@ -125,7 +128,7 @@ def pmc_traffic(args, pruned_run):
     raw = (k["fetch_MB_per_launch_max"] + k["write_MB_per_launch_max"]) * 1024 * 1024
     # the dense kernel streams the bases with 16-byte loads (FETCH_SIZE counts half of such a stream on gfx950); the
     # pruned kernel reads the 2-bit image with dword loads, to which that correction does not apply
-    corr = 0.0 if pruned_run else 0.5 * args.mbp * 1e6
+    corr = 0.0 if pruned_run else 0.5 * args.mbp * 1e6 * args.genomes
     return {"bytes_per_launch": int(raw + corr), "raw_fetch_plus_write_bytes": int(raw),
             "source": "profiles/r01_pmc_traffic.json"}
 
@@ -170,6 +173,10 @@ def main():
     host = [synth.derive_genome(anc, div, j) for j in mine]
     genomes = [upload(ctx, g) for g in host]
     bases = sum(g.total_bp for g in genomes)
+    # the rank's batch as one resident genome (records of genome 0, then 1, ...): one sequence of launches sketches all
+    # of it, as ntsynt_amd/pipeline.py does for assemblies of this size (GpuBackend.sketch_batch)
+    from ntsynt_amd.device import Genome
+    units = [Genome.concat(ctx, genomes)] if (not args.no_batch and len(genomes) > 1) else genomes
 
     # ---- common Bloom filter: per-genome filters, local AND, AND-all-reduce over ranks --------------
     # sized from genome 0 of the family (the lexicographically first file, cpp:105-118): same on all ranks
@@ -215,14 +222,14 @@ def main():
     if world > 1:
         # density 2/(w+1) of the nominal genome size + 25 %: identical on every rank, and little padding to ship
         cap = int(2.5 * total_bp * 1.05 / (w + 1)) + 4096
-        gatherer = ndist.PackedListGather(len(genomes), cap, f"cuda:{local_rank}", comm_dev)
+        gatherer = ndist.PackedListGather(len(units), cap * (len(genomes) // len(units)), f"cuda:{local_rank}", comm_dev)
 
     def step():
         if gatherer is not None:
             gatherer.begin()
         n = 0
         held = []
-        for i, g in enumerate(genomes):
+        for i, g in enumerate(units):
             mx = sketch(ctx, g, k, w, common)
             n += len(mx)
             if gatherer is not None:
@@ -276,7 +283,8 @@ def main():
     ctx.profile(2)
     cand, gaps, gap_kmers = ctx.sketch_stats()
     c_used = getattr(ctx, "last_prune_c", 0)
-    per_launch_bases = bases / len(genomes)
+    per_launch_bases = bases / len(units)
+    per_genome_bases = bases / len(genomes)
 
     def avg(n):
         return tm[n][0] / max(tm[n][1], 1)
@@ -319,7 +327,8 @@ def main():
                                    + (f" (one family of {world * args.genomes} genomes, pairwise divergence {div * 100:g}%: "
                                       f"common-filter acceptance held at the 1-GPU value)" if world > 1 else ""),
                        "sketch_mode": args.mode, "prune_c": c_used,
-                       "genomes_per_gpu": args.genomes, "bases_per_step_per_gpu": bases,
+                       "genomes_per_gpu": args.genomes, "sketch_launch_sequences_per_step": len(units),
+                       "bases_per_step_per_gpu": bases,
                        "minimizers_per_step_per_gpu": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": kern,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -337,10 +346,10 @@ def main():
                          "unpruned": dense},
             "bloom": {"bytes": nbytes, "build_s": round(t_build, 4), "allreduce_and_s": round(t_allreduce, 4),
                       "bf_insert_avg_ms": round(ins_ms / max(ins_n, 1), 4),
-                      "bf_insert_Gbases_s": round(per_launch_bases / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 3)
+                      "bf_insert_Gbases_s": round(per_genome_bases / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 3)
                       if ins_ms > 0 else None,
                       # SURVEY.md 8(d) prices the build at 129 B/base (sector read + write-back per k-mer)
-                      "bf_insert_GBs_at_129B_per_base": round(129.0 * per_launch_bases / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 1)
+                      "bf_insert_GBs_at_129B_per_base": round(129.0 * per_genome_bases / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 1)
                       if ins_ms > 0 else None,
                       "occupancy": round(fpr_final, 6)},
         }

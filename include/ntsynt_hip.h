@@ -75,6 +75,11 @@ int nts_genome_upload(nts_ctx* ctx,
                       const uint64_t* rec_len,
                       uint32_t n_rec,
                       nts_genome** out);
+/* A batch of uploaded genomes as one device genome (device-to-device copy): the records of part 0, then those of
+ * part 1, ...; record ids of part p start at the number of records of the parts before it.  Sketching the batch is
+ * the reference's "indexlr per assembly" (bin/ntsynt_run_pipeline.smk:74-85) for all assemblies with one sequence of launches --
+ * records never share k-mers, so the minimizers of a record are those of the same record sketched alone. */
+int nts_genome_concat(nts_ctx* ctx, uint32_t n_parts, const nts_genome* const* parts, nts_genome** out);
 void nts_genome_free(nts_ctx* ctx, nts_genome* g);
 /* Bench / scale-test utilities (no counterpart in the reference): a synthetic genome generated directly in
  * HBM -- `n_contigs` equal records of i.i.d. bases drawn from `seed_ancestor`, with independent substitutions

@@ -94,6 +94,7 @@ struct nts_genome
   mutable uint32_t* d_pack = nullptr;
   std::vector<uint64_t> rec_off, rec_len;
   uint64_t total_bases = 0;
+  std::vector<uint64_t> part_bases; // nts_genome_concat: bases of each part (empty for an uploaded genome)
   // maximal stretches [a,b) of valid bases, clipped to records, ascending
   std::vector<uint64_t> st_a, st_b;
   uint64_t* d_rec_off = nullptr; // [n_rec] record offsets on the device
@@ -1379,6 +1380,61 @@ int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64
   return NTS_OK;
 }
 
+// A batch of genomes as one device genome: the parts' records one after the other (record ids of part p start at the
+// number of records before it), bases copied device to device.  Records never share k-mers, so sketching the batch
+// gives every part's minimizers -- with one sequence of launches for all of them, which is what counts while a
+// genome is small enough for the fixed cost of a launch sequence to show.
+int nts_genome_concat(nts_ctx* ctx, uint32_t n_parts, const nts_genome* const* parts, nts_genome** out)
+{
+  if (!ctx || !out || !n_parts || !parts) return fail(ctx, NTS_EINVAL, "nts_genome_concat: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t n = 0, n_rec = 0;
+  for (uint32_t p = 0; p < n_parts; ++p) {
+    if (!parts[p]) return fail(ctx, NTS_EINVAL, "nts_genome_concat: null part");
+    n += parts[p]->n;
+    n_rec += parts[p]->n_rec;
+  }
+  if (n_rec > 0xFFFFFFF0ULL) return fail(ctx, NTS_ERANGE, "nts_genome_concat: too many records");
+  nts_genome* g = new nts_genome();
+  g->n = n;
+  g->n_rec = (uint32_t)n_rec;
+  if (hipMalloc((void**)&g->d_code, PAD + n + PAD) != hipSuccess ||
+      hipMalloc((void**)&g->d_rec_off, std::max<uint64_t>(n_rec, 1) * 8) != hipSuccess) {
+    hipFree(g->d_code);
+    delete g;
+    return fail(ctx, NTS_ENOMEM, "nts_genome_concat: hipMalloc");
+  }
+  bool ok = hipMemsetAsync(g->d_code, CODE_INVALID, PAD, ctx->stream) == hipSuccess &&
+            hipMemsetAsync(g->d_code + PAD + n, CODE_INVALID, PAD, ctx->stream) == hipSuccess;
+  uint64_t base = 0;
+  for (uint32_t p = 0; p < n_parts && ok; ++p) {
+    const nts_genome* q = parts[p];
+    if (q->n) ok = hipMemcpyAsync(g->d_code + PAD + base, q->d_code + PAD, q->n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess;
+    for (uint32_t r = 0; r < q->n_rec; ++r) {
+      g->rec_off.push_back(base + q->rec_off[r]);
+      g->rec_len.push_back(q->rec_len[r]);
+    }
+    for (size_t i = 0; i < q->st_a.size(); ++i) {
+      g->st_a.push_back(base + q->st_a[i]);
+      g->st_b.push_back(base + q->st_b[i]);
+    }
+    g->total_bases += q->total_bases;
+    g->part_bases.push_back(q->total_bases);
+    base += q->n;
+  }
+  if (ok && n_rec) ok = hipMemcpyAsync(g->d_rec_off, g->rec_off.data(), n_rec * 8, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+  if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+  if (!ok) {
+    const std::string msg = std::string("nts_genome_concat: ") + hipGetErrorString(hipGetLastError());
+    hipFree(g->d_code);
+    hipFree(g->d_rec_off);
+    delete g;
+    return fail(ctx, NTS_EHIP, msg);
+  }
+  *out = g;
+  return NTS_OK;
+}
+
 void nts_genome_free(nts_ctx* ctx, nts_genome* g)
 {
   if (!g) return;
@@ -2044,8 +2100,8 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   PR_WS(d_tord, uint8_t*, "sel_tile_ord", n_kt);
   PR_WS(d_tscan, uint64_t*, "sel_tile_scan", n_kt * 8);
   PR_WS(d_tcnt64, uint64_t*, "sel_tile_cnt64", (n_kt > SCAN1_MAX ? n_kt : 2) * 8);
-  // control block: [0..63] candidate segment counters, [64] uncovered-range counter
-  PR_WS(d_ctl, unsigned long long*, "sel_ctl", (N_SEG + 1) * 8);
+  // control block: [0..63] candidate segment counters, [64] uncovered-range counter, [65] "a tile list did not fit"
+  PR_WS(d_ctl, unsigned long long*, "sel_ctl", (N_SEG + 2) * 8);
   const uint64_t gap_cap = V / w + g->n_rec + 16;
   PR_WS(d_glo, uint64_t*, "gap_lo", gap_cap * 8);
   PR_WS(d_ghi, uint64_t*, "gap_hi", gap_cap * 8);
@@ -2067,7 +2123,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     PR_WS(d_bcnt, uint64_t*, "blk_cnt", n_blk * 8);
     PR_WS(d_bscan, uint64_t*, "blk_scan", n_blk * 8);
     if (!d_sj || !d_sk) return NTS_ENOMEM;
-    HIP_TRY(ctx, hipMemsetAsync(d_ctl, 0, (N_SEG + 1) * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_ctl, 0, (N_SEG + 2) * 8, ctx->stream));
     SelParams S;
     S.code = g->d_code + PAD;
     if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
@@ -2106,7 +2162,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       ScopedTimer t(ctx, "cand_compact");
       if (int rc_s = scan_counts<uint32_t>(ctx, d_tcnt, n_kt, d_tscan, d_tcnt64)) return rc_s;
       hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)((n_kt + CC_TILES - 1) / CC_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tord, d_tscan, n_kt,
-                         d_pj, d_pk, m_max);
+                         d_pj, d_pk, m_max, d_ctl + N_SEG + 1);
     }
     SparseParams Q;
     Q.pj = d_pj;
@@ -2125,6 +2181,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     Q.gap_hi = d_ghi;
     Q.gap_count = d_ctl + N_SEG;
     Q.gap_cap = gap_cap;
+    Q.overflow = d_ctl + N_SEG + 1;
     {
       ScopedTimer t(ctx, "sparse_win");
       hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
@@ -2318,8 +2375,22 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
       uint64_t pc = 0;
       SK_TRY(nts_bf_popcount(ctx, filter, &pc));
       const double bits = (double)filter->bytes * 8.0;
-      const double own = bits * (1.0 - std::exp(-(double)rt.n_valid / bits));
-      p = own > 0 ? std::min(1.0, (double)pc / own) : 1.0;
+      auto share = [&](double kmers) { // of a genome with that many (distinct) k-mers
+        const double own = bits * (1.0 - std::exp(-kmers / bits));
+        return own > 0 ? std::min(1.0, (double)pc / own) : 1.0;
+      };
+      if (g->part_bases.size() > 1 && g->total_bases) {
+        // a batch: every part is a genome of its own as far as the filter is concerned (the parts of a batch are
+        // assemblies of one family: their k-mers are largely the same ones, not three times as many)
+        double acc = 0;
+        for (uint64_t b : g->part_bases) {
+          const double f = (double)b / (double)g->total_bases;
+          acc += f * share((double)rt.n_valid * f);
+        }
+        p = acc;
+      } else {
+        p = share((double)rt.n_valid);
+      }
     }
     // c*p = 12 accepted candidates per window on average.  (More would not empty the list of uncovered ranges:
     // beyond the ~V*(cp/w)*exp(-cp) chance ones there are the stretches the other genomes do not share at all.)

@@ -97,6 +97,7 @@ class Genome:
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         self.rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
         self.rec_len = np.ascontiguousarray(rec_len, dtype=np.uint64)
+        self.n_bytes = int(seq.size)
         h = c_vp()
         ctx.check(ctx.lib.nts_genome_upload(ctx.h, seq.ctypes.data, seq.size,
                                             self.rec_off.ctypes.data_as(_lib.c_u64p),
@@ -113,11 +114,39 @@ class Genome:
         g.names = [f"chr{i + 1}" for i in range(n_contigs)]
         g.rec_len = np.full(n_contigs, per, dtype=np.uint64)
         g.rec_off = (np.arange(n_contigs, dtype=np.uint64) * np.uint64(per)).astype(np.uint64)
+        g.n_bytes = per * int(n_contigs)
         h = c_vp()
         ctx.check(ctx.lib.nts_genome_synth(ctx.h, int(total_bp), int(n_contigs), int(seed_ancestor), int(seed_genome),
                                            float(substitution_rate), ctypes.byref(h)), "nts_genome_synth")
         g.h = h
         return g
+
+    @classmethod
+    def concat(cls, ctx, parts):
+        """The batch of resident genomes `parts` as one resident genome (nts_genome_concat, a device-to-device copy):
+        record ids of part p start at rec_base[p].  One sketch of the batch replaces one sketch per part --
+        split_minimizers() takes the list apart again."""
+        g = cls.__new__(cls)
+        g.ctx = ctx
+        g.names = [n for p in parts for n in p.names]
+        g.rec_base = np.concatenate(([0], np.cumsum([len(p.names) for p in parts]))).astype(np.int64)
+        sizes = np.array([p.n_bytes for p in parts], dtype=np.uint64)
+        g.n_bytes = int(sizes.sum())
+        starts = np.concatenate(([0], np.cumsum(sizes)[:-1])).astype(np.uint64)
+        g.rec_off = np.concatenate([p.rec_off + s for p, s in zip(parts, starts)]).astype(np.uint64)
+        g.rec_len = np.concatenate([p.rec_len for p in parts]).astype(np.uint64)
+        arr = (c_vp * len(parts))(*[p.h for p in parts])
+        h = c_vp()
+        ctx.check(ctx.lib.nts_genome_concat(ctx.h, len(parts), arr, ctypes.byref(h)), "nts_genome_concat")
+        g.h = h
+        return g
+
+    def split_minimizers(self, h1, rec, pos):
+        """(h1, rec, pos) of a sketch of a concat() batch -> one (h1, rec, pos) per part, record ids local to the part
+        (the list is in (record, position) order, so each part is a slice)."""
+        cut = np.searchsorted(rec, self.rec_base.astype(rec.dtype))
+        return [(h1[a:b], rec[a:b] - rec.dtype.type(base), pos[a:b])
+                for a, b, base in zip(cut[:-1], cut[1:], self.rec_base[:-1])]
 
     def download(self, offset, length):
         "upper-case ASCII of bases [offset, offset+length) of the concatenated records"

@@ -141,6 +141,24 @@ class GpuBackend:
         mx.free()
         return out
 
+    # below this many bases per assembly the fixed cost of a launch sequence shows: sketch the assemblies as one batch
+    BATCH_BELOW_BP = 1 << 30
+
+    def sketch_batch(self, genomes, k, w, bf):
+        """Whole-genome sketches of several resident genomes with one sequence of launches (Genome.concat): the same
+        lists as sketch() per genome."""
+        from .device import Genome, sketch
+        if len(genomes) < 2 or max(g.total_bp for g in genomes) >= self.BATCH_BELOW_BP:
+            return [self.sketch(g, k, w, bf) for g in genomes]
+        batch = Genome.concat(self.ctx, genomes)
+        try:
+            mx = sketch(self.ctx, batch, k, w, bf)
+            out = mx.to_numpy()
+            mx.free()
+            return batch.split_minimizers(*out)
+        finally:
+            batch.free()
+
     def graph(self, lists, keeps, list_ids):
         from .graph import build_graph_device
         return build_graph_device(self.ctx, lists, keeps, list_ids)
@@ -285,8 +303,14 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
 
     st.start("indexlr")
     tsv_names, initial = [], []
+    batched = None
+    if world == 1 and hasattr(backend, "sketch_batch"):
+        batched = dict(zip(fastas, backend.sketch_batch([genomes[p] for p in fastas], k, w, bf)))
     for p in fastas:
-        out = backend.sketch(genomes[p], k, w, bf) if owner[p] == rank else None
+        if batched is not None:
+            out = batched[p]
+        else:
+            out = backend.sketch(genomes[p], k, w, bf) if owner[p] == rank else None
         tsv = f"{fa.basename(p)}.k{k}.w{w}.tsv"
         if owner[p] == rank and write_mx_tsv:
             pending_files.append(writers.submit(write_indexlr_tsv, tsv, genomes[p].recs, out[0], out[1], out[2], k, mx_with_seq))

@@ -173,6 +173,51 @@ def test_sketch_with_filter(ctx, k, w, fpr):
             assert np.array_equal(a, b.astype(a.dtype))
 
 
+@pytest.mark.parametrize("k,w,use_bf", [(24, 1000, True), (24, 100, True), (20, 10, False), (129, 50, False)])
+def test_sketch_batch_equals_per_genome_and_oracle(ctx, k, w, use_bf):
+    """Genome.concat: several resident genomes sketched with one sequence of launches; the list splits into exactly
+    the per-genome lists (records never share k-mers), which are the oracle's.  Empty records, records shorter than
+    k, N runs and a part without records are in the batch."""
+    from ntsynt_amd.device import BloomFilter, Genome, sketch
+    parts = [_family(4000 + w, lengths=[60000, 300, 0, 20000], n_frac=0.003),
+             _family(4100 + w, lengths=[5, 70001], n_frac=0.0),
+             ([], []),
+             _family(4200 + w, lengths=[1024, 23, 33000, 0], n_frac=0.01)]
+    og = [to_oracle(n, s) for n, s in parts]
+    dg = [to_device(ctx, n, s) for n, s in parts]
+    obf = dbf = None
+    if use_bf:
+        nbytes = O.bf_ctor_bytes(O.bf_approx_bytes(og[0].total_bp, 0.3))
+        obf = O.bf_build(og[0], k, nbytes)
+        for o in og[1:]:
+            obf |= O.bf_build(o, k, nbytes)            # (a union, so that every part keeps minimizers)
+        obf[::3] = 0                                    # and holes, so that the filter rejects some k-mers everywhere
+        dbf = BloomFilter(ctx, nbytes, k)
+        dbf.from_numpy(obf)
+    batch = Genome.concat(ctx, dg)
+    assert batch.total_bp == sum(d.total_bp for d in dg) and len(batch.names) == sum(len(n) for n, _ in parts)
+    assert batch.valid_kmers(k) == sum(d.valid_kmers(k) for d in dg)
+    got = batch.split_minimizers(*sketch(ctx, batch, k, w, dbf).to_numpy())
+    assert len(got) == len(parts)
+    total = 0
+    for o, d, g in zip(og, dg, got):
+        exp = oracle_flat(O.minimize(o, k, w, obf))
+        alone = sketch(ctx, d, k, w, dbf).to_numpy()
+        total += len(exp[0])
+        for a, b, c in zip(g, exp, alone):
+            assert np.array_equal(a, b.astype(a.dtype)) and np.array_equal(a, c)
+    assert total > 0
+    # masks address the batch's record ids
+    masks = [(0, 1000, 30000), (int(batch.rec_base[1]) + 1, 100, 50000), (int(batch.rec_base[3]) + 2, 0, 40000)]
+    gm = batch.split_minimizers(*sketch(ctx, batch, k, w, dbf, masks).to_numpy())
+    for p, d, g in zip(range(len(dg)), dg, gm):
+        local = [(r - int(batch.rec_base[p]), s, e) for r, s, e in masks if batch.rec_base[p] <= r < batch.rec_base[p + 1]]
+        alone = sketch(ctx, d, k, w, dbf, local).to_numpy()
+        for a, c in zip(g, alone):
+            assert np.array_equal(a, c)
+    batch.free()
+
+
 @pytest.mark.parametrize("w", [100, 10])
 def test_sketch_masked(ctx, w):
     "refinement re-sketch (B5): masks applied on the resident genome == indexlr on the N-masked FASTA"
