@@ -2172,6 +2172,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     Q.m_max = m_max;
     Q.rec_vstart = T.d_rec_vstart;
     Q.rec_nv = T.d_rec_nv;
+    Q.n_valid = V;
     Q.n_rec = g->n_rec;
     Q.w = w;
     Q.stage_j = d_stj;
