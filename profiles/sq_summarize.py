@@ -6,7 +6,8 @@
   rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT ...                                (pmc_sq3)
   python profiles/sq_summarize.py gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_sq3 > profiles/rNN_sq_counters.json
 
-Largest launch of each kernel (one 100 Mbp genome = 100.06 M k-mers).  valu_issue_utilisation = wave-level VALU
+Largest launch of each kernel: the sketch kernels see the batch of three 100 Mbp genomes (300.19 M k-mers), the Bloom
+build kernels one genome (100.06 M).  valu_issue_utilisation = wave-level VALU
 instructions x 4 clocks / (256 CUs x 4 SIMDs) / launch duration at 2.4 GHz: the share of the chip's VALU issue slots
 the kernel used (the launch duration is the one measured under PMC collection)."""
 import csv
@@ -16,7 +17,9 @@ import re
 import sys
 
 KEEP = ["k_hash_select", "k_sparse_win", "k_cand_compact", "k_bin1", "k_bin2", "k_bin3", "k_hash<0>", "k_window_min"]
-KMERS = 100.06e6
+KMERS = 100.06e6          # one genome (the Bloom build inserts genome by genome)
+BATCH_KMERS = 300.19e6    # the three genomes of a step, sketched as one batch
+PER_GENOME = ("k_bin1", "k_bin2", "k_bin3")
 
 
 def short(n):
@@ -41,14 +44,15 @@ def main():
                     if c == "SQ_INSTS_VALU":
                         dur[k] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     res = {"workload": "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dense-leg under rocprofv3 --pmc "
-                       "(three passes); largest launch of each kernel (one 100 Mbp genome)", "kernels": {}}
+                       "(three passes); largest launch of each kernel (sketch kernels: the batch of three 100 Mbp genomes; "
+                       "k_bin*: one genome)", "kernels": {}}
     for k in KEEP:
         if k not in out:
             continue
         e = out[k]
         row = {c: int(v) for c, v in e.items()}
         if "SQ_INSTS_VALU" in e:
-            row["valu_wave_instructions_per_64_kmers"] = round(e["SQ_INSTS_VALU"] / (KMERS / 64), 1)
+            row["valu_wave_instructions_per_64_kmers"] = round(e["SQ_INSTS_VALU"] / ((KMERS if k in PER_GENOME else BATCH_KMERS) / 64), 1)
             if k in dur:
                 row["launch_us_under_pmc"] = round(dur[k], 1)
                 row["valu_issue_utilisation_at_2.4GHz"] = round(e["SQ_INSTS_VALU"] * 4 / (256 * 4) / (dur[k] * 1e-6 * 2.4e9), 3)
