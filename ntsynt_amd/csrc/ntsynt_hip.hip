@@ -1959,7 +1959,10 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
   OutSegs segs;
   segs.d_count = d_seg;
   segs.seg_cap = std::max<uint64_t>(256, (3 * est_kmers / w + 2 * n_tiles) / N_SEG + 64);
-  if (sparse && ctx->small_gap_path && n_tiles <= 1024 && segs.seg_cap <= 512) {
+  // (the device-side sort holds GAP_SORT_CAP winners: about two per w k-mers of a range and one more per range;
+  // when that estimate is close to the capacity the general path is taken at once instead of after a failed try)
+  const uint64_t expect_winners = 2 * est_kmers / std::max<uint32_t>(w, 1) + n_rec;
+  if (sparse && ctx->small_gap_path && n_tiles <= 1024 && segs.seg_cap <= 512 && expect_winners <= GAP_SORT_CAP * 3 / 4) {
     // ---- few uncovered ranges: no host round trip --------------------------------------------------------------
     const uint64_t slots = segs.seg_cap * N_SEG;
     segs.d_j = (uint64_t*)ws_get(ctx, (pre + "out_j").c_str(), slots * 8);
