@@ -513,6 +513,11 @@ struct WinParams
   uint64_t* out_key;          // its key (= h0)                          pre-filled with ~0 (sorts last)
   unsigned long long* seg_count; // [N_SEG] slots reserved per segment (one returning atomic per workgroup)
   uint64_t seg_cap;
+  // per-tile mode (few tiles: the uncovered ranges of a pruned sketch): tile b writes its winners in index order to
+  // out_j/out_key[b * tile_cap ...] and their number to tile_cnt[b] (more than tile_cap: nothing written, the
+  // collector sees the count) -- tiles are in index order, so no sort is needed afterwards
+  uint32_t* tile_cnt;
+  uint32_t tile_cap;
 };
 constexpr uint32_t N_SEG = 64;
 
@@ -684,9 +689,23 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
       kcur = knx;
     }
   }
-  // ---- flush: one returning atomic per workgroup, on one of N_SEG counters ---------------------------
   __syncthreads();
   const uint32_t n_emit = s_ctl[0];
+  if (P.tile_cnt != nullptr) {
+    // ---- per-tile mode: rank the tile's winners (distinct indices, a handful) by counting, write them in order ----
+    if (threadIdx.x == 0) P.tile_cnt[blockIdx.x] = n_emit;
+    if (n_emit == 0 || n_emit > P.tile_cap) return;
+    const uint64_t jb = P.rec_vstart[rec] + tf;
+    for (uint32_t i = threadIdx.x; i < n_emit; i += WIN_THREADS) {
+      const uint32_t idx = s_list[i];
+      uint32_t rank = 0;
+      for (uint32_t x = 0; x < n_emit; ++x) rank += s_list[x] < idx ? 1u : 0u;
+      P.out_j[(uint64_t)blockIdx.x * P.tile_cap + rank] = jb + idx;
+      P.out_key[(uint64_t)blockIdx.x * P.tile_cap + rank] = s_key[pe(idx)];
+    }
+    return;
+  }
+  // ---- flush: one returning atomic per workgroup, on one of N_SEG counters ---------------------------
   if (n_emit == 0) return;
   const uint32_t seg = blockIdx.x % N_SEG;
   if (threadIdx.x == 0) {
@@ -1776,6 +1795,8 @@ struct OutSegs
   uint64_t* d_key = nullptr;
   unsigned long long* d_count = nullptr;
   uint64_t seg_cap = 0;
+  uint32_t* d_tile_cnt = nullptr; // per-tile mode (see WinParams): d_j/d_key are [n_tiles][tile_cap]
+  uint32_t tile_cap = 0;
 };
 
 // window tiles over a table of (pseudo-)records; returns the number of tiles
@@ -1821,6 +1842,8 @@ int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_
   P.out_key = out.d_key;
   P.seg_count = out.d_count;
   P.seg_cap = out.seg_cap;
+  P.tile_cnt = out.d_tile_cnt;
+  P.tile_cap = out.tile_cap;
   ScopedTimer t(ctx, tag);
   hipLaunchKernelGGL(k_window_min, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
@@ -1906,7 +1929,7 @@ struct SortedOut
 // dense kernels over (pseudo-)records into segmented buffers, then a sort: `res` gets the ordered list.
 // tiles: optional list of key tiles to hash (uncovered ranges only); nullptr = all tiles.
 // sparse: when given (the ordered winners of the pruned pass) and the uncovered ranges are few, their winners are sorted
-// and merged into that list on the device (k_gap_sort, k_merge_lists_dev): `res` is then the merged list with
+// and merged into that list on the device (k_gap_collect, k_merge_lists_dev): `res` is then the merged list with
 // res.d_ctl set and res.count an upper bound, and no synchronisation happens here.
 int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter,
                      const std::vector<uint64_t>* pseudo_vstart, const std::vector<uint64_t>* pseudo_nv, const std::vector<uint32_t>* tiles,
@@ -1959,27 +1982,28 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
   OutSegs segs;
   segs.d_count = d_seg;
   segs.seg_cap = std::max<uint64_t>(256, (3 * est_kmers / w + 2 * n_tiles) / N_SEG + 64);
-  // (the device-side sort holds GAP_SORT_CAP winners: about two per w k-mers of a range and one more per range;
-  // when that estimate is close to the capacity the general path is taken at once instead of after a failed try)
+  // ---- few uncovered ranges: no host round trip, no sort -----------------------------------------------------
+  // the window kernel writes every tile's winners in order to a slot of its own; one workgroup (k_gap_collect) strings
+  // the tiles together, k_merge_lists_dev merges them into the sparse winners; the count is read at the call's end
   const uint64_t expect_winners = 2 * est_kmers / std::max<uint32_t>(w, 1) + n_rec;
-  if (sparse && ctx->small_gap_path && n_tiles <= 1024 && segs.seg_cap <= 512 && expect_winners <= GAP_SORT_CAP * 3 / 4) {
-    // ---- few uncovered ranges: no host round trip --------------------------------------------------------------
-    const uint64_t slots = segs.seg_cap * N_SEG;
-    segs.d_j = (uint64_t*)ws_get(ctx, (pre + "out_j").c_str(), slots * 8);
-    segs.d_key = (uint64_t*)ws_get(ctx, (pre + "out_key").c_str(), slots * 8);
-    DN_WS(d_gj, uint64_t*, "gap_sorted_j", GAP_SORT_CAP * 8);
-    DN_WS(d_gk, uint64_t*, "gap_sorted_key", GAP_SORT_CAP * 8);
+  if (sparse && ctx->small_gap_path && n_tiles <= GAP_TILES_MAX && expect_winners <= GAP_LIST_CAP * 3 / 4) {
+    OutSegs tl;
+    tl.tile_cap = GAP_TILE_CAP;
+    tl.d_j = (uint64_t*)ws_get(ctx, "gap_tile_j", n_tiles * GAP_TILE_CAP * 8);
+    tl.d_key = (uint64_t*)ws_get(ctx, "gap_tile_key", n_tiles * GAP_TILE_CAP * 8);
+    tl.d_tile_cnt = (uint32_t*)ws_get(ctx, "gap_tile_cnt", (n_tiles + 4) * 4);
+    DN_WS(d_gj, uint64_t*, "gap_sorted_j", GAP_LIST_CAP * 8);
+    DN_WS(d_gk, uint64_t*, "gap_sorted_key", GAP_LIST_CAP * 8);
     DN_WS(d_gctl, uint64_t*, "gap_ctl", 4 * 8);
-    const uint64_t total_max = sparse->count + GAP_SORT_CAP;
+    const uint64_t total_max = sparse->count + GAP_LIST_CAP;
     DN_WS(d_mj, uint64_t*, "merged_j", total_max * 8);
     DN_WS(d_mk, uint64_t*, "merged_key", total_max * 8);
-    if (!segs.d_j || !segs.d_key) return NTS_ENOMEM;
-    HIP_TRY(ctx, hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
-    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, segs, "window_min", d_tiles, n_tile_ids))) return rc;
+    if (!tl.d_j || !tl.d_key || !tl.d_tile_cnt) return NTS_ENOMEM;
+    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, tl, "window_min", d_tiles, n_tile_ids))) return rc;
     {
       ScopedTimer t(ctx, "merge_lists");
-      hipLaunchKernelGGL(k_gap_sort, dim3(1), dim3(GAP_SORT_THREADS), 0, ctx->stream, d_seg, segs.d_j, segs.d_key, segs.seg_cap, sparse->count,
-                         d_gj, d_gk, d_gctl);
+      hipLaunchKernelGGL(k_gap_collect, dim3(1), dim3(GAP_COLLECT_THREADS), 0, ctx->stream, tl.d_tile_cnt, (uint32_t)n_tiles, tl.d_j, tl.d_key,
+                         sparse->count, d_gj, d_gk, d_gctl);
       hipLaunchKernelGGL(k_merge_lists_dev, dim3((uint32_t)((total_max + 255) / 256)), dim3(256), 0, ctx->stream, sparse->d_j, sparse->d_key,
                          sparse->count, d_gj, d_gk, d_gctl, d_mj, d_mk);
     }

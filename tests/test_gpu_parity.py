@@ -336,6 +336,30 @@ def test_sketch_modes_identical(ctx, mode, c):
         ctx.sketch_mode("auto", 64)
 
 
+@pytest.mark.parametrize("w,n", [(33, 100_000), (64, 150_000), (300, 800_000)])
+def test_uncovered_ranges_device_merge_and_its_fallback(ctx, w, n):
+    """Pruned sketch with c = 1: nearly every window is uncovered.  The uncovered ranges' winners are strung together on
+    the device (k_gap_collect) when the host expects few of them; with w = 33 and 64 a window tile holds more winners
+    than its slot (128), the device flags it and the call is repeated on the general path; w = 300 fits."""
+    from ntsynt_amd.device import sketch
+    k = 24
+    names, seqs = _family(7000 + w, lengths=[n, 0, 40], n_frac=0.0)
+    og, dg = to_oracle(names, seqs), to_device(ctx, names, seqs)
+    exp = oracle_flat(O.minimize(og, k, w))
+    ctx.sketch_mode("pruned", 1)
+    try:
+        got = sketch(ctx, dg, k, w).to_numpy()
+        cand, gaps, gk = ctx.sketch_stats()
+        assert gaps > 0 and gk > n // 2
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b.astype(a.dtype))
+        got2 = sketch(ctx, dg, k, w).to_numpy()          # the context is back on the device-side path afterwards
+        for a, b in zip(got2, exp):
+            assert np.array_equal(a, b.astype(a.dtype))
+    finally:
+        ctx.sketch_mode("auto", 64)
+
+
 @pytest.mark.parametrize("k", [1, 129, 200])
 def test_long_and_degenerate_k_end_to_end(ctx, k):
     """k beyond the LDS-staged fast paths (and k = 1): Bloom build (both builds), pruned and dense sketch vs the oracle"""
