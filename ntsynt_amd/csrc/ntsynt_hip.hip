@@ -790,11 +790,17 @@ __global__ __launch_bounds__(256) void k_bench_probe(const uint32_t* __restrict_
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sink, (unsigned long long)acc);
 }
 
-// compact index -> (record, position in record), and the printed hash h1
+// compact index -> (record, position in record), and the printed hash h1.  With a second list (b_j / b_k, its length at
+// nb_dev; disjoint indices) the two ordered lists are merged on the way: every element finds its slot by a binary search
+// in the other list -- the few winners of the uncovered ranges join the sparse winners without a pass of their own.
 __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j_sorted,
                                                   const uint64_t* __restrict__ key_sorted,
                                                   uint64_t n_out,
                                                   const uint64_t* __restrict__ n_out_dev, // if not null: the count lives here
+                                                  const uint64_t* __restrict__ b_j,
+                                                  const uint64_t* __restrict__ b_k,
+                                                  const uint64_t* __restrict__ nb_dev,
+                                                  uint64_t na, // (merging) length of the first list; n_out_dev = na + *nb_dev
                                                   const uint64_t* __restrict__ run_pos,
                                                   const uint64_t* __restrict__ run_vstart,
                                                   uint32_t n_runs,
@@ -805,9 +811,29 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j
                                                   uint32_t* __restrict__ rec,
                                                   uint64_t* __restrict__ pos)
 {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (n_out_dev ? *n_out_dev : n_out)) return;
-  const uint64_t j = j_sorted[i];
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (n_out_dev ? *n_out_dev : n_out)) return;
+  uint64_t i = t, j, key;
+  if (b_j == nullptr) {
+    j = j_sorted[t];
+    key = key_sorted[t];
+  } else {
+    const uint64_t nb = *nb_dev;
+    const bool from_a = t < na;
+    const uint64_t self = from_a ? t : t - na;
+    j = from_a ? j_sorted[self] : b_j[self];
+    key = from_a ? key_sorted[self] : b_k[self];
+    const uint64_t* other = from_a ? b_j : j_sorted;
+    uint64_t lo = 0, hi = from_a ? nb : na;
+    while (lo < hi) {
+      const uint64_t mid = lo + ((hi - lo) >> 1);
+      if (other[mid] < j)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    i = self + lo;
+  }
   uint32_t lo = 0, hi = n_runs;
   while (hi - lo > 1) {
     const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -825,7 +851,7 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j
     else
       z = mid;
   }
-  h1[i] = extend_h1(key_sorted[i], k);
+  h1[i] = extend_h1(key, k);
   rec[i] = a;
   pos[i] = gp - rec_off[a];
 }
@@ -1924,13 +1950,18 @@ struct SortedOut
   // few uncovered ranges are merged in on the device; d_ctl[1] = number of minimizers, d_ctl[2] = 1 if that path
   // gave up (the call is repeated with ctx->small_gap_path = false)
   uint64_t* d_ctl = nullptr;
+  // ... in which case d_j/d_key hold the first `na` of them (the sparse winners) and b_j/b_key the others (the winners of
+  // the uncovered ranges, d_ctl[0] of them): k_finalize merges the two lists
+  uint64_t* b_j = nullptr;
+  uint64_t* b_key = nullptr;
+  uint64_t na = 0;
 };
 
 // dense kernels over (pseudo-)records into segmented buffers, then a sort: `res` gets the ordered list.
 // tiles: optional list of key tiles to hash (uncovered ranges only); nullptr = all tiles.
 // sparse: when given (the ordered winners of the pruned pass) and the uncovered ranges are few, their winners are sorted
-// and merged into that list on the device (k_gap_collect, k_merge_lists_dev): `res` is then the merged list with
-// res.d_ctl set and res.count an upper bound, and no synchronisation happens here.
+// and handed on as a second list next to it (k_gap_collect; k_finalize merges): `res` then has res.d_ctl and res.b_j set
+// and res.count is an upper bound, and no synchronisation happens here.
 int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter,
                      const std::vector<uint64_t>* pseudo_vstart, const std::vector<uint64_t>* pseudo_nv, const std::vector<uint32_t>* tiles,
                      uint64_t est_kmers, const char* slot_prefix, SortedOut& res, const SortedOut* sparse = nullptr)
@@ -1984,7 +2015,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
   segs.seg_cap = std::max<uint64_t>(256, (3 * est_kmers / w + 2 * n_tiles) / N_SEG + 64);
   // ---- few uncovered ranges: no host round trip, no sort -----------------------------------------------------
   // the window kernel writes every tile's winners in order to a slot of its own; one workgroup (k_gap_collect) strings
-  // the tiles together, k_merge_lists_dev merges them into the sparse winners; the count is read at the call's end
+  // the tiles together, k_finalize merges them into the sparse winners; the count is read at the call's end
   const uint64_t expect_winners = 2 * est_kmers / std::max<uint32_t>(w, 1) + n_rec;
   if (sparse && ctx->small_gap_path && n_tiles <= GAP_TILES_MAX && expect_winners <= GAP_LIST_CAP * 3 / 4) {
     OutSegs tl;
@@ -1995,22 +2026,20 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     DN_WS(d_gj, uint64_t*, "gap_sorted_j", GAP_LIST_CAP * 8);
     DN_WS(d_gk, uint64_t*, "gap_sorted_key", GAP_LIST_CAP * 8);
     DN_WS(d_gctl, uint64_t*, "gap_ctl", 4 * 8);
-    const uint64_t total_max = sparse->count + GAP_LIST_CAP;
-    DN_WS(d_mj, uint64_t*, "merged_j", total_max * 8);
-    DN_WS(d_mk, uint64_t*, "merged_key", total_max * 8);
     if (!tl.d_j || !tl.d_key || !tl.d_tile_cnt) return NTS_ENOMEM;
     if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, tl, "window_min", d_tiles, n_tile_ids))) return rc;
     {
       ScopedTimer t(ctx, "merge_lists");
       hipLaunchKernelGGL(k_gap_collect, dim3(1), dim3(GAP_COLLECT_THREADS), 0, ctx->stream, tl.d_tile_cnt, (uint32_t)n_tiles, tl.d_j, tl.d_key,
                          sparse->count, d_gj, d_gk, d_gctl);
-      hipLaunchKernelGGL(k_merge_lists_dev, dim3((uint32_t)((total_max + 255) / 256)), dim3(256), 0, ctx->stream, sparse->d_j, sparse->d_key,
-                         sparse->count, d_gj, d_gk, d_gctl, d_mj, d_mk);
     }
     HIP_TRY(ctx, hipGetLastError());
-    res.d_j = d_mj;
-    res.d_key = d_mk;
-    res.count = total_max;
+    res.d_j = sparse->d_j;
+    res.d_key = sparse->d_key;
+    res.na = sparse->count;
+    res.b_j = d_gj;
+    res.b_key = d_gk;
+    res.count = sparse->count + GAP_LIST_CAP;
     res.d_ctl = d_gctl;
     return NTS_OK;
   }
@@ -2444,7 +2473,7 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
       {
         ScopedTimer t(ctx, "finalize");
         hipLaunchKernelGGL(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, res.d_j, res.d_key, (uint64_t)count,
-                           res.d_ctl ? res.d_ctl + 1 : nullptr, T->d_run_pos, T->d_run_vstart, T->n_runs, g->d_rec_off, g->n_rec, k, mx->d_h1,
+                           res.d_ctl ? res.d_ctl + 1 : nullptr, res.b_j, res.b_key, res.b_j ? res.d_ctl : nullptr, res.na, T->d_run_pos, T->d_run_vstart, T->n_runs, g->d_rec_off, g->n_rec, k, mx->d_h1,
                            mx->d_rec, mx->d_pos);
       }
       SK_HIP(hipGetLastError());
