@@ -2742,6 +2742,15 @@ __global__ __launch_bounds__(256) void k_g_order_keys(const uint32_t* __restrict
   idx[e] = e;
 }
 
+// element numbers base .. base+m-1 and the assembly id of one list of the concatenation
+__global__ __launch_bounds__(256) void k_g_number(uint64_t* __restrict__ idx, uint32_t* __restrict__ asm_id, uint64_t m, uint64_t base, uint32_t a)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  idx[i] = base + i;
+  asm_id[i] = a;
+}
+
 __global__ __launch_bounds__(256) void k_g_permute_edges(const uint64_t* __restrict__ idx_sorted, uint64_t ne, const uint32_t* __restrict__ e_u,
                                                          const uint32_t* __restrict__ e_v, const uint32_t* __restrict__ e_w,
                                                          const uint64_t* __restrict__ e_first, uint32_t* __restrict__ o_u,
@@ -2804,10 +2813,8 @@ extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* l
   G_WS(d_flag, uint64_t*, "g_flag", n * 8);
   G_WS(d_scan, uint64_t*, "g_scan", (n + 1) * 8);
   G_WS(d_evid, uint32_t*, "g_evid", n * 4);
-  // host staging (assembly-major concatenation)
-  std::vector<uint64_t> h_idx(n);
-  std::vector<uint32_t> h_asm(n);
-  std::vector<uint8_t> h_keep(n, 1);
+  // assembly-major concatenation; element numbers and assembly ids are generated on the device (each assembly's range is
+  // one launch), the keep mask is uploaded only where a list brings one
   uint64_t o = 0;
   for (uint32_t a = 0; a < n_asm; ++a) {
     const uint64_t m = lists[a].n;
@@ -2816,17 +2823,14 @@ extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* l
       HIP_TRY(ctx, hipMemcpyAsync(d_rec + o, lists[a].rec, m * 4, hipMemcpyHostToDevice, ctx->stream));
       HIP_TRY(ctx, hipMemcpyAsync(d_pos + o, lists[a].pos, m * 8, hipMemcpyHostToDevice, ctx->stream));
       HIP_TRY(ctx, hipMemcpyAsync(d_list + o, lists[a].list_id ? lists[a].list_id : lists[a].rec, m * 4, hipMemcpyHostToDevice, ctx->stream));
-      if (lists[a].keep) memcpy(h_keep.data() + o, lists[a].keep, m);
-    }
-    for (uint64_t i = 0; i < m; ++i) {
-      h_idx[o + i] = o + i;
-      h_asm[o + i] = a;
+      if (lists[a].keep)
+        HIP_TRY(ctx, hipMemcpyAsync(d_keep + o, lists[a].keep, m, hipMemcpyHostToDevice, ctx->stream));
+      else
+        HIP_TRY(ctx, hipMemsetAsync(d_keep + o, 1, m, ctx->stream));
+      hipLaunchKernelGGL(k_g_number, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_idx + o, d_asm + o, m, o, a);
     }
     o += m;
   }
-  HIP_TRY(ctx, hipMemcpyAsync(d_idx, h_idx.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d_asm, h_asm.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d_keep, h_keep.data(), n, hipMemcpyHostToDevice, ctx->stream));
   const uint32_t nb = (uint32_t)((n + 255) / 256);
   size_t tmp_sort = 0, tmp_scan = 0;
   HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort, d_h, d_h2, d_idx, d_idx2, n, 0, 64, ctx->stream));
