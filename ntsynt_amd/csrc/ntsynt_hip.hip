@@ -2110,7 +2110,7 @@ int ensure_pack(nts_ctx* ctx, const nts_genome* g)
 
 // exclusive scan of per-tile / per-workgroup counts: one single-workgroup kernel while the list is short (one launch,
 // ~4 us), the library's two-kernel scan beyond (a single workgroup would take ~0.1 ms over 2*10^5 counts)
-constexpr uint64_t SCAN1_MAX = 32768;
+constexpr uint64_t SCAN1_MAX = 8192;
 
 template <typename T>
 int scan_counts(nts_ctx* ctx, const T* d_in, uint64_t n, uint64_t* d_out, uint64_t* d_in64)
