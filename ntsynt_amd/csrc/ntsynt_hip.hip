@@ -1925,9 +1925,19 @@ struct Mail
   // up); the stream is in order, so the flag also means that everything queued before has finished.
   int post(nts_ctx* ctx)
   {
+    if (int rc = launch(ctx)) return rc;
+    return wait(ctx);
+  }
+  // the two halves of post(): work queued between them runs while the values travel and the host gets going again
+  int launch(nts_ctx* ctx)
+  {
     P.seq = ++ctx->mail_seq;
     hipLaunchKernelGGL(k_mail, dim3(1), dim3(256), 0, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
+    return NTS_OK;
+  }
+  int wait(nts_ctx* ctx)
+  {
     volatile uint64_t* flag = ctx->mail + (MAIL_WORDS - 1);
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spin = 0; *flag != P.seq; ++spin) {
@@ -2243,9 +2253,8 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       ScopedTimer t(ctx, "sparse_win");
       hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
       hipLaunchKernelGGL(k_gap_records, dim3((g->n_rec + 255) / 256), dim3(256), 0, ctx->stream, Q);
-      // ordered output without a sort: scan the per-workgroup counts, gather (the candidate segments are free again)
+      // ordered output without a sort: scan the per-workgroup counts, gather (below; the candidate segments are free again)
       if (int rc_s = scan_counts<uint64_t>(ctx, d_bcnt, n_blk, d_bscan, nullptr)) return rc_s;
-      hipLaunchKernelGGL(k_gather_winners, dim3((uint32_t)n_blk), dim3(256), 0, ctx->stream, d_stj, d_stk, d_bcnt, d_bscan, d_sj, d_sk);
     }
     HIP_TRY(ctx, hipGetLastError());
     // one synchronisation: candidate counters, uncovered-range count + a first batch of ranges, winner count
@@ -2259,8 +2268,15 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       const uint32_t a_cnt = mb.add(d_bcnt + (n_blk - 1), 1);
       const uint32_t a_lo = mb.add(d_glo, peek);
       const uint32_t a_hi = mb.add(d_ghi, peek);
-      int rc_m = mb.post(ctx);
+      // the gather runs behind the mail kernel: the counters are on their way to the host while it works
+      int rc_m = mb.launch(ctx);
       if (rc_m) return rc_m;
+      {
+        ScopedTimer t(ctx, "sparse_win");
+        hipLaunchKernelGGL(k_gather_winners, dim3((uint32_t)n_blk), dim3(256), 0, ctx->stream, d_stj, d_stk, d_bcnt, d_bscan, d_sj, d_sk);
+      }
+      HIP_TRY(ctx, hipGetLastError());
+      if ((rc_m = mb.wait(ctx))) return rc_m;
       for (uint32_t i = 0; i <= N_SEG; ++i) ctl[i] = ctx->mail[a_ctl + i];
       last_scan = ctx->mail[a_scan];
       last_cnt = ctx->mail[a_cnt];
