@@ -273,7 +273,8 @@ def main():
         return el, n_mx
 
     dt, n_mx = timed(args.warmup, args.steps)
-    names = ["hash_select", "cand_compact", "sparse_win", "hash_probe", "window_min", "sort_minimizers", "merge_lists", "finalize"]
+    names = ["hash_select", "cand_compact", "sparse_win", "gather_winners", "hash_probe", "window_min", "sort_minimizers", "merge_lists",
+             "finalize"]
     tm = {n: ctx.timing(n) for n in names}
     # the other kernels of the call: one more pass, untimed, with every kernel group bracketed by events
     ctx.profile(1)

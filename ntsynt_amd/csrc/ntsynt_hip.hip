@@ -2272,7 +2272,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       int rc_m = mb.launch(ctx);
       if (rc_m) return rc_m;
       {
-        ScopedTimer t(ctx, "sparse_win");
+        ScopedTimer t(ctx, "gather_winners");
         hipLaunchKernelGGL(k_gather_winners, dim3((uint32_t)n_blk), dim3(256), 0, ctx->stream, d_stj, d_stk, d_bcnt, d_bscan, d_sj, d_sk);
       }
       HIP_TRY(ctx, hipGetLastError());

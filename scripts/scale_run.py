@@ -80,7 +80,7 @@ def main():
                 sketch(ctx, g, k, w, common).free()
         ctx.sync()
         dt = time.time() - t0
-        names = ["hash_select", "cand_compact", "sparse_win", "hash_probe", "window_min", "sort_minimizers", "finalize"]
+        names = ["hash_select", "cand_compact", "sparse_win", "gather_winners", "hash_probe", "window_min", "sort_minimizers", "merge_lists", "finalize"]
         tm = {n: ctx.timing(n) for n in names}
         return {"Gbases_s": round(bases * len(genomes) * args.repeats / dt / 1e9, 2),
                 "ms_per_genome": round(dt / (len(genomes) * args.repeats) * 1e3, 3),
