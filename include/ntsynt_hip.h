@@ -144,11 +144,11 @@ int nts_sketch(nts_ctx* ctx,
                const nts_interval* mask,
                uint64_t n_mask,
                nts_mx** out);
-/* Sketch policy.  mode 0 = auto (pruned when w >= 256 and the filter accepts >= 2 % of the genome's k-mers),
+/* Sketch policy.  mode 0 = auto (pruned when w >= 200 and c = 12 / accepted share stays below w/4, below 0.15 w for w < 512),
  * 1 = dense (probe the filter for every k-mer), 2 = pruned: only k-mers whose hash is <= (c / w) * 2^64 are probed;
  * windows holding no accepted candidate are re-evaluated densely, so the result is identical
  * (ntsynt_amd/csrc/nts_pruned.inc).  prune_c = 0: c is chosen per call from the filter's occupancy
- * (c = 12 / accepted share, clamped to [8, 128]); otherwise c = prune_c. */
+ * (c = 12 / accepted share, at least 8); otherwise c = prune_c. */
 int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c);
 /* of the last nts_sketch call: accepted candidates, uncovered ranges handed to the dense kernels, the number of
  * k-mers in them, and the c that was used (all 0 for a dense-mode call) */

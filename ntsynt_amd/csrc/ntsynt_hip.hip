@@ -72,7 +72,7 @@ struct nts_ctx
   std::vector<hipEvent_t> spare_events; // recycled timing events (creating one costs microseconds of host time)
   // grow-only device scratch, reused across calls (a ctx serves one call at a time)
   std::map<std::string, std::pair<void*, size_t>> ws;
-  // sketch policy: 0 auto (pruned when w >= 256), 1 dense, 2 pruned; prune_c/w = fraction of hashes kept as candidates
+  // sketch policy: 0 auto (pruned when w >= 200), 1 dense, 2 pruned; prune_c/w = fraction of hashes kept as candidates
   std::vector<std::pair<void*, uint64_t>> mx_pool; // recycled result allocations
   size_t win_lds_set = 0;
   bool bin_lds_set = false;
@@ -2440,7 +2440,7 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   // windows uncovered (they are re-evaluated densely).  The select kernel probes its candidates in batches and keeps
   // only the accepted ones, so c may grow until a quarter of the k-mers are candidates (p down to 48/w); below that
   // the dense kernels take over.
-  bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= 256);
+  bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= 200);
   uint32_t prune_c = ctx->prune_c;
   double p = 1.0; // accepted share of the candidates (1 when unknown: sizes the candidate arrays)
   if (pruned && prune_c == 0) {
@@ -2471,8 +2471,11 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
     const double want = std::max(8.0, std::ceil(cp / std::max(p, 1e-4)));
     // (measured: at a quarter of the k-mers as candidates the pruned pass is still twice as fast as the dense one;
     // at 40 % single lanes run out of slots in most tiles and it is half as fast)
-    prune_c = (uint32_t)std::min(want, 0.25 * (double)w);
-    if (ctx->sketch_mode == 0 && want > 0.25 * (double)w) pruned = false;
+    // (with short windows the accepted candidates per lane of k_hash_select get dense sooner: measured at w = 250,
+    // 3 x 100 Mbp: c = 35 -> 56 Gbases/s against 34 dense, c = 50 -> 17; at w = 1000, c = 203 still gives 94)
+    const double cap = (w >= 512 ? 0.25 : 0.15) * (double)w;
+    prune_c = (uint32_t)std::min(want, cap);
+    if (ctx->sketch_mode == 0 && want > cap) pruned = false;
   }
   ctx->last_c = pruned ? prune_c : 0;
 
