@@ -305,6 +305,10 @@ unsigned host_threads(unsigned cap)
     }
     fclose(f);
   }
+  if (const char* e = getenv("NTS_HOST_THREADS")) { // (an upper limit set by the user, e.g. to leave cores to other work)
+    const long v = atol(e);
+    if (v > 0) n = std::min<unsigned>(n, (unsigned)v);
+  }
   return std::max(1u, std::min(n, cap));
 }
 
