@@ -2252,7 +2252,6 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     {
       ScopedTimer t(ctx, "sparse_win");
       hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
-      hipLaunchKernelGGL(k_gap_records, dim3((g->n_rec + 255) / 256), dim3(256), 0, ctx->stream, Q);
       // ordered output without a sort: scan the per-workgroup counts, gather (below; the candidate segments are free again)
       if (int rc_s = scan_counts<uint64_t>(ctx, d_bcnt, n_blk, d_bscan, nullptr)) return rc_s;
     }
