@@ -2123,17 +2123,19 @@ int ensure_pack(nts_ctx* ctx, const nts_genome* g)
 constexpr uint64_t SCAN1_MAX = 8192;
 
 template <typename T>
-int scan_counts(nts_ctx* ctx, const T* d_in, uint64_t n, uint64_t* d_out, uint64_t* d_in64)
+struct WidenU64
+{
+  __host__ __device__ uint64_t operator()(T x) const { return (uint64_t)x; }
+};
+
+template <typename T>
+int scan_counts(nts_ctx* ctx, const T* d_in, uint64_t n, uint64_t* d_out)
 {
   if (n <= SCAN1_MAX) {
     hipLaunchKernelGGL(k_scan_excl<T>, dim3(1), dim3(SCAN1_THREADS), 0, ctx->stream, d_in, n, d_out);
     return NTS_OK;
   }
-  const uint64_t* src = reinterpret_cast<const uint64_t*>(d_in);
-  if (sizeof(T) != 8) {
-    hipLaunchKernelGGL(k_widen_u64<T>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, d_in64);
-    src = d_in64;
-  }
+  auto src = rocprim::make_transform_iterator(d_in, WidenU64<T>()); // (32-bit counts are widened on the way in)
   size_t bytes = 0;
   HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, bytes, src, d_out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
   void* tmp = ws_get(ctx, "sel_scan_tmp", std::max<size_t>(bytes, 16));
@@ -2165,7 +2167,6 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   PR_WS(d_tcnt, uint32_t*, "sel_tile_cnt", n_kt * 4);
   PR_WS(d_tord, uint8_t*, "sel_tile_ord", n_kt);
   PR_WS(d_tscan, uint64_t*, "sel_tile_scan", n_kt * 8);
-  PR_WS(d_tcnt64, uint64_t*, "sel_tile_cnt64", (n_kt > SCAN1_MAX ? n_kt : 2) * 8);
   // control block: [0..63] candidate segment counters, [64] uncovered-range counter, [65] "a tile list did not fit"
   PR_WS(d_ctl, unsigned long long*, "sel_ctl", (N_SEG + 2) * 8);
   const uint64_t gap_cap = V / w + g->n_rec + 16;
@@ -2226,7 +2227,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     }
     {
       ScopedTimer t(ctx, "cand_compact");
-      if (int rc_s = scan_counts<uint32_t>(ctx, d_tcnt, n_kt, d_tscan, d_tcnt64)) return rc_s;
+      if (int rc_s = scan_counts<uint32_t>(ctx, d_tcnt, n_kt, d_tscan)) return rc_s;
       hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)((n_kt + CC_TILES - 1) / CC_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tord, d_tscan, n_kt,
                          d_pj, d_pk, m_max, d_ctl + N_SEG + 1);
     }
@@ -2253,7 +2254,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       ScopedTimer t(ctx, "sparse_win");
       hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
       // ordered output without a sort: scan the per-workgroup counts, gather (below; the candidate segments are free again)
-      if (int rc_s = scan_counts<uint64_t>(ctx, d_bcnt, n_blk, d_bscan, nullptr)) return rc_s;
+      if (int rc_s = scan_counts<uint64_t>(ctx, d_bcnt, n_blk, d_bscan)) return rc_s;
     }
     HIP_TRY(ctx, hipGetLastError());
     // one synchronisation: candidate counters, uncovered-range count + a first batch of ranges, winner count
