@@ -159,3 +159,21 @@ def test_synthetic_family_is_deterministic(tmp_path):
     g0 = synth.derive_genome(anc, 0.01, 0, seed=3)
     diff = sum(int((x != y).sum()) for x, y in zip(anc, g0)) / 50_000
     assert 0.003 < diff < 0.007           # p/2 substitutions per genome
+
+
+def test_batch_list_splits_at_record_boundaries():
+    """Genome.split_minimizers (host side of nts_genome_concat): the (record, position)-ordered list of a batch is cut
+    where the record ids pass a part's first record; parts without minimizers (or without records) give empty lists."""
+    from ntsynt_amd.device import Genome
+    g = Genome.__new__(Genome)
+    g.rec_base = np.array([0, 3, 3, 7, 9], dtype=np.int64)          # parts of 3, 0, 4 and 2 records
+    rec = np.array([0, 0, 2, 3, 3, 6, 8, 8, 8], dtype=np.uint32)
+    h1 = np.arange(rec.size, dtype=np.uint64) * 11
+    pos = np.arange(rec.size, dtype=np.uint64) * 7
+    parts = g.split_minimizers(h1, rec, pos)
+    assert [p[1].tolist() for p in parts] == [[0, 0, 2], [], [0, 0, 3], [1, 1, 1]]
+    assert [p[0].tolist() for p in parts] == [[0, 11, 22], [], [33, 44, 55], [66, 77, 88]]
+    assert np.concatenate([p[2] for p in parts]).tolist() == pos.tolist()
+    assert all(p[1].dtype == np.uint32 for p in parts)
+    empty = g.split_minimizers(h1[:0], rec[:0], pos[:0])
+    assert [p[0].size for p in empty] == [0, 0, 0, 0]
