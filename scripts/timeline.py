@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Kernel timeline of the last sketch call in a rocprofv3 --kernel-trace CSV: start offset, duration, idle gap before
-each kernel (us).  usage: python scripts/timeline.py <..._kernel_trace.csv> [anchor-kernel-substring]"""
+"""Kernel timeline of one sketch call in a rocprofv3 --kernel-trace CSV: start offset, duration, idle gap before each
+kernel (us).  usage: python scripts/timeline.py <..._kernel_trace.csv> [anchor-kernel-substring] [occurrence]
+The call is the one starting at the given occurrence of the anchor kernel (default -2: with bench.py that is the last
+TIMED step -- the very last call is bench.py's detail pass, where an event pair sits between all kernels)."""
 import csv
 import re
 import sys
@@ -15,8 +17,10 @@ def main():
     if not starts:
         print("anchor kernel not found")
         return
-    i0 = starts[-1]
-    i1 = len(rows)
+    which = int(sys.argv[3]) if len(sys.argv) > 3 else -2
+    i0 = starts[which]
+    later = [i for i in starts if i > i0]
+    i1 = later[0] if later else len(rows)
     t0 = rows[i0][0]
     prev_end = rows[i0 - 1][1] if i0 else t0
     busy = 0
