@@ -77,6 +77,7 @@ struct nts_ctx
   size_t win_lds_set = 0;
   bool bin_lds_set = false;
   bool small_gap_path = true; // uncovered ranges: device-side sort + merge when they are few (nts_pruned.inc)
+  bool sel_ctl_clean = false; // the pruned pass's control block was cleared by the previous call's last kernel
   int bf_build_mode = 0; // 0 auto (binned build for large genomes), 1 one atomic per k-mer, 2 binned whenever it applies
   int sketch_mode = 0;
   uint32_t prune_c = 0; // 0 = adaptive (from the filter's occupancy), else fixed
@@ -1887,12 +1888,15 @@ struct MailParams
   uint32_t count;
   uint64_t seq; // arrival flag value, written to the last word of the mailbox
   uint64_t* mail;
+  uint64_t* zero; // after the copies: words to clear (the next call's control block: it then starts without a memset)
+  uint32_t n_zero;
 };
 
 __global__ __launch_bounds__(256) void k_mail(MailParams P)
 {
   for (uint32_t s = 0; s < P.count; ++s)
     for (uint32_t i = threadIdx.x; i < P.n[s]; i += 256) P.mail[P.off[s] + i] = P.src[s][i];
+  for (uint32_t i = threadIdx.x; i < P.n_zero; i += 256) P.zero[i] = 0; // (not among the sources of this mail)
   // arrival flag for the polling host: after every lane's values are visible system-wide
   __threadfence_system();
   __syncthreads();
@@ -1909,6 +1913,13 @@ struct Mail
   {
     P.count = 0;
     P.mail = ctx->d_mail;
+    P.zero = nullptr;
+    P.n_zero = 0;
+  }
+  void clear_after(uint64_t* dev, uint32_t n_words)
+  {
+    P.zero = dev;
+    P.n_zero = n_words;
   }
   // returns the word offset of the range in the mailbox
   uint32_t add(const void* dev, uint32_t n_words)
@@ -2190,7 +2201,8 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     PR_WS(d_bcnt, uint64_t*, "blk_cnt", n_blk * 8);
     PR_WS(d_bscan, uint64_t*, "blk_scan", n_blk * 8);
     if (!d_sj || !d_sk) return NTS_ENOMEM;
-    HIP_TRY(ctx, hipMemsetAsync(d_ctl, 0, (N_SEG + 2) * 8, ctx->stream));
+    if (!ctx->sel_ctl_clean) HIP_TRY(ctx, hipMemsetAsync(d_ctl, 0, (N_SEG + 2) * 8, ctx->stream)); // (else: cleared by the previous call's last kernel)
+    ctx->sel_ctl_clean = false;
     SelParams S;
     S.code = g->d_code + PAD;
     if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
@@ -2497,14 +2509,21 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
       }
       SK_HIP(hipGetLastError());
     }
+    // the last kernel of the call also clears the pruned pass's control block for the next call (one fill launch less
+    // at the head of every sketch)
+    uint64_t* const sel_ctl = pruned ? (uint64_t*)ws_get(ctx, "sel_ctl", (N_SEG + 2) * 8) : nullptr;
     if (!res.d_ctl) {
       Mail done(ctx); // nothing to fetch: only the arrival flag
+      if (sel_ctl) done.clear_after(sel_ctl, N_SEG + 2);
       SK_TRY(done.post(ctx));
+      ctx->sel_ctl_clean = sel_ctl != nullptr;
       break;
     }
     Mail mb(ctx);
     const uint32_t at = mb.add(res.d_ctl, 3);
+    if (sel_ctl) mb.clear_after(sel_ctl, N_SEG + 2);
     SK_TRY(mb.post(ctx));
+    ctx->sel_ctl_clean = sel_ctl != nullptr;
     if (ctx->mail[at + 2] == 0) {
       mx->n = ctx->mail[at + 1];
       break;
