@@ -360,6 +360,46 @@ def test_uncovered_ranges_device_merge_and_its_fallback(ctx, w, n):
         ctx.sketch_mode("auto", 64)
 
 
+@pytest.mark.parametrize("lo,hi", [(40, 400), (30, 110), (1500, 6000)])
+def test_fragmented_assembly_sketch_and_bloom(ctx, lo, hi):
+    """Thousands of short records: every tile of the select and Bloom kernels spans many runs, lanes have run boundaries
+    inside (several per wave; with records of ~70 bases more per tile than the Bloom kernel's side buffer holds).
+    Sketch (pruned, forced and automatic) and both Bloom builds against the oracle."""
+    from ntsynt_amd.device import BloomFilter, sketch
+    rng = np.random.default_rng(lo)
+    total = 260_000
+    lengths = []
+    while sum(lengths) < total:
+        lengths.append(int(rng.integers(lo, hi)))
+    k = 24
+    names, seqs = _family(9000 + lo, lengths=lengths, n_frac=0.002)
+    og, dg = to_oracle(names, seqs), to_device(ctx, names, seqs)
+    nbytes = 1 << 20
+    want_bf = O.bf_build(og, k, nbytes)
+    try:
+        for mode in ("atomic", "binned"):
+            ctx.bf_build_mode(mode)
+            bf = BloomFilter(ctx, nbytes, k)
+            bf.insert(dg)
+            assert np.array_equal(bf.to_numpy(), want_bf), mode
+    finally:
+        ctx.bf_build_mode("auto")
+    keep = want_bf.copy()
+    keep[::2] = 0
+    bf.from_numpy(keep)
+    try:
+        for mode, c in (("pruned", 4), ("pruned", 40), ("auto", 0)):
+            ctx.sketch_mode(mode, c)
+            for w in (300, 64, 20):
+                for fo, fd in ((keep, bf), (None, None)):
+                    exp = oracle_flat(O.minimize(og, k, w, fo))
+                    got = sketch(ctx, dg, k, w, fd).to_numpy()
+                    for a, b in zip(got, exp):
+                        assert np.array_equal(a, b.astype(a.dtype)), (mode, c, w, fo is None)
+    finally:
+        ctx.sketch_mode("auto", 64)
+
+
 @pytest.mark.parametrize("k", [1, 129, 200])
 def test_long_and_degenerate_k_end_to_end(ctx, k):
     """k beyond the LDS-staged fast paths (and k = 1): Bloom build (both builds), pruned and dense sketch vs the oracle"""
