@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end parity: synthetic genome families with random size, fragmentation, divergence and parameters
+through the GPU pipeline and through the CPU oracle pipeline; the synteny-block TSVs must be byte-identical.
+python scripts/stress_pipeline.py [--seconds 240] [--seed 1]"""
+import argparse
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ntsynt_amd import pipeline, synth  # noqa: E402
+from oracle import synteny_oracle as SO  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    cwd = os.getcwd()
+    n = 0
+    blocks = 0
+    while time.time() < t_end:
+        case = dict(n=int(rng.integers(2, 5)), bp=int(rng.integers(600_000, 3_000_000)), ctg=int(rng.choice([1, 2, 5, 40, 300])),
+                    div=float(rng.choice([0.002, 0.01, 0.03, 0.06])), seed=int(rng.integers(1, 10_000)),
+                    micro=int(rng.choice([0, 6, 12])), n_runs=bool(rng.integers(0, 2)))
+        w = int(rng.choice([200, 250, 500, 1000]))
+        kw = dict(k=int(rng.choice([20, 24, 32])), w=w, w_rounds=[int(x) for x in rng.choice([[100, 10], [250, 100], [50, 5]])],
+                  indel=int(rng.choice([500, 5000, 50000])), merge=rng.choice([3000, 20000, "100w", "3w"]).item(),
+                  block_size=int(rng.choice([200, 500, 1000])))
+        if isinstance(kw["merge"], str) and kw["merge"].isdigit():
+            kw["merge"] = int(kw["merge"])
+        tmp = tempfile.mkdtemp(prefix="nts_stress_")
+        try:
+            paths = synth.make_family(tmp, case["n"], case["bp"], case["ctg"], case["div"], seed=case["seed"], micro=case["micro"],
+                                      n_runs=case["n_runs"], soft_mask=True, line_width=(60 if case["seed"] % 2 else 0))
+            os.makedirs(os.path.join(tmp, "ora"))
+            os.makedirs(os.path.join(tmp, "hip"))
+            os.chdir(os.path.join(tmp, "ora"))
+            ora = SO.run_pipeline(paths, prefix="p", **kw)
+            os.chdir(os.path.join(tmp, "hip"))
+            eng = pipeline.run(paths, prefix="p", log=lambda *a: None, **kw)
+            for name in ("p.synteny_blocks.tsv", "p.pre-collinear-merge.synteny_blocks.tsv"):
+                if eng.outputs[name] != ora.outputs[name]:
+                    print("PIPELINE MISMATCH", name, case, kw, "seed", args.seed, "case", n)
+                    sys.exit(1)
+            blocks += len(eng.outputs["p.synteny_blocks.tsv"].splitlines()) // max(case["n"], 1)
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(tmp, ignore_errors=True)
+        n += 1
+    print(f"ok: {n} families end to end, {blocks} synteny blocks, seed {args.seed}")
+
+
+if __name__ == "__main__":
+    main()
