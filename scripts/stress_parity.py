@@ -14,11 +14,11 @@ from oracle import nts_oracle as O  # noqa: E402
 from tests.helpers import oracle_flat, random_records, to_device, to_oracle  # noqa: E402
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     from ntsynt_amd.device import BloomFilter, Context, Genome, sketch
     ctx = Context(0)
     rng = np.random.default_rng(args.seed)

@@ -16,11 +16,11 @@ from ntsynt_amd import pipeline, synth  # noqa: E402
 from oracle import synteny_oracle as SO  # noqa: E402
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
     cwd = os.getcwd()
