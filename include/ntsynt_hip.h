@@ -238,6 +238,10 @@ int nts_walk_chains(uint64_t nv, uint64_t ne, const uint32_t* e_u, const uint32_
 int nts_walk_paths(uint64_t nv, uint64_t ne, const int64_t* e_u, const int64_t* e_v, const uint8_t* e_alive,
                    const int64_t* key, uint64_t** off, int64_t** verts, uint64_t* n_paths);
 
+/* Host-side helper (host threads): dst[i] = src[i] as a 64-bit integer, src holding 32-bit (src_bytes 4) or 64-bit (8)
+ * unsigned values -- how a caller that keeps everything in int64 (the Python engine) takes over nts_graph's arrays. */
+int nts_to_i64(const void* src, uint32_t src_bytes, uint64_t n, int64_t* dst);
+
 /* Host-side helper: deg[v] = number of live edge ends at v, saturating at 255 (bubble detection asks
  * "degree 3", bin/ntsynt_synteny.py:548-590; path ends ask "degree 1"). */
 int nts_edge_degrees(uint64_t nv, uint64_t ne, const int64_t* e_u, const int64_t* e_v, const uint8_t* e_alive,

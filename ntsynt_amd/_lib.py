@@ -85,6 +85,7 @@ SYMBOLS = [
     ("nts_walk_chains", ctypes.c_int, [u64, u64, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_u32p), c_u64p]),
     ("nts_walk_paths", ctypes.c_int, [u64, u64, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_i64p), c_u64p]),
     ("nts_edge_degrees", ctypes.c_int, [u64, u64, c_vp, c_vp, c_vp, c_vp]),
+    ("nts_to_i64", ctypes.c_int, [c_vp, u32, u64, c_vp]),
     ("nts_path_scan", ctypes.c_int, [u32, u64, c_vp, c_vp, u64, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, c_vp]),
     ("nts_graph_free", None, [ctypes.POINTER(Graph)]),
     ("nts_fasta_read", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Fasta)]),

@@ -493,6 +493,23 @@ extern "C" int nts_walk_paths(uint64_t nv, uint64_t ne, const int64_t* e_u, cons
   return walk_impl<int64_t, int64_t>(nv, ne, e_u, e_v, e_alive, key, off, verts, n_paths);
 }
 
+// dst[i] = src[i] widened to 64 bits (src_bytes = 4) or copied (8), over host threads: the graph build hands its arrays to
+// the engine this way (numpy's astype does the same on one thread: 0.15 s for the 65 M elements of a 3 x 3 Gbp run).
+extern "C" int nts_to_i64(const void* src, uint32_t src_bytes, uint64_t n, int64_t* dst)
+{
+  if (n && (!src || !dst)) return NTS_EINVAL;
+  if (src_bytes != 4 && src_bytes != 8) return NTS_EINVAL;
+  parallel_ranges(n, host_threads(16), [&](unsigned, uint64_t lo, uint64_t hi) {
+    if (src_bytes == 4) {
+      const uint32_t* s4 = (const uint32_t*)src;
+      for (uint64_t i = lo; i < hi; ++i) dst[i] = (int64_t)s4[i];
+    } else {
+      memcpy(dst + lo, (const uint64_t*)src + lo, (hi - lo) * 8);
+    }
+  });
+  return NTS_OK;
+}
+
 // Degree of every vertex over the live edges, saturating at 255 (the engine asks "== 1" and "== 3").
 extern "C" int nts_edge_degrees(uint64_t nv, uint64_t ne, const int64_t* e_u, const int64_t* e_v, const uint8_t* e_alive, uint8_t* deg)
 {

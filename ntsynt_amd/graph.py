@@ -35,7 +35,11 @@ def build_graph_device(ctx, lists, keeps=None, list_ids=None):
     def take(ptr, n, dtype):
         if n == 0:
             return np.zeros(0, dtype=dtype)
-        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+        out = np.empty(n, dtype=dtype)          # widened / copied by the library's host threads (nts_to_i64)
+        src_bytes = ctypes.sizeof(ptr._type_)
+        if ctx.lib.nts_to_i64(ctypes.cast(ptr, ctypes.c_void_p), src_bytes, n, out.ctypes.data) != 0:
+            raise RuntimeError("nts_to_i64 failed")
+        return out
     out = GraphArrays(
         v_hash=take(g.v_hash, nv, np.uint64),
         occ_rec=take(g.occ_rec, G * nv, np.int64).reshape(G, nv),
