@@ -146,4 +146,14 @@ __device__ __forceinline__ void bf_set(uint32_t* words, uint64_t idx)
   atomicOr(&words[idx >> 5], 1u << (idx & 31));
 }
 
+// The same, looking first (a load past the L1, which the atomics of other workgroups do not update): the overflow of the
+// partitioned build is made of the copies of a few k-mers -- satellite arrays -- and after the first copy of each the
+// bit is there; millions of atomics on a few hundred words are what this avoids.
+__device__ __forceinline__ void bf_set_unless_set(uint32_t* words, uint64_t idx)
+{
+  uint32_t* w = &words[idx >> 5];
+  const uint32_t bit = 1u << (idx & 31);
+  if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
+}
+
 } // namespace nts
