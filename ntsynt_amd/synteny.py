@@ -491,32 +491,34 @@ class SyntenyEngine:
                 is_internal[order] = uh[p] == sh
             inside = np.zeros(h1.size, bool)
             cut_before = np.zeros(h1.size, bool)
-            for r, ivs in spans[a].items():
-                sel = np.flatnonzero((rec == r) & uniq)
-                if sel.size == 0:
-                    continue
-                ivs = sorted(ivs)
-                st = np.array([x[0] for x in ivs], np.int64)
-                mx_end = np.maximum.accumulate(np.array([x[1] for x in ivs], np.int64))
+            # "does [s, e) of record r reach into a block interior of r?" for all records at once: intervals and queries
+            # as composite keys record * 2^40 + position; the running maximum of the interval ends (S:194-203's merged
+            # intervals) never carries over from one record to the next because a later record's keys are all larger
+            OFF = np.int64(1) << 40
+            if spans[a] and (max(spans[a]) >= (1 << 22) or (pos.size and int(pos.max()) >= (1 << 40) - 1)):
+                raise ValueError("more than 2^22 records or a record beyond 2^40 bases: composite interval keys would overflow")
+            if spans[a]:
+                ir = np.concatenate([np.full(len(v), r, np.int64) for r, v in spans[a].items()])
+                iv = np.array([x for v in spans[a].values() for x in v], np.int64).reshape(-1, 2)
+                order = np.argsort(ir * OFF + iv[:, 0], kind="stable")
+                comp_s = (ir * OFF + iv[:, 0])[order]
+                comp_mx = np.maximum.accumulate((ir * OFF + iv[:, 1])[order])
 
-                def overlaps(s, e):
-                    i = np.searchsorted(st, e, side="left")
-                    return (i > 0) & (mx_end[np.maximum(i - 1, 0)] > s) & (e > s)
-                pp = pos[sel]
-                inside[sel] = overlaps(pp, pp + 1)
+                def overlaps(r, s0, e0):
+                    base = r * OFF
+                    i = np.searchsorted(comp_s, base + e0, side="left")
+                    j = np.maximum(i - 1, 0)
+                    return (i > 0) & (comp_s[j] >= base) & (comp_mx[j] > base + s0) & (e0 > s0)
+                sel = np.flatnonzero(uniq)
+                inside[sel] = overlaps(rec[sel], pos[sel], pos[sel] + 1)
             kept = uniq & ~is_internal & ~inside
-            # cut a list wherever the span between two consecutive kept minimizers crosses a block interior
-            for r, ivs in spans[a].items():
-                sel = np.flatnonzero((rec == r) & kept)
-                if sel.size < 2:
-                    continue
-                ivs = sorted(ivs)
-                st = np.array([x[0] for x in ivs], np.int64)
-                mx_end = np.maximum.accumulate(np.array([x[1] for x in ivs], np.int64))
-                s, e = pos[sel[:-1]], pos[sel[1:]]
-                i = np.searchsorted(st, e, side="left")
-                ov = (i > 0) & (mx_end[np.maximum(i - 1, 0)] > s) & (e > s)
-                cut_before[sel[1:][ov]] = True
+            # cut a list wherever the span between two consecutive kept minimizers (of one record) crosses a block interior
+            if spans[a]:
+                sel = np.flatnonzero(kept)
+                if sel.size > 1:
+                    same = rec[sel[1:]] == rec[sel[:-1]]
+                    ov = same & overlaps(rec[sel[1:]], pos[sel[:-1]], pos[sel[1:]])
+                    cut_before[sel[1:][ov]] = True
             # list ids: a new list at every record change and at every cut
             new_list = np.ones(h1.size, bool)
             if h1.size:
