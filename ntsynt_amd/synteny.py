@@ -455,18 +455,22 @@ class SyntenyEngine:
         nv = self.v_hash.size
         internal = np.zeros(nv, bool)
         terminal = np.zeros(nv, bool)
-        for b in blocks:
-            terminal[b.vids[0]] = True
-            terminal[b.vids[-1]] = True
-            internal[b.vids[1:-1]] = True
-        # block interiors [min+1, max) per assembly, per contig (S:194-203)
-        spans = [dict() for _ in range(self.G)]
-        for b in blocks:
-            for a in range(self.G):
-                lo = min(int(self.v_pos[a][b.vids[0]]), int(self.v_pos[a][b.vids[-1]]))
-                hi = max(int(self.v_pos[a][b.vids[0]]), int(self.v_pos[a][b.vids[-1]]))
-                if hi - lo >= 2:
-                    spans[a].setdefault(b.rec[a], []).append((lo + 1, hi))
+        first = np.array([b.vids[0] for b in blocks], np.int64)
+        last = np.array([b.vids[-1] for b in blocks], np.int64)
+        terminal[first] = True
+        terminal[last] = True
+        if blocks:
+            inner = np.concatenate([b.vids[1:-1] for b in blocks])
+            internal[inner] = True
+        # block interiors [min+1, max) per assembly, per contig (S:194-203): per assembly the records and the intervals
+        # of all blocks as arrays (tens of thousands of blocks in a fragmented assembly)
+        spans = []
+        for a in range(self.G):
+            p0, p1 = self.v_pos[a][first], self.v_pos[a][last]
+            lo, hi = np.minimum(p0, p1), np.maximum(p0, p1)
+            ok = hi - lo >= 2
+            recs = np.array([b.rec[a] for b in blocks], np.int64)
+            spans.append((recs[ok], lo[ok] + 1, hi[ok]))
         hs, hid = self._live_index()
         uh = hs[internal[hid]]                             # hashes of the live internal vertices, ascending
         lists, keeps, list_ids = [], [], []
@@ -495,14 +499,14 @@ class SyntenyEngine:
             # as composite keys record * 2^40 + position; the running maximum of the interval ends (S:194-203's merged
             # intervals) never carries over from one record to the next because a later record's keys are all larger
             OFF = np.int64(1) << 40
-            if spans[a] and (max(spans[a]) >= (1 << 22) or (pos.size and int(pos.max()) >= (1 << 40) - 1)):
+            ir, iv_s, iv_e = spans[a]
+            have = ir.size > 0
+            if have and (int(ir.max()) >= (1 << 22) or (pos.size and int(pos.max()) >= (1 << 40) - 1)):
                 raise ValueError("more than 2^22 records or a record beyond 2^40 bases: composite interval keys would overflow")
-            if spans[a]:
-                ir = np.concatenate([np.full(len(v), r, np.int64) for r, v in spans[a].items()])
-                iv = np.array([x for v in spans[a].values() for x in v], np.int64).reshape(-1, 2)
-                order = np.argsort(ir * OFF + iv[:, 0], kind="stable")
-                comp_s = (ir * OFF + iv[:, 0])[order]
-                comp_mx = np.maximum.accumulate((ir * OFF + iv[:, 1])[order])
+            if have:
+                order = np.argsort(ir * OFF + iv_s, kind="stable")
+                comp_s = (ir * OFF + iv_s)[order]
+                comp_mx = np.maximum.accumulate((ir * OFF + iv_e)[order])
 
                 def overlaps(r, s0, e0):
                     base = r * OFF
@@ -513,7 +517,7 @@ class SyntenyEngine:
                 inside[sel] = overlaps(rec[sel], pos[sel], pos[sel] + 1)
             kept = uniq & ~is_internal & ~inside
             # cut a list wherever the span between two consecutive kept minimizers (of one record) crosses a block interior
-            if spans[a]:
+            if have:
                 sel = np.flatnonzero(kept)
                 if sel.size > 1:
                     same = rec[sel[1:]] == rec[sel[:-1]]
