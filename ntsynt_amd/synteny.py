@@ -89,6 +89,7 @@ class SyntenyEngine:
             from .graph import scan_paths as scan_fn       # native host helper (nts_path_scan)
         self.scan_fn = scan_fn
         self.degree_fn = degree_fn
+        self._asm_names = None
         self.times = {}
         if os.environ.get("NTS_ENGINE_TIMES"):             # wall clock per step, for scripts/e2e_run.py
             self._instrument()
@@ -372,19 +373,41 @@ class SyntenyEngine:
     def _end(self, b, a):
         return max(b.first_pos[a], b.last_pos[a]) + self.k
 
+    def _finish_all(self, blocks):
+        "first/last positions of every block that does not have them yet, gathered per assembly in one indexing each"
+        todo = [b for b in blocks if not b.first_pos]
+        if not todo:
+            return
+        first = np.array([b.vids[0] for b in todo], np.int64)
+        last = np.array([b.vids[-1] for b in todo], np.int64)
+        fp = [self.v_pos[a][first].tolist() for a in range(self.G)]
+        lp = [self.v_pos[a][last].tolist() for a in range(self.G)]
+        for i, b in enumerate(todo):
+            b.first_pos = [fp[a][i] for a in range(self.G)]
+            b.last_pos = [lp[a][i] for a in range(self.G)]
+            b.n_mx = int(b.vids.size)
+
     def _long_enough(self, b):
-        return all(self._end(b, a) - self._start(b, a) >= self.z for a in range(self.G))
+        need = self.z - self.k                                 # end - start = |first - last| + k
+        for f, l in zip(b.first_pos, b.last_pos):
+            if abs(f - l) < need:
+                return False
+        return True
 
     def _sorted(self, blocks):
-        for b in blocks:
-            self._finish(b)
-        return sorted(blocks, key=lambda b: (self.contigs[self.ref][b.rec[self.ref]], self._start(b, self.ref)))
+        self._finish_all(blocks)
+        ref, names = self.ref, self.contigs[self.ref]
+        return sorted(blocks, key=lambda b: (names[b.rec[ref]], min(b.first_pos[ref], b.last_pos[ref])))
 
     def _text(self, b, num, verbose):
         rows = []
+        if self._asm_names is None:                            # assembly names as printed: the TSV name without its suffix
+            self._asm_names = []
+            for f in self.files:
+                mt = MX_SUFFIX.search(f)
+                self._asm_names.append(mt.group(1) if mt else f)
         for a in self.out_order:
-            mt = MX_SUFFIX.search(self.files[a])
-            name = mt.group(1) if mt else self.files[a]
+            name = self._asm_names[a]
             row = f"{num}\t{name}\t{self.contigs[a][b.rec[a]]}\t{self._start(b, a)}\t{self._end(b, a)}\t{b.ori[a]}\t{b.n_mx}"
             if verbose:
                 row = f"{row.strip()}\t{b.reason}"
@@ -440,8 +463,8 @@ class SyntenyEngine:
     def _mask_intervals(self, blocks, w):
         masks = [[] for _ in range(self.G)]
         lim = max(2 * w, w + self.k + 1)
+        self._finish_all(blocks)
         for b in blocks:
-            self._finish(b)
             for a in range(self.G):
                 s, e = self._start(b, a), self._end(b, a)
                 if e - s > lim:
