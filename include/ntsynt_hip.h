@@ -28,6 +28,7 @@ extern "C" {
 #define NTS_ENOMEM (-12)
 #define NTS_EHIP (-5)
 #define NTS_ERANGE (-34)
+#define NTS_EFORMAT (-74) /* input file is not FASTA (e.g. FASTQ) */
 
 typedef struct nts_ctx nts_ctx;
 typedef struct nts_genome nts_genome; /* one FASTA resident in HBM */
@@ -63,6 +64,16 @@ int nts_timing(nts_ctx* ctx, const char* name, double* total_ms, uint64_t* launc
  * the btllib::KmerBloomFilter constructor used at :122-123.  approx_bytes = ceil(-n/ln(1-fpr))/8
  * (truncating), ctor_bytes = approx_bytes rounded up to a multiple of 8. */
 int nts_bf_size_bytes(uint64_t genome_bp, double fpr, uint64_t* approx_bytes, uint64_t* ctor_bytes);
+/* The constructor's rounding is recalled from btllib's source, which is not in the reference tree,
+ * and it decides the modulus of every bit index: a maintainer holding btllib can settle it by flipping this switch.
+ *   NTS_BF_ROUND_UP   ceil(double(bytes) / 8) * 8   -- the default, what nts_bf_size_bytes() returns
+ *   NTS_BF_ROUND_DOWN (bytes / 8) * 8               -- an integer division inside the ceil
+ *   NTS_BF_ROUND_NONE bytes as approximate_bf_size() returned them
+ * Every filter entry point accepts any positive byte count. */
+#define NTS_BF_ROUND_UP 0
+#define NTS_BF_ROUND_DOWN 1
+#define NTS_BF_ROUND_NONE 2
+int nts_bf_size_bytes_ex(uint64_t genome_bp, double fpr, int rounding, uint64_t* approx_bytes, uint64_t* ctor_bytes);
 
 /* ---- genome ---------------------------------------------------------------------------------
  * replaces btllib::SeqReader(path, LONG_MODE) record streaming (src/...cpp:32-36,125-131).
@@ -262,7 +273,8 @@ int nts_path_scan(uint32_t n_asm, uint64_t nv, const int64_t* v_rec, const int64
 
 /* ---- host-side I/O (no GPU work) ---------------------------------------------------------------------
  * nts_fasta_read: plain or gzip FASTA, single- or multi-line, LF or CRLF -> concatenated bases + record table +
- *   record ids (header up to the first whitespace, NUL-separated) + the `samtools faidx` columns.  Replaces
+ *   record ids (header up to the first whitespace, NUL-separated) + the `samtools faidx` columns; NTS_EFORMAT for a
+ *   non-empty file that does not start with a '>' header (FASTQ is not accepted).  Replaces
  *   btllib::SeqReader(LONG_MODE) record streaming (src/ntsynt_make_common_bf.cpp:32-36) and rule faidx (smk:48-53).
  * nts_write_indexlr_tsv: `indexlr --long --pos [--seq]` text (smk:81-85): "id\thash:pos[:KMER] ...\n" per record;
  *   minimizers given in (record, position) order as nts_mx_download returns them. */

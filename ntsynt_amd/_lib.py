@@ -46,6 +46,7 @@ SYMBOLS = [
     ("nts_profile", ctypes.c_int, [c_vp, ctypes.c_int]),
     ("nts_timing", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), c_u64p]),
     ("nts_bf_size_bytes", ctypes.c_int, [u64, ctypes.c_double, c_u64p, c_u64p]),
+    ("nts_bf_size_bytes_ex", ctypes.c_int, [u64, ctypes.c_double, ctypes.c_int, c_u64p, c_u64p]),
     ("nts_genome_upload", ctypes.c_int, [c_vp, c_vp, u64, c_u64p, c_u64p, u32, ctypes.POINTER(c_vp)]),
     ("nts_genome_synth", ctypes.c_int, [c_vp, u64, u32, u64, u64, ctypes.c_double, ctypes.POINTER(c_vp)]),
     ("nts_genome_download", ctypes.c_int, [c_vp, c_vp, u64, u64, c_vp]),

@@ -60,6 +60,9 @@ def build_parser():
     p.add_argument("-f", "--force", help="Run all ntSynt steps, regardless of existing output files", action="store_true")
     p.add_argument("--dev", help="Run in developer mode: more verbose logging", action="store_true")
     p.add_argument("--device", help="GPU index [0]", type=int, default=0)
+    # switches for the two btllib details this implementation recalls rather than reads
+    p.add_argument("--bf-rounding", help=argparse.SUPPRESS, choices=["up", "down", "none"], default="up")
+    p.add_argument("--bf-signature", help=argparse.SUPPRESS, default=None)
     p.add_argument("-v", "--version", action="version", version=NTSYNT_VERSION)
     return p
 
@@ -98,8 +101,10 @@ def main(argv=None):
     parser = build_parser()
     args = parser.parse_args(argv)
     fastas = resolve(parser, args)
-    print(NTSYNT_ASCII)
-    print("\n".join(["Running ntSynt...",
+    rank0 = int(os.environ.get("RANK", "0")) == 0                # under torchrun every rank runs this; one of them talks
+    say = print if rank0 else (lambda *a, **k: None)
+    say(NTSYNT_ASCII)
+    say("\n".join(["Running ntSynt...",
                      f"Specified percent divergence: {args.divergence}",
                      "Parameter settings:",
                      f"\tfastas {fastas}",
@@ -122,7 +127,7 @@ def main(argv=None):
     plan = ["faidx x%d" % len(fastas)] + ([] if args.no_common else ["make_common_bf"]) + \
            ["indexlr x%d" % len(fastas), "ntsynt_synteny"]
     if args.dry_run:
-        print("Stages (GPU, in process):", " -> ".join(plan))
+        say("Stages (GPU, in process):", " -> ".join(plan))
         return 0
     from . import pipeline
     # one process per GPU under `python -m torch.distributed.run --nproc-per-node N bin/ntSynt ...`:
@@ -148,6 +153,7 @@ def main(argv=None):
     pipeline.run(fastas, k=args.k, w=args.w, fpr=args.fpr, prefix=args.prefix, w_rounds=args.w_rounds,
                  indel=args.indel, merge=args.merge, block_size=args.block_size, common=not args.no_common,
                  simplify=not args.no_simplify_graph, device=device, benchmark=args.benchmark,
+                 bf_rounding=args.bf_rounding, bf_signature=args.bf_signature or pipeline.BF_SIGNATURE,
                  log=print if (args.dev and int(os.environ.get("RANK", "0")) == 0) else quiet)
     if world > 1:
         dist.barrier()

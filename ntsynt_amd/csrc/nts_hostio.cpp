@@ -157,6 +157,15 @@ extern "C" int nts_fasta_read(const char* path, nts_fasta* out)
   if (!file.open(path)) return NTS_EINVAL;
   const uint8_t* const data = file.p;
   const size_t n = file.n;
+  bool blank = true;
+  {
+    // FASTA only: FASTQ (first non-blank byte '@') would parse as zero records and the run would go on with an empty
+    // assembly; so would any other non-blank file without a single '>' header (checked after the parse)
+    size_t q = 0;
+    while (q < n && (data[q] == '\n' || data[q] == '\r' || data[q] == ' ' || data[q] == '\t')) ++q;
+    blank = q == n;
+    if (!blank && data[q] == '@') return NTS_EFORMAT;
+  }
   uint8_t* seq = (uint8_t*)big_alloc(n);
   if (!seq) return NTS_ENOMEM;
   std::vector<uint64_t> rec_off, rec_len, fai_off;
@@ -206,6 +215,10 @@ extern "C" int nts_fasta_read(const char* path, nts_fasta* out)
     i = nl ? line_end + 1 : n;
   }
   if (in_record) rec_len.back() = w - rec_off.back();
+  if (rec_off.empty() && !blank) {
+    free(seq);
+    return NTS_EFORMAT;
+  }
   for (size_t r = 0; r < rec_len.size(); ++r)
     if (rec_len[r] == 0) fai_bases[r] = fai_width[r] = 0;
   out->seq = seq;

@@ -1308,16 +1308,24 @@ int nts_timing(nts_ctx* ctx, const char* name, double* total_ms, uint64_t* launc
   return NTS_OK;
 }
 
-int nts_bf_size_bytes(uint64_t genome_bp, double fpr, uint64_t* approx_bytes, uint64_t* ctor_bytes)
+int nts_bf_size_bytes_ex(uint64_t genome_bp, double fpr, int rounding, uint64_t* approx_bytes, uint64_t* ctor_bytes)
 {
-  if (!(fpr > 0.0 && fpr < 1.0)) return NTS_EINVAL;
+  if (!(fpr > 0.0 && fpr < 1.0) || rounding < NTS_BF_ROUND_UP || rounding > NTS_BF_ROUND_NONE) return NTS_EINVAL;
   // src/ntsynt_make_common_bf.cpp:38-39
   const long long genome_size = (long long)genome_bp;
   const long long size_bits = (long long)std::ceil(((double)(-1 * genome_size)) / std::log(1 - fpr));
   const uint64_t approx = (uint64_t)(size_bits / 8);
   if (approx_bytes) *approx_bytes = approx;
-  if (ctor_bytes) *ctor_bytes = (uint64_t)(std::ceil((double)approx / 8.0) * 8.0);
+  uint64_t ctor = approx;
+  if (rounding == NTS_BF_ROUND_UP) ctor = (uint64_t)(std::ceil((double)approx / 8.0) * 8.0);
+  if (rounding == NTS_BF_ROUND_DOWN) ctor = approx / 8 * 8;
+  if (ctor_bytes) *ctor_bytes = ctor;
   return NTS_OK;
+}
+
+int nts_bf_size_bytes(uint64_t genome_bp, double fpr, uint64_t* approx_bytes, uint64_t* ctor_bytes)
+{
+  return nts_bf_size_bytes_ex(genome_bp, fpr, NTS_BF_ROUND_UP, approx_bytes, ctor_bytes);
 }
 
 int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64_t* rec_off, const uint64_t* rec_len,
@@ -1571,7 +1579,7 @@ int nts_genome_valid_kmers(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64
 // ---- Bloom filter ------------------------------------------------------------------------------------
 int nts_bf_create(nts_ctx* ctx, uint64_t bytes, nts_bf** out)
 {
-  if (!ctx || !out || bytes == 0 || (bytes % 8) != 0) return fail(ctx, NTS_EINVAL, "nts_bf_create: bytes must be a positive multiple of 8");
+  if (!ctx || !out || bytes == 0) return fail(ctx, NTS_EINVAL, "nts_bf_create: bytes must be positive");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   nts_bf* bf = new nts_bf();
   bf->bytes = bytes;
@@ -1601,8 +1609,8 @@ void nts_bf_free(nts_ctx* ctx, nts_bf* bf)
 
 int nts_bf_wrap(nts_ctx* ctx, void* device_ptr, uint64_t bytes, nts_bf** out)
 {
-  if (!ctx || !out || !device_ptr || bytes == 0 || (bytes % 8) != 0 || ((uintptr_t)device_ptr % 16) != 0)
-    return fail(ctx, NTS_EINVAL, "nts_bf_wrap: need a 16-byte aligned buffer and a positive multiple of 8 bytes");
+  if (!ctx || !out || !device_ptr || bytes == 0 || ((uintptr_t)device_ptr % 16) != 0)
+    return fail(ctx, NTS_EINVAL, "nts_bf_wrap: need a 16-byte aligned buffer and a positive byte count");
   nts_bf* bf = new nts_bf();
   bf->bytes = bytes;
   bf->d_words = (uint32_t*)device_ptr;

@@ -79,10 +79,15 @@ class Context:
             pass
 
 
-def bf_size_bytes(genome_bp, fpr):
-    """(approx_bytes, ctor_bytes): src/ntsynt_make_common_bf.cpp:28-40 + btllib ctor rounding."""
+BF_ROUNDING = {"up": 0, "down": 1, "none": 2}
+
+
+def bf_size_bytes(genome_bp, fpr, rounding="up"):
+    """(approx_bytes, ctor_bytes): src/ntsynt_make_common_bf.cpp:28-40 + btllib ctor rounding.  `rounding` selects the
+    constructor's rule ('up' = ceil(bytes / 8.0) * 8, recalled from btllib; 'down' and 'none' are the alternatives a
+    reader of btllib's source can switch to: SURVEY.md 8(c) u1)."""
     a, c = u64(), u64()
-    rc = _lib.load().nts_bf_size_bytes(int(genome_bp), float(fpr), ctypes.byref(a), ctypes.byref(c))
+    rc = _lib.load().nts_bf_size_bytes_ex(int(genome_bp), float(fpr), BF_ROUNDING[rounding], ctypes.byref(a), ctypes.byref(c))
     if rc != 0:
         raise NtsError("nts_bf_size_bytes: bad arguments")
     return a.value, c.value

@@ -47,6 +47,8 @@ def read_fasta(path):
     lib = _lib.load()
     f = _lib.Fasta()
     rc = lib.nts_fasta_read(os.fsencode(path), ctypes.byref(f))
+    if rc == -74:                                             # NTS_EFORMAT
+        raise ValueError(f"{path!r} is not a FASTA file (a FASTA file starts with a '>' header; FASTQ is not accepted)")
     if rc != 0:
         raise OSError(f"cannot read FASTA file {path!r} (code {rc})")
     n_rec, n = int(f.n_rec), int(f.n)

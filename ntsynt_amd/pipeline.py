@@ -23,10 +23,15 @@ from .graph import edge_degrees
 from .synteny import SyntenyEngine
 
 
-def write_bf(path, bits, k, hash_num=1):
-    """btllib KmerBloomFilter file: TOML-style header + raw bit array (layout recalled from btllib's
-    BloomFilter::save, not verifiable here: SURVEY.md 8(f) rank 3)."""
-    header = (f"[BTLKmerBloomFilter_v5]\nbytes = {bits.size}\nhash_fn = \"ntHash_v2\"\n"
+BF_SIGNATURE = "[BTLKmerBloomFilter_v5]"
+
+
+def write_bf(path, bits, k, hash_num=1, signature=BF_SIGNATURE):
+    """btllib KmerBloomFilter file: TOML-style header + raw bit array.  The layout (table name `signature`, keys
+    bytes / hash_fn / hash_num / k, terminator [HeaderEnd]) is recalled from btllib's BloomFilter::save, which is not in
+    the reference tree: the file is NOT guaranteed to load in a stock btllib (`indexlr -s`).
+    The table name is a parameter (`--bf-signature`) so that a maintainer holding a real btllib file can match it."""
+    header = (f"{signature}\nbytes = {bits.size}\nhash_fn = \"ntHash_v2\"\n"
               f"hash_num = {hash_num}\nk = {k}\n\n[HeaderEnd]\n")
     with open(path, "wb") as fh:
         fh.write(header.encode())
@@ -46,6 +51,10 @@ def read_bf(path):
 
 
 write_indexlr_tsv = fa.write_indexlr_tsv      # native writer (csrc/nts_hostio.cpp)
+
+MAX_W = 12000                  # nts_sketch: NTS_ERANGE beyond (csrc/ntsynt_hip.hip)
+MAX_RECORDS = 1 << 22          # ntsynt_amd/synteny.py _new_round_graph: record * 2^40 + position keys
+MAX_RECORD_BP = (1 << 40) - 1
 
 
 class Stages:
@@ -233,7 +242,7 @@ def _bcast_list(backend, owner, payload):
 
 def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000, merge=10000,
         block_size=500, common=True, simplify=True, device=0, write_mx_tsv=True, mx_with_seq=True,
-        benchmark=False, log=print, ctx=None, backend=None):
+        benchmark=False, log=print, ctx=None, backend=None, bf_rounding="up", bf_signature=BF_SIGNATURE):
     """FASTA paths -> engine (outputs in .outputs and in the CWD).  Mirrors oracle.synteny_oracle.run_pipeline's
     signature so the parity tests read alike.  Under torch.distributed (WORLD_SIZE > 1, process group already
     initialised by the caller) genomes are sharded over the ranks."""
@@ -251,8 +260,20 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     owner = {p: i % world for i, p in enumerate(fastas)}
     mine = [p for p in fastas if owner[p] == rank]
 
+    # limits of this implementation, checked before anything is written (the reference has none of them)
+    for ww in [w] + list(w_rounds):
+        if not 1 <= int(ww) <= MAX_W:
+            raise ValueError(f"window size {ww} outside 1..{MAX_W} (limit of the window kernels)")
     st.start("read_fasta+upload")
     genomes = load_genomes(backend, mine)
+    for p in mine:
+        g = genomes[p]
+        if len(g.names) == 0 or g.total_bp == 0:
+            raise ValueError(f"{p}: no sequence records")
+        rl = getattr(g, "rec_len", None)
+        if len(g.names) >= MAX_RECORDS or (rl is not None and len(rl) and int(np.max(rl)) >= MAX_RECORD_BP):
+            raise ValueError(f"{p}: more than 2^22 records or a record of 2^40 bases or more "
+                             "(limits of the refinement rounds' composite interval keys)")
     for p in mine:
         fa.write_fai(f"{fa.basename(p)}.fai", genomes[p].recs)
     # record names and sizes are needed everywhere (output text, filter sizing)
@@ -272,7 +293,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         st.start("make_common_bf")
         ordered = sorted(fastas)                               # src/ntsynt_make_common_bf.cpp:105-107
         from .device import bf_size_bytes
-        approx, nbytes = bf_size_bytes(meta[ordered[0]][1], fpr)
+        approx, nbytes = bf_size_bytes(meta[ordered[0]][1], fpr, bf_rounding)
         log(f"Genome size (bp): {meta[ordered[0]][1]}")
         log(f"BF size (bytes): {approx}")
         my_sorted = [p for p in ordered if owner[p] == rank]
@@ -322,7 +343,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     if bf is not None and rank == 0:
         # filter file: device -> host copy on the library's copy stream + write, on a writer thread, started once the
         # whole-genome sketches are out of the way (their small read-backs would queue behind the bulk copy)
-        pending_files.append(writers.submit(lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k)))
+        pending_files.append(writers.submit(lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k, signature=bf_signature)))
 
     st.start("ntsynt_synteny")
 
@@ -339,7 +360,14 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         out_prefix = prefix
     eng = SyntenyEngine(tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size, out_prefix,
                         backend.graph, sketch_fn, backend.walk, simplify=simplify, log=log, degree_fn=edge_degrees)
-    eng.run(initial)
+    try:
+        eng.run(initial)
+    except BaseException:
+        # a run that dies after its first round must not leave a plausible-looking block table behind
+        for name in (f"{out_prefix}.synteny_blocks.tsv", f"{out_prefix}.pre-collinear-merge.synteny_blocks.tsv"):
+            if os.path.exists(name):
+                os.remove(name)
+        raise
     if rank != 0:
         eng.outputs = {os.path.basename(n): t for n, t in eng.outputs.items()}
         import shutil

@@ -223,6 +223,16 @@ nts_o_bf_ctor_bytes(uint64_t bytes)
   return (uint64_t)(ceil((double)bytes / 8.0) * 8.0);
 }
 
+/* The same with the rounding as a switch (u1 is recalled, not verifiable in the reference tree):
+ * 0 = up (above), 1 = down ((bytes / 8) * 8, an integer division inside the ceil), 2 = none. */
+uint64_t
+nts_o_bf_ctor_bytes_mode(uint64_t bytes, int rounding)
+{
+  if (rounding == 1) return bytes / 8 * 8;
+  if (rounding == 2) return bytes;
+  return nts_o_bf_ctor_bytes(bytes);
+}
+
 static inline void
 bf_set(uint8_t* bf, uint64_t bits, uint64_t h)
 {

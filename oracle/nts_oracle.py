@@ -38,6 +38,8 @@ def _load(native=False):
     lib.nts_o_bf_approx_bytes.restype = ctypes.c_longlong
     lib.nts_o_bf_ctor_bytes.argtypes = [_u64]
     lib.nts_o_bf_ctor_bytes.restype = _u64
+    lib.nts_o_bf_ctor_bytes_mode.argtypes = [_u64, ctypes.c_int]
+    lib.nts_o_bf_ctor_bytes_mode.restype = _u64
     lib.nts_o_bf_records.argtypes = [_u8p, _u8p, _u64, ctypes.c_char_p, _u64p, _u64p,
                                      ctypes.c_uint32, ctypes.c_uint, ctypes.c_int]
     lib.nts_o_bf_records.restype = None
@@ -100,9 +102,14 @@ def bf_approx_bytes(genome_size, fpr):
     return lib().nts_o_bf_approx_bytes(int(genome_size), float(fpr))
 
 
-def bf_ctor_bytes(nbytes):
-    "btllib BloomFilter constructor rounding (SURVEY.md 8(c) u1)"
-    return lib().nts_o_bf_ctor_bytes(int(nbytes))
+ROUNDING = {"up": 0, "down": 1, "none": 2}
+
+
+def bf_ctor_bytes(nbytes, rounding="up"):
+    "btllib BloomFilter constructor rounding (SURVEY.md 8(c) u1); `rounding`: the alternatives a btllib reader can settle"
+    if rounding == "up":
+        return lib().nts_o_bf_ctor_bytes(int(nbytes))
+    return lib().nts_o_bf_ctor_bytes_mode(int(nbytes), ROUNDING[rounding])
 
 
 class Genome:
@@ -166,13 +173,13 @@ def bf_contains(bf, h0):
     return bool(lib().nts_o_bf_contains(_p8(bf), bf.size, int(h0)))
 
 
-def common_bf(genomes_by_path, k, fpr, threads=1, bf_bytes=None, native=False):
+def common_bf(genomes_by_path, k, fpr, threads=1, bf_bytes=None, native=False, rounding="up"):
     """src/ntsynt_make_common_bf.cpp main(): paths sorted as strings (105-107); size from the
     first (109-118); level 1 then cascade (121-160).  genomes_by_path: {path: Genome}."""
     paths = sorted(genomes_by_path)
     if bf_bytes is None:
         bf_bytes = bf_approx_bytes(genomes_by_path[paths[0]].total_bp, fpr)
-    nbytes = bf_ctor_bytes(bf_bytes)
+    nbytes = bf_ctor_bytes(bf_bytes, rounding)
     bf = bf_build(genomes_by_path[paths[0]], k, nbytes, None, threads, native)
     for p in paths[1:]:
         bf = bf_build(genomes_by_path[p], k, nbytes, bf, threads, native)

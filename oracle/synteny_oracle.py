@@ -682,14 +682,14 @@ def divergence_defaults(d):
 
 def run_pipeline(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000,
                  merge=10000, block_size=500, common=True, simplify=True, threads=1,
-                 write_mx_tsv=True, log=None):
+                 write_mx_tsv=True, log=None, bf_rounding="up"):
     """FASTA paths -> {output file name: text}; files are written into the CWD like the reference.
     Stage order: make_common_bf (smk:55-62) -> indexlr per genome (smk:74-85) -> ntsynt_run.py
     (smk:87-103)."""
     import os
     prefix = prefix or f"ntSynt.k{k}.w{w}"
     genomes = {p: O.read_fasta(p) for p in fastas}
-    bf = O.common_bf(genomes, k, fpr, threads) if common else None
+    bf = O.common_bf(genomes, k, fpr, threads, rounding=bf_rounding) if common else None
     tables, by_tsv = {}, {}
     for p in fastas:
         tsv = f"{os.path.basename(p)}.k{k}.w{w}.tsv"

@@ -78,7 +78,7 @@ def test_fasta_reader_matches_oracle_reader(tmp_path):
 
 def test_native_fasta_edge_cases(tmp_path):
     from ntsynt_amd import fasta as fa
-    cases = [b"", b"no header at all\nACGT\n", b">only\n", b">a\nAC\n\nGT\n>b x y\n", b"junk\n>a\tdesc\r\nAC\r\nG\r\n>b\r\n\r\nT",
+    cases = [b"", b"\n \n", b">only\n", b">a\nAC\n\nGT\n>b x y\n", b"junk\n>a\tdesc\r\nAC\r\nG\r\n>b\r\n\r\nT",
              b">a\nACGT"]
     for i, raw in enumerate(cases):
         p = tmp_path / f"c{i}.fa"
@@ -87,6 +87,12 @@ def test_native_fasta_edge_cases(tmp_path):
         assert a.names == c.names, raw
         assert a.rec_len.tolist() == c.rec_len.tolist(), raw
         assert bytes(a.seq) == bytes(c.seq), raw
+    # not FASTA: FASTQ, or text without a single header -> a dedicated error instead of an empty assembly
+    for i, raw in enumerate([b"@r1\nACGT\n+\nIIII\n", b"no header at all\nACGT\n"]):
+        p = tmp_path / f"bad{i}.fq"
+        p.write_bytes(raw)
+        with pytest.raises(ValueError, match="not a FASTA file"):
+            fa.read_fasta(str(p))
 
 
 def test_native_tsv_writer_matches_oracle_writer(tmp_path):
