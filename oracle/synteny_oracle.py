@@ -486,16 +486,19 @@ class SyntenyOracle:
             seqs.append(rec)
         return O.Genome(g.names, seqs)
 
+    def sketch_masked(self, asm, ctg_masks, new_w):                 # S:134-192: maskfasta + indexlr + read_minimizers
+        "(mx_info, lists) of assembly `asm` re-sketched with hard masks (a seam: list-level tests script this step)"
+        mg = self.masked_genome(asm, ctg_masks)
+        mins = O.minimize(mg, self.k, new_w, self.bf, self.threads)
+        return mx_tables_from_tokens(mx_records_from_arrays(mg.names, mins))
+
     def new_minimizers(self, blocks, new_w, prev_w):               # S:532-541
         masks = self.mask_intervals(blocks, prev_w)
         list_mxs, new_info = {}, {}
         # S:138 iterates the assemblies that appear in synteny_beds (block.assembly_blocks order)
         order = list(blocks[0].asm) if blocks else []
         for a in order:
-            mg = self.masked_genome(a, masks.get(a, {}))
-            mins = O.minimize(mg, self.k, new_w, self.bf, self.threads)
-            info, lists = mx_tables_from_tokens(mx_records_from_arrays(mg.names, mins))
-            new_info[a], list_mxs[a] = info, lists
+            new_info[a], list_mxs[a] = self.sketch_masked(a, masks.get(a, {}), new_w)
         terminal, internal, spans = set(), set(), defaultdict(dict)    # S:205-226
         for blk in blocks:
             for a, ab in blk.asm.items():

@@ -255,3 +255,62 @@ def test_path_scan_matches_numpy_statement():
             for a in range(G):
                 assert n_up[a, i] == int((np.diff(v_pos[a][q]) > 0).sum())
     assert over.any() and (start > off[:-1]).any()
+
+
+def test_unoriented_block_is_deleted_in_situ(tmp_path):
+    """The `all_oriented` == False branch (bin/ntsynt_synteny.py:84-86,96-104; synteny_block.py:48-70) inside a whole
+    run, engine against oracle.  List-adjacent minimizers are monotone in every assembly, so no sequence-level family
+    reaches it; it takes a refinement round that re-sights a block's terminal minimizer elsewhere in one assembly (a
+    second copy of the k-mer that only becomes a minimizer at the smaller w) and overwrites its position
+    (S:282-290).  Both sides are driven at list level: scripted minimizer lists instead of a re-sketch."""
+    k, w = 24, 1000
+    names = ["b.fa.k24.w1000.tsv", "a.fa.k24.w1000.tsv"]
+    rng = np.random.default_rng(3)
+    H = rng.integers(1 << 40, 1 << 62, size=40, dtype=np.uint64)
+    X = rng.integers(1 << 40, 1 << 62, size=8, dtype=np.uint64)
+    contigs = ["c1", "c2", "c3"]
+    # initial round: c1 carries a 4-minimizer block, c2 and c3 longer ones; same order and positions in both assemblies
+    layout = [(0, H[0:4]), (1, H[4:20]), (2, H[20:40])]
+
+    def initial():
+        h1 = np.concatenate([hs for _, hs in layout])
+        rec = np.concatenate([np.full(hs.size, r, np.uint32) for r, hs in layout])
+        pos = np.concatenate([(np.arange(hs.size, dtype=np.uint64) + 1) * 10000 for _, hs in layout])
+        return h1, rec, pos
+    # the scripted refinement list: new minimizers X0, X1 left of the c1 block, X2 right of it; in assembly b the
+    # block's last minimizer H3 (position 40000) turns up at 3000
+    script = {
+        "a": ([X[0], X[1], H[0], H[3], X[2]], [2000, 5000, 10000, 40000, 45000]),
+        "b": ([X[0], H[3], X[1], H[0], X[2]], [2000, 3000, 5000, 10000, 45000]),
+    }
+
+    def scripted(asm):
+        hs, ps = script["a" if asm.startswith("a.") else "b"]
+        return (np.array(hs, np.uint64), np.zeros(len(hs), np.uint32), np.array(ps, np.uint64))
+
+    cwd = os.getcwd()
+    try:
+        os.makedirs(tmp_path / "ora")
+        os.makedirs(tmp_path / "eng")
+        os.chdir(tmp_path / "ora")
+
+        class Scripted(SO.SyntenyOracle):
+            def sketch_masked(self, asm, ctg_masks, new_w):
+                h1, rec, pos = scripted(asm)
+                return SO.mx_tables_from_tokens([("c1", [(str(h), int(p)) for h, p in zip(h1.tolist(), pos.tolist())])])
+        ora = Scripted(names, {}, k, w, [100], 500, 3000, 500, "p")
+        h1, rec, pos = initial()
+        recs = [(contigs[r], [(str(h), int(p)) for h, p in zip(h1[rec == r].tolist(), pos[rec == r].tolist())]) for r in range(3)]
+        ora.load({n: SO.mx_tables_from_tokens(recs) for n in names})
+        exp = ora.main()
+        os.chdir(tmp_path / "eng")
+        eng = SyntenyEngine(names, [contigs, contigs], k, w, [100], 500, 3000, 500, "p", build_graph_numpy,
+                            lambda i, masks, new_w: scripted(names[i]), walk_paths, degree_fn=edge_degrees)
+        got = eng.run([initial(), initial()])
+    finally:
+        os.chdir(cwd)
+    assert eng.stats["unoriented"] == 1
+    for name in got:
+        assert got[name] == exp[name], name
+    final = got["p.synteny_blocks.tsv"]
+    assert "\tc1\t" not in final and "\tc2\t" in final and "\tc3\t" in final     # the c1 block is gone, the others stay
