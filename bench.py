@@ -1,29 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- minimizer-sketch throughput of the HIP hot path on MI355X.
+"""bench.py -- minimizer-sketch throughput of the HIP hot path on MI355X, on BASELINE.json's configurations.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the sketch (canonical ntHash + common-Bloom probe + window-of-w argmin,
-rows B1-B3) over the rank's batch of synthetic genomes, which are resident in HBM (together with
-the common Bloom filter) before the timed region starts -- as one resident genome whose records are
-those of genome 0, then 1, ... (nts_genome_concat), so that one sequence of launches sketches the batch
-(--no-batch: one sequence per genome); for N>1 the step ends with the all-gather
-of the minimizer lists (SURVEY.md 8(e) exchange 2).  Weak scaling: every rank holds its own
-`--genomes` genomes of one family of N*genomes genomes; the common Bloom filter is the AND over the
-whole family (exchange 1, timed separately and reported under "bloom").  The family's pairwise divergence
-is divergence/N, which keeps the share of k-mers the common filter accepts -- and with it the candidates
-and minimizers per base each GPU handles -- at its 1-GPU value (at a fixed 1 % the AND over 24 genomes
-would accept ~6 % of the k-mers and the per-GPU work would not be the 1-GPU work any more).
+A "step" is one pass of the sketch (canonical ntHash + common-Bloom probe + window-of-w argmin, rows B1-B3) over the
+rank's synthetic genomes, which are resident in HBM together with the common Bloom filter before the timed region
+starts (generated there: nts_genome_synth).  `value` = bases sketched by all ranks per second.
 
-N=1 workload = BASELINE.json configs[1]: 3 synthetic 100 Mbp genomes at 1 % divergence, k=24 w=1000.
-The timed steps use the library's default policy (exact pruning of Bloom probes, nts_pruned.inc); the
-same sketch with every k-mer probed ("dense", SURVEY.md 8(d)'s 65 B/base formulation) is run after the
-timed region and reported under roofline.unpruned.  Prints ONE JSON line (rank 0).
+Workloads (--workload; default c3 at N=1, c4 at N>1):
+  c3   BASELINE configs[2], the configuration the metric is quoted on: 3 synthetic 3 Gbp genomes (24 contigs) at 1 %
+       divergence, k=24 w=1000 fpr=0.025.  Fits one GPU (9 GB of bases + 2 x 14.8 GB of filters).
+  c4   BASELINE configs[3]: 8 synthetic 3 Gbp genomes at 10 % divergence, genome g on rank g mod N (one per GPU at
+       N=8), common filter = AND over all eight (exchange 1: nts_bf_allreduce_and over RCCL), every step ends with the
+       all-gather of the minimizer lists (exchange 2: nts_mx_allgather).  The family, the filter and therefore the work
+       per genome are the same at every N: strong scaling.  At N=1 all eight genomes live on one GPU.
+  c2   BASELINE configs[1]: 3 x 100 Mbp at 1 %, sketched as one batch genome (round 1's bench line).
+Extra legs at N=1 (rank 0), all inside the one JSON line: `cold` (first sketch of a fresh genome: 2-bit image, run
+table, first-k-mer tables included), `roofline.unpruned` (every k-mer probed), `c4_n1` (config 4's eight genomes on
+this one GPU: the N=1 point of the c4 curve), `e2e` (FASTA files on disk -> final synteny TSV through the product
+pipeline, per stage), `cpu_baseline` (the CPU oracle on the host cores, per stage, at the reference's default
+parallelism and on all cores).
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -32,7 +36,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-SECTOR = 64.0                                        # bytes moved per Bloom probe
+SECTOR = 64.0                                        # bytes per Bloom probe in SURVEY.md 8(d)'s accounting
+L2_LINE = 128.0                                      # what one missing probe moves if the L2 fetches whole lines
+ANCESTOR_SEED = 20240207
+WORKLOADS = {
+    # name: (genomes in the family, Mbp per genome, contigs, pairwise divergence, scaling)
+    "c3": (3, 3000.0, 24, 0.01, "strong"),
+    "c4": (8, 3000.0, 24, 0.10, "strong"),
+    "c2": (3, 100.0, 4, 0.01, "strong"),
+}
+SKETCH_KERNELS = ["hash_select", "cand_compact", "sparse_win", "gather_winners", "hash_probe", "window_min", "sort_minimizers",
+                  "merge_lists", "finalize"]
 
 
 def parse():
@@ -40,10 +54,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--genomes", type=int, default=3, help="genomes per GPU")
-    ap.add_argument("--mbp", type=float, default=100.0, help="Mbp per genome")
-    ap.add_argument("--contigs", type=int, default=4)
-    ap.add_argument("--divergence", type=float, default=0.01)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
+    ap.add_argument("--genomes", type=int, default=None, help="override: genomes in the family")
+    ap.add_argument("--mbp", type=float, default=None, help="override: Mbp per genome")
+    ap.add_argument("--contigs", type=int, default=None)
+    ap.add_argument("--divergence", type=float, default=None)
     ap.add_argument("-k", type=int, default=24)
     ap.add_argument("-w", type=int, default=1000)
     ap.add_argument("--fpr", type=float, default=0.025)
@@ -51,15 +66,12 @@ def parse():
     ap.add_argument("--prune-c", type=int, default=0, help="0 = adaptive (library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-leg", action="store_true")
-    ap.add_argument("--no-batch", action="store_true", help="one launch sequence per genome instead of one per step")
+    ap.add_argument("--no-cold-leg", action="store_true")
+    ap.add_argument("--no-c4-leg", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="c2: one launch sequence per genome instead of one per step")
+    ap.add_argument("--e2e-dir", default=None, help="where the e2e leg writes its FASTA files [a temp dir]")
     return ap.parse_args()
-
-
-def upload(ctx, contigs):
-    from ntsynt_amd.device import Genome
-    lens = np.array([c.size for c in contigs], dtype=np.uint64)
-    off = np.concatenate(([0], np.cumsum(lens[:-1]))).astype(np.uint64)
-    return Genome(ctx, [f"chr{i + 1}" for i in range(len(contigs))], np.concatenate(contigs), off, lens)
 
 
 def effective_cores():
@@ -86,9 +98,24 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(args, contigs, bf_np):
-    """The CPU oracle (a port of btllib's algorithm class: rolling ntHash, ring-buffer window
-    minimum, Bloom probe per k-mer) on the box's host cores, on a bounded sample of the workload."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(k, w, fpr, sample, bf_np, budget_s=24.0):
+    """The CPU oracle (a port of btllib's algorithm class: rolling ntHash, ring-buffer window minimum, byte-atomic Bloom
+    insert, one probe per k-mer) on this box's host cores, per stage: Bloom build and sketch, each at the
+    reference's default parallelism -- make_common_bf with 12 threads (bin/ntSynt:59), indexlr 5 threads x 2 genomes at
+    once (bin/ntsynt_run_pipeline.smk:79-80, bin/ntSynt:154) -- and on all cores the cgroup grants.  `sample` = the
+    first bases of genome 0 read back from HBM (uint8 ASCII); the filter is the real common filter (so the probes miss
+    the caches like they do in a full run); the Bloom build of the sample goes into a filter sized for the sample by the
+    reference's rule.  Bounded to ~budget_s seconds of CPU work."""
     from oracle import nts_oracle as O
     try:
         O.build(native=True)
@@ -96,41 +123,91 @@ def cpu_baseline(args, contigs, bf_np):
     except Exception:
         native = False
     cores = effective_cores()
-    # genome 0 cut into four records per thread (windows do not cross records, so this is the same
-    # algorithm on independent pieces); repeated until >= ~8 s of wall time have elapsed
-    whole = np.concatenate(contigs)
-    per = max(whole.size // (4 * cores), 4 * args.w)
-    seqs = [whole[i:i + per].tobytes() for i in range(0, whole.size - per + 1, per)]
-    g = O.Genome([f"s{i}" for i in range(len(seqs))], seqs)
-    O.minimize(g, args.k, args.w, bf_np, threads=cores, native=native)   # warm-up (page in, spawn threads)
-    done, t = 0, time.time()
-    while time.time() - t < 8.0:
-        O.minimize(g, args.k, args.w, bf_np, threads=cores, native=native)
-        done += g.total_bp
-    dt = time.time() - t
-    return {"value": round(done / dt / 1e9, 4), "unit": "Gbases/s", "cores": cores, "kind": "port",
-            "sample": f"genome 0 ({g.total_bp / 1e6:.0f} Mbp) as {len(seqs)} records over {cores} OpenMP threads "
-                      f"(the cgroup CPU quota of the box; {os.cpu_count()} logical CPUs visible), "
-                      f"sketch with the same common Bloom filter, {done // g.total_bp} passes in {dt:.1f} s"}
+
+    def as_records(n_threads):
+        per = max(sample.size // (4 * n_threads), 4 * w)
+        seqs = [sample[i:i + per].tobytes() for i in range(0, sample.size - per + 1, per)]
+        return O.Genome([f"s{i}" for i in range(len(seqs))], seqs)
+
+    def rate(fn, g, slot_s):
+        fn()                                                         # warm-up: page in, spawn threads
+        done, t = 0, time.time()
+        while True:
+            fn()
+            done += g.total_bp
+            if time.time() - t >= slot_s:
+                break
+        return done / (time.time() - t) / 1e9
+
+    stages = {}
+    slot = budget_s / 8.0
+    build_bytes = O.bf_ctor_bytes(O.bf_approx_bytes(sample.size, fpr))
+    for label, n_thr in (("reference_default", None), ("all_cores", cores)):
+        thr_bf = min(12, cores) if n_thr is None else n_thr
+        thr_sk = min(10, cores) if n_thr is None else n_thr
+        g_bf, g_sk = as_records(thr_bf), as_records(thr_sk)
+        stages[label] = {
+            "bf_build_Gbases_s": round(rate(lambda: O.bf_build(g_bf, k, build_bytes, None, thr_bf, native), g_bf, slot), 4),
+            "bf_build_threads": thr_bf,
+            "sketch_Gbases_s": round(rate(lambda: O.minimize(g_sk, k, w, bf_np, threads=thr_sk, native=native), g_sk, slot), 4),
+            "sketch_threads": thr_sk,
+        }
+    return {"value": stages["all_cores"]["sketch_Gbases_s"], "unit": "Gbases/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "logical_cpus_visible": os.cpu_count(), "stages": stages,
+            "sample": f"first {sample.size / 1e6:.0f} Mbp of genome 0 read back from HBM, cut into 4 records per thread "
+                      f"(windows do not cross records), sketched against the real {bf_np.size / 1e9:.1f} GB common filter; "
+                      f"Bloom build of the same sample into a filter sized for it ({build_bytes / 1e6:.0f} MB); "
+                      f"~{budget_s:.0f} s of CPU work in all; "
+                      f"`value` = sketch on all {cores} cores the cgroup grants"}
 
 
-def pmc_traffic(args, pruned_run):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command).  FETCH_SIZE is
-    corrected by +1/2 of the sequence stream where the kernel reads it with wide loads (the guide's gfx950 factor)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    default = (args.mbp, args.genomes, args.divergence, args.k, args.w, args.fpr, args.no_batch) == (100.0, 3, 0.01, 24, 1000, 0.025, False)
-    if not (default and os.path.exists(path)):
-        return None
-    k = json.load(open(path))["kernels"].get("k_hash_select" if pruned_run else "k_hash<0>")
-    if not k:
-        return None
-    raw = (k["fetch_MB_per_launch_max"] + k["write_MB_per_launch_max"]) * 1024 * 1024
-    # the dense kernel streams the bases with 16-byte loads (FETCH_SIZE counts half of such a stream on gfx950); the
-    # pruned kernel reads the 2-bit image with dword loads, to which that correction does not apply
-    corr = 0.0 if pruned_run else 0.5 * args.mbp * 1e6 * args.genomes
-    return {"bytes_per_launch": int(raw + corr), "raw_fetch_plus_write_bytes": int(raw),
-            "source": "profiles/r01_pmc_traffic.json"}
+def write_fasta_from_device(g, path, chunk=1 << 28):
+    "resident genome -> single-line FASTA file (inputs of the e2e leg; not timed)"
+    with open(path, "wb") as fh:
+        for r, name in enumerate(g.names):
+            fh.write(b">" + name.encode() + b"\n")
+            off, ln = int(g.rec_off[r]), int(g.rec_len[r])
+            for s in range(0, ln, chunk):
+                fh.write(g.download(off + s, min(chunk, ln - s)).tobytes())
+            fh.write(b"\n")
+
+
+def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir):
+    """FASTA files on disk -> {prefix}.synteny_blocks.tsv through ntsynt_amd.pipeline.run with ntSynt's defaults for the
+    divergence (the second half of BASELINE's metric).  The files are written from genomes generated in HBM first (same
+    family as the sketch legs; not timed)."""
+    from ntsynt_amd import cli, pipeline
+    from ntsynt_amd.device import Context, Genome
+    divergence_pct = max(div * 100, 0.01)
+    t = time.time()
+    paths = []
+    ctx = Context(device)
+    for j in range(n_fam):
+        g = Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + j, div / 2.0)
+        p = os.path.join(workdir, f"syn{j}.fa")
+        write_fasta_from_device(g, p)
+        g.free()
+        paths.append(p)
+    ctx.close()
+    t_write = time.time() - t
+    parser = cli.build_parser()
+    a = parser.parse_args(paths + ["-d", f"{divergence_pct:g}", "-p", "e2e", "-k", str(args.k), "-w", str(args.w), "--fpr", str(args.fpr)])
+    cli.resolve(parser, a)
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        t = time.time()
+        eng = pipeline.run(paths, k=a.k, w=a.w, fpr=a.fpr, prefix=a.prefix, w_rounds=a.w_rounds, indel=a.indel, merge=a.merge,
+                           block_size=a.block_size, device=device, log=lambda *x: None)
+        wall = time.time() - t
+    finally:
+        os.chdir(cwd)
+    tsv = eng.outputs["e2e.synteny_blocks.tsv"]
+    return {"what": f"{len(paths)} FASTA files on disk -> final synteny TSV (ntSynt -d {divergence_pct:g}: w_rounds {a.w_rounds}, "
+                    f"indel {a.indel}, merge {a.merge}, block {a.block_size}), one GPU, files in the page cache",
+            "seconds": round(wall, 3), "stages_s": {n: round(s, 3) for n, s in eng.stage_times},
+            "blocks": len(tsv.splitlines()) // len(paths), "tsv_md5": hashlib.md5(tsv.encode()).hexdigest(),
+            "write_inputs_s": round(t_write, 1)}
 
 
 def main():
@@ -138,19 +215,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    name = args.workload or ("c3" if world == 1 else "c4")
+    n_fam, mbp, contigs, div, scaling = WORKLOADS[name]
+    n_fam = args.genomes or n_fam
+    mbp = args.mbp or mbp
+    contigs = args.contigs or contigs
+    div = args.divergence if args.divergence is not None else div
+    if n_fam < world:
+        raise SystemExit(f"workload {name}: {n_fam} genomes cannot occupy {world} GPUs")
     import torch
     import torch.distributed as dist
-    from ntsynt_amd import dist as ndist
-    from ntsynt_amd import synth
-    from ntsynt_amd.device import (BloomFilter, Context, and_raw, bf_size_bytes, export_minimizers, sketch,
-                                   wrap_bloom)
+    from ntsynt_amd.device import BloomFilter, Comm, Context, Genome, allgather_minimizers, bf_size_bytes, sketch
     # NTS_BENCH_BACKEND=gloo is a verification mode for boxes with fewer GPUs than ranks (tests/test_gpu_multirank.py):
-    # ranks share the visible GPUs and the collectives run on host copies; the measured configuration is nccl (= RCCL).
+    # ranks share the visible GPUs and the two exchanges run on host copies; the measured configuration is RCCL.
     backend = os.environ.get("NTS_BENCH_BACKEND", "nccl")
     host_comm = backend != "nccl"
     if host_comm and torch.cuda.is_available():
         local_rank = local_rank % torch.cuda.device_count()
-    comm_dev = "cpu" if host_comm else f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -160,96 +241,92 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = Context(local_rank)
     ctx.sketch_mode(args.mode, args.prune_c)
+    comm = Comm.from_torch(ctx) if (world > 1 and not host_comm) else None
     k, w = args.k, args.w
-    total_bp = int(args.mbp * 1e6)
+    total_bp = int(mbp * 1e6)
 
-    # ---- synthetic family: rank r owns genomes r*G .. r*G+G-1 ------------------------------------
-    anc = synth.make_ancestor(total_bp, args.contigs)
-    mine = list(range(rank * args.genomes, (rank + 1) * args.genomes))
-    # Weak scaling keeps the work per GPU fixed: the family grows to world x G genomes, all reduced into one common
-    # filter, so the pairwise divergence is divided by `world` -- the share of k-mers the common filter accepts
-    # ((1 - d/2)^(k x genomes)), hence candidates and minimizers per base, stays what it is on one GPU.
-    div = args.divergence / world
-    host = [synth.derive_genome(anc, div, j) for j in mine]
-    genomes = [upload(ctx, g) for g in host]
+    # ---- the family: genome g lives on rank g mod world ------------------------------------------------------
+    mine = [g for g in range(n_fam) if g % world == rank]
+    t0 = time.time()
+    genomes = [Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + g, div / 2.0) for g in mine]
+    t_synth = time.time() - t0
     bases = sum(g.total_bp for g in genomes)
-    # the rank's batch as one resident genome (records of genome 0, then 1, ...): one sequence of launches sketches all
-    # of it, as ntsynt_amd/pipeline.py does for assemblies of this size (GpuBackend.sketch_batch)
-    from ntsynt_amd.device import Genome
-    units = [Genome.concat(ctx, genomes)] if (not args.no_batch and len(genomes) > 1) else genomes
+    batch = name == "c2" and not args.no_batch and len(genomes) > 1 and world == 1
+    units = [Genome.concat(ctx, genomes)] if batch else genomes
 
-    # ---- common Bloom filter: per-genome filters, local AND, AND-all-reduce over ranks --------------
-    # sized from genome 0 of the family (the lexicographically first file, cpp:105-118): same on all ranks
-    _, nbytes = bf_size_bytes(total_bp // args.contigs * args.contigs, args.fpr)
+    # ---- common Bloom filter: per-genome filters, local AND, AND-all-reduce over the ranks (exchange 1) --------------
+    _, nbytes = bf_size_bytes(genomes[0].total_bp, args.fpr)        # every genome of the family has this size
     ctx.profile(True)
     t0 = time.time()
-    if world > 1:
-        buf = torch.zeros(ndist.padded_len(nbytes, world), dtype=torch.uint8, device=f"cuda:{local_rank}")
-        torch.cuda.synchronize()
-        common = wrap_bloom(ctx, buf, nbytes, k)
-    else:
-        common = BloomFilter(ctx, nbytes, k)
+    common = BloomFilter(ctx, nbytes, k, world=world if comm is not None else 1)
     common.insert(genomes[0])
-    tmp = BloomFilter(ctx, nbytes, k)
-    for g in genomes[1:]:
-        tmp.clear()
-        tmp.insert(g)
-        common.and_(tmp)
+    occ_single = common.get_fpr()
+    if len(genomes) > 1:
+        tmp = BloomFilter(ctx, nbytes, k)
+        for g in genomes[1:]:
+            tmp.clear()
+            tmp.insert(g)
+            common.and_(tmp)
+        tmp.free()
     ctx.sync()
     t_build = time.time() - t0
     t_allreduce = 0.0
     if world > 1:
         t1 = time.time()
-
-        def and_into(a, b):
-            and_raw(ctx, a.data_ptr(), b.data_ptr(), a.numel())
-            ctx.sync()
-        if host_comm:
-            staged = buf.cpu()
-            ndist.allreduce_and(staged, lambda a, b: a.bitwise_and_(b))
-            buf.copy_(staged)
-        else:
-            ndist.allreduce_and(buf, and_into)
-        torch.cuda.synchronize()
+        if comm is not None:
+            comm.allreduce_and(common)
+        else:                                               # verification mode: the same reduction on host copies
+            bits = torch.from_numpy(common.to_numpy())
+            gathered = [torch.empty_like(bits) for _ in range(world)]
+            dist.all_gather(gathered, bits)
+            for other in gathered:
+                bits &= other
+            common.from_numpy(bits.numpy())
+        ctx.sync()
         t_allreduce = time.time() - t1
-    tmp.free()
     ins_ms, ins_n = ctx.timing("bf_insert")
-    fpr_final = common.get_fpr()
+    occ_common = common.get_fpr()
 
-    # exchange 2: the rank's lists of a step go out in one all-gather, which runs behind the next
-    # step's kernels (ntsynt_amd/dist.py PackedListGather); slots sized from the minimizer density 2/(w+1)
-    gatherer = None
-    if world > 1:
-        # density 2/(w+1) of the nominal genome size + 25 %: identical on every rank, and little padding to ship
-        cap = int(2.5 * total_bp * 1.05 / (w + 1)) + 4096
-        gatherer = ndist.PackedListGather(len(units), cap * (len(genomes) // len(units)), f"cuda:{local_rank}", comm_dev)
+    # ---- cold leg: the first sketch of a genome nothing has been derived from yet ---------------------------------
+    cold = None
+    if world == 1 and not args.no_cold_leg:
+        fresh = Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + mine[0], div / 2.0)
+        ctx.sync()
+        t1 = time.time()
+        mx = sketch(ctx, fresh, k, w, common)
+        n_cold = len(mx)
+        t_fresh = time.time() - t1
+        mx.free()
+        fresh.free()
+        t1 = time.time()
+        sketch(ctx, genomes[-1], k, w, common).free()               # after its Bloom insert (2-bit image exists): the
+        t_first = time.time() - t1                                  # pipeline's situation
+        cold = {"first_sketch_of_a_fresh_genome_ms": round(t_fresh * 1e3, 2),
+                "Gbases_s": round(genomes[0].total_bp / t_fresh / 1e9, 2),
+                "first_sketch_after_its_bloom_insert_ms": round(t_first * 1e3, 2), "minimizers": n_cold,
+                "includes": "2-bit image, run table of valid k-mers, first-k-mer tables, workspace allocation"}
 
     def step():
-        if gatherer is not None:
-            gatherer.begin()
-        n = 0
-        held = []
-        for i, g in enumerate(units):
+        held, n = [], 0
+        for g in units:
             mx = sketch(ctx, g, k, w, common)
             n += len(mx)
-            if gatherer is not None:
-                h1p, recp, posp = gatherer.slot_ptrs(i)
-                export_minimizers(ctx, mx, h1p, recp, posp, wait=False)
-                gatherer.set_count(i, len(mx), mine[i])
-                held.append(mx)
+            held.append(mx)
+        if world > 1:                                               # exchange 2: every rank receives every list
+            if comm is not None:
+                everything = comm.allgather_minimizers(held, mine, n_fam)
+                for mx in everything:
+                    mx.free()
             else:
-                mx.free()
-        if gatherer is not None:
-            ctx.sync()                  # the three queued copies: one wait
-            for mx in held:
-                mx.free()
-            gatherer.post()
+                local = [mx.to_numpy() for mx in held]
+                box = [None] * world
+                dist.all_gather_object(box, local)
+        for mx in held:
+            mx.free()
         return n
 
     def fence():
         ctx.sync()
-        if gatherer is not None:
-            gatherer.drain()
         if world > 1:
             dist.barrier()
         if torch.cuda.is_available():
@@ -267,25 +344,23 @@ def main():
         fence()
         el = time.time() - t_start
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=comm_dev)
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if host_comm else f"cuda:{local_rank}")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, n_mx
 
     dt, n_mx = timed(args.warmup, args.steps)
-    names = ["hash_select", "cand_compact", "sparse_win", "gather_winners", "hash_probe", "window_min", "sort_minimizers", "merge_lists",
-             "finalize"]
-    tm = {n: ctx.timing(n) for n in names}
+    tm = {n: ctx.timing(n) for n in SKETCH_KERNELS}
     # the other kernels of the call: one more pass, untimed, with every kernel group bracketed by events
     ctx.profile(1)
     step()
     fence()
-    detail = {n: ctx.timing(n) for n in names}
+    detail = {n: ctx.timing(n) for n in SKETCH_KERNELS}
     ctx.profile(2)
     cand, gaps, gap_kmers = ctx.sketch_stats()
     c_used = getattr(ctx, "last_prune_c", 0)
     per_launch_bases = bases / len(units)
-    per_genome_bases = bases / len(genomes)
+    dense_bpb = 1.0 + SECTOR + 32.0 / (w + 1)
 
     def avg(n):
         return tm[n][0] / max(tm[n][1], 1)
@@ -293,20 +368,68 @@ def main():
     dense = None
     if args.mode != "dense" and not args.no_dense_leg and world == 1:
         ctx.sketch_mode("dense")
-        d_dt, _ = timed(1, max(2, args.steps // 2), level=1)
+        n_d = max(2, args.steps // 2)
+        d_dt, _ = timed(1, n_d, level=1)
         hp_ms, hp_n = ctx.timing("hash_probe")
         wm_ms, wm_n = ctx.timing("window_min")
         a_ms = hp_ms / max(hp_n, 1)
-        bpb = 1.0 + SECTOR + 32.0 / (w + 1)
-        ach = bpb * per_launch_bases / (a_ms * 1e-3) / 1e9
-        dense = {"kernel": "k_hash<MODE_KEYS> (every k-mer probed)", "algorithmic_bytes_per_base": round(bpb, 3),
+        ach = dense_bpb * per_launch_bases / (a_ms * 1e-3) / 1e9
+        line = (1.0 + L2_LINE + 32.0 / (w + 1)) * per_launch_bases / (a_ms * 1e-3) / 1e9
+        dense = {"kernel": "k_hash<MODE_KEYS> (every k-mer probed)", "algorithmic_bytes_per_base": round(dense_bpb, 3),
                  "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(a_ms, 4),
+                 "G_probes_s": round(per_launch_bases / (a_ms * 1e-3) / 1e9, 2),
+                 # the L2 fetches 128-byte lines: what a missing 4-byte probe really moves (profiles/r02_probe_granularity.md)
+                 "at_128B_line_granularity": {"GBs": round(line, 1), "frac": round(line / HBM_PEAK_GBS, 4)},
                  "window_min_avg_ms": round(wm_ms / max(wm_n, 1), 4),
-                 "value_Gbases_s": round(bases * max(2, args.steps // 2) / d_dt / 1e9, 3)}
+                 "value_Gbases_s": round(bases * n_d / d_dt / 1e9, 3)}
         ctx.sketch_mode(args.mode, args.prune_c)
 
+    valu = None
+    if world == 1:
+        # VALU roof of the issue-bound kernel: measured issue rate of its instruction mix's slowest member (nts_bench_valu)
+        rows = {kind: ctx.bench_valu(kind, 4, 20000) for kind in ("v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64")}
+        valu = {"cycles_per_wave_instr_per_simd": {n: r["cycles_per_wave_instr_per_simd"] for n, r in rows.items()},
+                "wave_instr_per_s_per_cu": {n: round(r["wave_instr_per_s_per_cu"] / 1e9, 3) for n, r in rows.items()},
+                "unit": "G wave-instructions/s/CU"}
+
+    c4_n1 = None
+    if world == 1 and name == "c3" and not args.no_c4_leg:
+        # config 4's family on this one GPU: the N=1 point of the strong-scaling curve `--gpus N` measures
+        for g in units:
+            g.free()
+        fam = [Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + g, 0.10 / 2.0) for g in range(8)]
+        c4 = BloomFilter(ctx, nbytes, k)
+        c4.insert(fam[0])
+        tmp = BloomFilter(ctx, nbytes, k)
+        for g in fam[1:]:
+            tmp.clear()
+            tmp.insert(g)
+            c4.and_(tmp)
+        tmp.free()
+        for g in fam:
+            sketch(ctx, g, k, w, c4).free()
+        ctx.sync()
+        t1 = time.time()
+        n4 = 0
+        for _ in range(2):
+            n4 = 0
+            for g in fam:
+                mx = sketch(ctx, g, k, w, c4)
+                n4 += len(mx)
+                mx.free()
+        ctx.sync()
+        d4 = time.time() - t1
+        c4_n1 = {"workload": "8 synthetic 3000 Mbp genomes at 10% divergence on one GPU (bench.py --workload c4 --gpus 1)",
+                 "value_Gbases_s": round(8 * total_bp * 2 / d4 / 1e9, 3), "ms_per_step": round(d4 / 2 * 1e3, 2),
+                 "common_filter_occupancy": c4.get_fpr(), "minimizers_per_step": n4}
+        c4.free()
+        for g in fam:
+            g.free()
+        genomes = [Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + g, div / 2.0) for g in mine]
+
+    out = None
     if rank == 0:
-        value = bases * world * args.steps / dt / 1e9
+        value = bases_total(n_fam, genomes) * args.steps / dt / 1e9
         pruned_run = tm["hash_select"][1] > 0
         if pruned_run:
             kern, a_ms = "k_hash_select (hash every k-mer, probe candidates only)", avg("hash_select")
@@ -316,50 +439,101 @@ def main():
             bpb = 0.25 + SECTOR * probe_frac + 16.0 * cand / per_launch_bases
         else:
             kern, a_ms = "k_hash<MODE_KEYS> (every k-mer probed)", avg("hash_probe")
-            bpb = 1.0 + SECTOR + 32.0 / (w + 1)
+            bpb = dense_bpb
         achieved = bpb * per_launch_bases / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
+        if valu is not None and pruned_run and a_ms > 0:
+            # 29.7 VALU wave-instructions per 64 k-mers (PMC, profiles/r01_sq_counters.json); the roof: 4 SIMDs per CU each
+            # issuing one wave-instruction every `cycles` shader cycles, as the microbenchmark measures them
+            per_64 = 29.7
+            n_cu = 256
+            ach_v = per_64 * per_launch_bases / 64.0 / (a_ms * 1e-3) / n_cu / 1e9
+            peak_v = min(valu["wave_instr_per_s_per_cu"].values())
+            valu.update({"kernel": "k_hash_select", "valu_wave_instr_per_64_kmers": per_64, "achieved": round(ach_v, 3),
+                         "peak": peak_v, "frac": round(ach_v / peak_v, 3)})
         out = {
             "metric": "minimizer-sketch Gbases/s (sketch with common Bloom filter, inputs resident in HBM)",
             "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.genomes} synthetic {args.mbp:g} Mbp genomes per GPU at "
-                                   f"{args.divergence * 100:g}% divergence, k={k} w={w} fpr={args.fpr}"
-                                   + (f" (one family of {world * args.genomes} genomes, pairwise divergence {div * 100:g}%: "
-                                      f"common-filter acceptance held at the 1-GPU value)" if world > 1 else ""),
-                       "sketch_mode": args.mode, "prune_c": c_used,
-                       "genomes_per_gpu": args.genomes, "sketch_launch_sequences_per_step": len(units),
-                       "bases_per_step_per_gpu": bases,
-                       "minimizers_per_step_per_gpu": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)"},
+            "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{name}: {n_fam} synthetic {mbp:g} Mbp genomes ({contigs} contigs) at {div * 100:g}% divergence, "
+                                   f"k={k} w={w} fpr={args.fpr}, genome g on GPU g mod {world}",
+                       "sketch_mode": args.mode, "prune_c": c_used, "genomes_on_rank0": len(genomes),
+                       "sketch_launch_sequences_per_step_rank0": len(units), "bases_per_step": bases_total(n_fam, genomes),
+                       "minimizers_per_step_rank0": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)",
+                       "synth_s": round(t_synth, 3)},
             "roofline": {"bound": "hbm", "kernel": kern,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, pruned_run),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_base": round(bpb, 3),
                          "avg_launch_ms": round(a_ms, 4), "launches": tm["hash_select" if pruned_run else "hash_probe"][1],
-                         "other_kernels_avg_ms": {n: round(detail[n][0] / detail[n][1], 4) for n in names if detail[n][1]},
+                         "other_kernels_avg_ms": {n: round(detail[n][0] / detail[n][1], 4) for n in SKETCH_KERNELS if detail[n][1]},
                          "candidates_per_launch": cand, "uncovered_ranges": gaps, "uncovered_kmers": gap_kmers,
                          # the formulation with one sector read per k-mer moves 65.03 B/base, i.e. at
                          # most 8 TB/s / 65.03 B = 123 Gbases/s; the timed path, expressed in those bytes:
                          "one_probe_per_kmer_equivalent": {
-                             "bytes_per_base": round(1.0 + SECTOR + 32.0 / (w + 1), 3),
-                             "GBs": round(value * (1.0 + SECTOR + 32.0 / (w + 1)) / world, 1),
-                             "frac_of_peak": round(value * (1.0 + SECTOR + 32.0 / (w + 1)) / world / HBM_PEAK_GBS, 3)},
-                         "unpruned": dense},
+                             "bytes_per_base": round(dense_bpb, 3),
+                             "GBs": round(value * dense_bpb / world, 1),
+                             "frac_of_peak": round(value * dense_bpb / world / HBM_PEAK_GBS, 3)},
+                         "valu": valu, "unpruned": dense},
             "bloom": {"bytes": nbytes, "build_s": round(t_build, 4), "allreduce_and_s": round(t_allreduce, 4),
                       "bf_insert_avg_ms": round(ins_ms / max(ins_n, 1), 4),
-                      "bf_insert_Gbases_s": round(per_genome_bases / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 3)
-                      if ins_ms > 0 else None,
+                      "bf_insert_Gbases_s": round(total_bp / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 3) if ins_ms > 0 else None,
                       # SURVEY.md 8(d) prices the build at 129 B/base (sector read + write-back per k-mer)
-                      "bf_insert_GBs_at_129B_per_base": round(129.0 * per_genome_bases / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 1)
+                      "bf_insert_GBs_at_129B_per_base": round(129.0 * total_bp / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 1)
                       if ins_ms > 0 else None,
-                      "occupancy": round(fpr_final, 6)},
+                      "occupancy_one_genome": round(occ_single, 6), "occupancy_common": occ_common},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, host[0], common.to_numpy())
+        pm = pmc_traffic(name, pruned_run)
+        if pm:
+            out["roofline"]["traffic"] = pm
+        if cold:
+            out["cold"] = cold
+        if c4_n1:
+            out["c4_n1"] = c4_n1
+    if world == 1:
+        sample = bf_np = None
+        if not args.no_cpu_baseline:
+            sample = genomes[0].download(0, min(genomes[0].total_bp, 100_000_000))
+            bf_np = common.to_numpy()
+        if not args.no_e2e:
+            for g in genomes:                                        # everything of the sketch legs goes, the pipeline
+                g.free()                                             # starts from files like a user's run
+            common.free()
+            ctx.close()
+            workdir = args.e2e_dir or tempfile.mkdtemp(prefix="nts_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+            os.makedirs(workdir, exist_ok=True)
+            try:
+                out["e2e"] = e2e_leg(args, local_rank, n_fam, total_bp, contigs, div, workdir)
+            finally:
+                if not args.e2e_dir:
+                    shutil.rmtree(workdir, ignore_errors=True)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(k, w, args.fpr, sample, bf_np)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
+
+
+def bases_total(n_fam, rank0_genomes):
+    "bases sketched per step by all ranks: every genome of the family has the size of rank 0's"
+    return n_fam * rank0_genomes[0].total_bp
+
+
+def pmc_traffic(name, pruned_run):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if name != "c3" or not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"].get("k_hash_select" if pruned_run else "k_hash<0>")
+    if not k:
+        return None
+    raw = (k["fetch_MB_per_launch_max"] + k["write_MB_per_launch_max"]) * 1024 * 1024
+    return {"bytes_per_launch": int(raw), "raw_fetch_plus_write_bytes": int(raw), "source": "profiles/r02_pmc_traffic.json"}
 
 
 if __name__ == "__main__":

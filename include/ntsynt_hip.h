@@ -29,11 +29,13 @@ extern "C" {
 #define NTS_EHIP (-5)
 #define NTS_ERANGE (-34)
 #define NTS_EFORMAT (-74) /* input file is not FASTA (e.g. FASTQ) */
+#define NTS_ECOMM (-70)   /* RCCL unavailable or a collective failed */
 
 typedef struct nts_ctx nts_ctx;
 typedef struct nts_genome nts_genome; /* one FASTA resident in HBM */
 typedef struct nts_bf nts_bf;         /* Bloom bit array resident in HBM */
 typedef struct nts_mx nts_mx;         /* minimizer list resident in HBM */
+typedef struct nts_comm nts_comm;     /* RCCL communicator of the multi-GPU path (one rank per GPU) */
 
 /* hard-mask interval [start, end) in record coordinates (bedtools maskfasta semantics) */
 typedef struct
@@ -133,6 +135,14 @@ int nts_bf_upload(nts_ctx* ctx, nts_bf* bf, const uint8_t* host, uint64_t bytes)
 /* Microbenchmark: n_probes pseudo-random single-bit reads of the filter with the access shape of the sketch's
  * probe batches and no hashing -- the empirical ceiling for sector-granular random reads on this GPU. */
 int nts_bench_random_probe(nts_ctx* ctx, const nts_bf* bf, uint64_t n_probes, uint32_t repeats, double* avg_ms, uint64_t* hits);
+/* Microbenchmark: issue rate of the integer VALU instructions ntHash is made of (the roof of the VALU-bound kernels
+ * k_hash_select and k_bin1).  kind: 0 v_xor_b32, 1 v_alignbit_b32, 2 v_lshl_add_u64, 3 v_lshlrev_b64, 4 v_mul_lo_u32,
+ * 5 v_mad_u64_u32, 6 v_add_co_u32 + v_addc_co_u32 (a 64-bit add as two instructions), 7 a dependent chain of v_xor_b32
+ * (latency).  Every CU runs `waves_per_simd` (1..8) waves per SIMD, each wave `instr_per_wave` instructions in eight
+ * independent chains; cycles_per_instr = shader cycles (s_memtime) a SIMD needs per wave-instruction; wall_ms = the
+ * launch, from which wave-instructions per second per CU = 4 * waves_per_simd * instr_per_wave / wall follow. */
+int nts_bench_valu(nts_ctx* ctx, int kind, uint32_t waves_per_simd, uint32_t iters, double* wall_ms, double* cycles_per_instr,
+                   double* instr_per_wave);
 /* Non-owning filter over caller-provided HBM (e.g. the buffer a collective runs on): `device_ptr` must be
  * 16-byte aligned and hold `bytes` rounded up to a multiple of 16, the tail zeroed.  nts_bf_free() on a
  * wrapped filter releases only the handle. */
@@ -141,6 +151,38 @@ int nts_bf_wrap(nts_ctx* ctx, void* device_ptr, uint64_t bytes, nts_bf** out);
  * bitwise-AND all-reduce of per-genome filters across GPUs (SURVEY.md 8(e) exchange 1; RCCL has no
  * bitwise reduction). */
 int nts_and_raw(nts_ctx* ctx, void* acc_dev, const void* other_dev, uint64_t bytes);
+
+/* ---- multi-GPU exchange steps: one process per GPU, genomes partitioned over the ranks -------------
+ * The reference has no counterpart (it is a single-node Snakemake workflow); these calls are what a sharded
+ * make_common_bf (src/ntsynt_make_common_bf.cpp:134-160) and the hand-over of the per-genome indexlr outputs to
+ * ntsynt_run.py (bin/ntsynt_run_pipeline.smk:87-103) become across GPUs.
+ *
+ * nts_comm_unique_id : 128 opaque bytes (ncclGetUniqueId) made on one rank and handed to all by the launcher
+ *                      (torch.distributed store, MPI, a file)
+ * nts_comm_init      : ncclCommInitRank on the context's GPU
+ * nts_comm_wrap      : adopt an existing ncclComm_t (not destroyed by nts_comm_destroy)
+ * nts_bf_create_sharded : a filter whose allocation is `world` chunks of a multiple of 16 bytes -- the layout the
+ *                      all-reduce exchanges; otherwise identical to nts_bf_create
+ * nts_bf_fill_ones   : identity of AND, for a rank that owns no genome
+ * nts_bf_allreduce_and : exchange 1 -- in place, every rank ends with the bitwise AND of all ranks' filters (= the
+ *                      cascade's result).  RCCL has no bitwise reduction: direct reduce-scatter with
+ *                      ncclSend/ncclRecv over all xGMI links at once through a (world-1) x 256 MiB scratch, a local AND
+ *                      kernel, ncclAllGather in place.  comm == NULL or world 1: no-op.
+ * nts_mx_allgather   : exchange 2 -- the ranks' minimizer lists (n_local handles, genome numbers in local_ids; a rank
+ *                      holds at most ceil(n_total / world)) gathered on every rank: out[g] = list of genome g,
+ *                      resident in HBM, g in [0, n_total); released with nts_mx_free.  Two collectives per call. */
+int nts_comm_unique_id(uint8_t* id128);
+int nts_comm_init(nts_ctx* ctx, const uint8_t* id128, int world, int rank, nts_comm** out);
+int nts_comm_wrap(nts_ctx* ctx, void* rccl_comm, nts_comm** out);
+void nts_comm_destroy(nts_comm* comm);
+int nts_comm_world(const nts_comm* comm);
+int nts_comm_rank(const nts_comm* comm);
+void* nts_comm_handle(const nts_comm* comm);
+int nts_bf_create_sharded(nts_ctx* ctx, uint64_t bytes, int world, nts_bf** out);
+int nts_bf_fill_ones(nts_ctx* ctx, nts_bf* bf);
+int nts_bf_allreduce_and(nts_ctx* ctx, nts_bf* bf, nts_comm* comm);
+int nts_mx_allgather(nts_ctx* ctx, nts_comm* comm, uint32_t n_local, const nts_mx* const* local, const uint32_t* local_ids,
+                     uint32_t n_total, nts_mx** out);
 
 /* ---- B1-B3, B5: minimizer sketch -----------------------------------------------------------------
  * replaces `indexlr -k K -w W --long --pos -s common.bf genome.fa` (smk:81-85) and the re-sketch of

@@ -67,8 +67,21 @@ SYMBOLS = [
     ("nts_bf_download", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
     ("nts_bf_upload", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
     ("nts_bench_random_probe", ctypes.c_int, [c_vp, c_vp, u64, u32, ctypes.POINTER(ctypes.c_double), c_u64p]),
+    ("nts_bench_valu", ctypes.c_int, [c_vp, ctypes.c_int, u32, u32, ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     ("nts_bf_wrap", ctypes.c_int, [c_vp, c_vp, u64, ctypes.POINTER(c_vp)]),
     ("nts_and_raw", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
+    ("nts_comm_unique_id", ctypes.c_int, [c_vp]),
+    ("nts_comm_init", ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    ("nts_comm_wrap", ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    ("nts_comm_destroy", None, [c_vp]),
+    ("nts_comm_world", ctypes.c_int, [c_vp]),
+    ("nts_comm_rank", ctypes.c_int, [c_vp]),
+    ("nts_comm_handle", c_vp, [c_vp]),
+    ("nts_bf_create_sharded", ctypes.c_int, [c_vp, u64, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    ("nts_bf_fill_ones", ctypes.c_int, [c_vp, c_vp]),
+    ("nts_bf_allreduce_and", ctypes.c_int, [c_vp, c_vp, c_vp]),
+    ("nts_mx_allgather", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_vp), c_u32p, u32, ctypes.POINTER(c_vp)]),
     ("nts_mx_export", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("nts_mx_export_async", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("nts_sketch", ctypes.c_int, [c_vp, c_vp, u32, u32, c_vp, ctypes.POINTER(Interval), u64,

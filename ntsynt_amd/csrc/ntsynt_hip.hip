@@ -106,6 +106,7 @@ struct nts_genome
 struct nts_bf
 {
   uint64_t bytes = 0;
+  uint64_t alloc_bytes = 0; // bytes behind d_words (>= bytes rounded up to 16; nts_bf_create_sharded: world x chunk)
   uint32_t* d_words = nullptr;
   bool owned = true;
   mutable int64_t popcnt = -1; // cached number of set bits, -1 = unknown (any write invalidates it)
@@ -1216,6 +1217,7 @@ int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const Genom
 
 #include "nts_pruned.inc"
 #include "nts_bloom_bin.inc"
+#include "nts_microbench.inc"
 
 } // namespace
 
@@ -1577,13 +1579,12 @@ int nts_genome_valid_kmers(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64
 }
 
 // ---- Bloom filter ------------------------------------------------------------------------------------
-int nts_bf_create(nts_ctx* ctx, uint64_t bytes, nts_bf** out)
+static int bf_create_alloc(nts_ctx* ctx, uint64_t bytes, uint64_t alloc, nts_bf** out)
 {
-  if (!ctx || !out || bytes == 0) return fail(ctx, NTS_EINVAL, "nts_bf_create: bytes must be positive");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   nts_bf* bf = new nts_bf();
   bf->bytes = bytes;
-  const uint64_t alloc = (bytes + 15) / 16 * 16; // AND / popcount run on 16-byte lanes; tail stays zero
+  bf->alloc_bytes = alloc;
   hipError_t e = hipMalloc((void**)&bf->d_words, alloc);
   if (e != hipSuccess) {
     delete bf;
@@ -1596,6 +1597,28 @@ int nts_bf_create(nts_ctx* ctx, uint64_t bytes, nts_bf** out)
     return fail(ctx, NTS_EHIP, "hipMemset bloom");
   }
   *out = bf;
+  return NTS_OK;
+}
+
+int nts_bf_create(nts_ctx* ctx, uint64_t bytes, nts_bf** out)
+{
+  if (!ctx || !out || bytes == 0) return fail(ctx, NTS_EINVAL, "nts_bf_create: bytes must be positive");
+  return bf_create_alloc(ctx, bytes, (bytes + 15) / 16 * 16, out); // AND / popcount run on 16-byte lanes; tail stays zero
+}
+
+int nts_bf_create_sharded(nts_ctx* ctx, uint64_t bytes, int world, nts_bf** out)
+{
+  if (!ctx || !out || bytes == 0 || world < 1) return fail(ctx, NTS_EINVAL, "nts_bf_create_sharded: bad arguments");
+  const uint64_t chunk = ((bytes + world - 1) / world + 15) / 16 * 16; // the layout nts_bf_allreduce_and exchanges
+  return bf_create_alloc(ctx, bytes, chunk * world, out);
+}
+
+int nts_bf_fill_ones(nts_ctx* ctx, nts_bf* bf)
+{
+  if (!ctx || !bf) return fail(ctx, NTS_EINVAL, "nts_bf_fill_ones: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  bf->popcnt = -1;
+  HIP_TRY(ctx, hipMemsetAsync(bf->d_words, 0xFF, bf->bytes, ctx->stream)); // the pad behind `bytes` stays zero
   return NTS_OK;
 }
 
@@ -1613,6 +1636,7 @@ int nts_bf_wrap(nts_ctx* ctx, void* device_ptr, uint64_t bytes, nts_bf** out)
     return fail(ctx, NTS_EINVAL, "nts_bf_wrap: need a 16-byte aligned buffer and a positive byte count");
   nts_bf* bf = new nts_bf();
   bf->bytes = bytes;
+  bf->alloc_bytes = (bytes + 15) / 16 * 16;
   bf->d_words = (uint32_t*)device_ptr;
   bf->owned = false;
   *out = bf;
@@ -1758,6 +1782,48 @@ int nts_bench_random_probe(nts_ctx* ctx, const nts_bf* bf, uint64_t n_probes, ui
   if (e != hipSuccess) return fail(ctx, NTS_EHIP, std::string("bench: ") + hipGetErrorString(e));
   *avg_ms = ms / repeats;
   if (hits) *hits = h;
+  return NTS_OK;
+}
+
+int nts_bench_valu(nts_ctx* ctx, int kind, uint32_t waves_per_simd, uint32_t iters, double* wall_ms, double* cycles_per_instr,
+                   double* instr_per_wave)
+{
+  if (!ctx || kind < 0 || kind >= VK_COUNT || waves_per_simd == 0 || waves_per_simd > 8 || iters == 0)
+    return fail(ctx, NTS_EINVAL, "nts_bench_valu: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+  // a 256-lane workgroup = four waves, one per SIMD of its CU; `waves_per_simd` workgroups per CU
+  const uint32_t blocks = cus * waves_per_simd;
+  const uint64_t n_waves = (uint64_t)blocks * 4;
+  unsigned long long* d_cyc = (unsigned long long*)ws_get(ctx, "valu_cycles", n_waves * 8);
+  uint32_t* d_sink = (uint32_t*)ws_get(ctx, "valu_sink", 64);
+  if (!d_cyc || !d_sink) return NTS_ENOMEM;
+  ValuBenchFn fn = valu_bench_fn(kind);
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, ctx->stream, iters / 8 + 1, d_cyc, d_sink); // warm-up (clocks, code)
+  hipEventRecord(a, ctx->stream);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, ctx->stream, iters, d_cyc, d_sink);
+  hipEventRecord(b, ctx->stream);
+  std::vector<unsigned long long> cyc(n_waves);
+  hipMemcpyAsync(cyc.data(), d_cyc, n_waves * 8, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  if (e != hipSuccess) return fail(ctx, NTS_EHIP, std::string("nts_bench_valu: ") + hipGetErrorString(e));
+  const double per_iter = (double)VB_CHAINS * VB_UNROLL * (kind == VK_ADD_CO_PAIR ? 2 : 1);
+  const double n_instr = per_iter * iters;
+  std::sort(cyc.begin(), cyc.end());
+  const double median = (double)cyc[n_waves / 2];
+  if (wall_ms) *wall_ms = ms;
+  // all waves of a SIMD run their loops at the same time: the SIMD issued waves_per_simd x n_instr in `median` cycles
+  if (cycles_per_instr) *cycles_per_instr = median / (n_instr * waves_per_simd);
+  if (instr_per_wave) *instr_per_wave = n_instr;
   return NTS_OK;
 }
 
@@ -2646,6 +2712,8 @@ void nts_free(void* p)
 }
 
 } // extern "C"
+
+#include "nts_comm.inc"
 
 // ---- minimizer graph build (rows C1, C2a, C2b) --------------------------------------------------------
 namespace {

@@ -67,6 +67,22 @@ class Context:
         self.last_prune_c = d.value
         return a.value, b.value, c.value
 
+    VALU_KINDS = ["v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64", "v_lshlrev_b64", "v_mul_lo_u32", "v_mad_u64_u32",
+                  "v_add_co_u32+v_addc_co_u32", "v_xor_b32 (dependent chain)"]
+
+    def bench_valu(self, kind, waves_per_simd=4, iters=20000):
+        """Issue-rate microbenchmark of one integer VALU instruction (nts_bench_valu): dict with the shader cycles a SIMD
+        spends per wave-instruction and the wave-instructions per second per CU the wall time gives."""
+        ms, cyc, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        k = self.VALU_KINDS.index(kind) if isinstance(kind, str) else int(kind)
+        self.check(self.lib.nts_bench_valu(self.h, k, int(waves_per_simd), int(iters), ctypes.byref(ms), ctypes.byref(cyc),
+                                           ctypes.byref(n)), "nts_bench_valu")
+        per_cu = 4 * waves_per_simd * n.value / (ms.value * 1e-3)
+        return {"instruction": self.VALU_KINDS[k], "waves_per_simd": int(waves_per_simd), "wall_ms": round(ms.value, 4),
+                "cycles_per_wave_instr_per_simd": round(cyc.value, 3), "wave_instr_per_s_per_cu": per_cu,
+                # 4 SIMDs per CU, each issuing one wave-instruction per `cycles`: the clock the two figures imply
+                "implied_clock_GHz": round(per_cu * cyc.value / 4 / 1e9, 3)}
+
     def close(self):
         if self.h:
             self.lib.nts_destroy(self.h)
@@ -192,12 +208,19 @@ class Genome:
 class BloomFilter:
     """btllib::KmerBloomFilter(bytes, 1, k) stand-in, bit array in HBM."""
 
-    def __init__(self, ctx, nbytes, k):
+    def __init__(self, ctx, nbytes, k, world=1, ones=False):
+        """world > 1: allocation laid out for Comm.allreduce_and (nts_bf_create_sharded); ones: all bits set, the
+        identity of AND for a rank that owns no genome."""
         self.ctx, self.k = ctx, k
         h = c_vp()
-        ctx.check(ctx.lib.nts_bf_create(ctx.h, int(nbytes), ctypes.byref(h)), "nts_bf_create")
+        if world > 1:
+            ctx.check(ctx.lib.nts_bf_create_sharded(ctx.h, int(nbytes), int(world), ctypes.byref(h)), "nts_bf_create_sharded")
+        else:
+            ctx.check(ctx.lib.nts_bf_create(ctx.h, int(nbytes), ctypes.byref(h)), "nts_bf_create")
         self.h = h
         self.bytes = int(nbytes)
+        if ones:
+            ctx.check(ctx.lib.nts_bf_fill_ones(ctx.h, h), "nts_bf_fill_ones")
 
     def insert(self, genome):
         "bf->insert(record.seq) for every record (cpp:128-131)"
@@ -251,6 +274,66 @@ class BloomFilter:
             self.free()
         except Exception:
             pass
+
+
+class Comm:
+    """RCCL communicator of the multi-GPU path, one rank per GPU (nts_comm_*).  `exchange_id(id_or_None) -> id` hands the
+    128-byte id made on rank 0 to every rank (torch.distributed's store in this package; any launcher would do)."""
+
+    def __init__(self, ctx, world, rank, exchange_id):
+        self.ctx, self.world, self.rank = ctx, int(world), int(rank)
+        ident = None
+        if rank == 0:
+            buf = (ctypes.c_uint8 * 128)()
+            if ctx.lib.nts_comm_unique_id(buf) != 0:
+                raise NtsError("nts_comm_unique_id failed: librccl could not be loaded")
+            ident = bytes(buf)
+        ident = exchange_id(ident)
+        h = c_vp()
+        raw = (ctypes.c_uint8 * 128).from_buffer_copy(ident)
+        ctx.check(ctx.lib.nts_comm_init(ctx.h, raw, self.world, self.rank, ctypes.byref(h)), "nts_comm_init")
+        self.h = h
+
+    @classmethod
+    def from_torch(cls, ctx):
+        "communicator over the ranks of torch.distributed's default group (used only to pass the id around)"
+        import torch.distributed as dist
+
+        def exchange(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        return cls(ctx, dist.get_world_size(), dist.get_rank(), exchange)
+
+    def allreduce_and(self, bf):
+        "exchange 1: bf &= every other rank's filter, in place (bf from BloomFilter(..., world=N))"
+        self.ctx.check(self.ctx.lib.nts_bf_allreduce_and(self.ctx.h, bf.h, self.h), "nts_bf_allreduce_and")
+
+    def allgather_minimizers(self, local, local_ids, n_total):
+        "exchange 2: the ranks' Minimizers -> [Minimizers of genome g for g in range(n_total)], resident in HBM"
+        return allgather_minimizers(self.ctx, self, local, local_ids, n_total)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.nts_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def allgather_minimizers(ctx, comm, local, local_ids, n_total):
+    "nts_mx_allgather; comm None = one rank (the lists are copied into fresh handles)"
+    n = len(local)
+    arr = (c_vp * max(n, 1))(*[m.h for m in local])
+    ids = (ctypes.c_uint32 * max(n, 1))(*[int(i) for i in local_ids])
+    out = (c_vp * int(n_total))()
+    ctx.check(ctx.lib.nts_mx_allgather(ctx.h, comm.h if comm is not None else None, n, arr, ids, int(n_total), out),
+              "nts_mx_allgather")
+    return [Minimizers(ctx, c_vp(out[g])) for g in range(int(n_total))]
 
 
 class Minimizers:

@@ -87,6 +87,8 @@ class GpuBackend:
         self.device = self.ctx.device
         # collectives on host copies (gloo) instead of device buffers (RCCL): verification mode, see cli.py
         self.host_comm = os.environ.get("NTS_DIST_BACKEND", "nccl") != "nccl"
+        self.comm = None
+        self._batch = None                 # (key, Genome): the run's assemblies as one resident batch genome
 
     # genomes
     def read_host(self, path):
@@ -103,13 +105,18 @@ class GpuBackend:
     def load_genome(self, path):
         return self.upload_host(self.read_host(path))
 
-    # Bloom filters: the bit array lives in a torch tensor when collectives will run on it
+    # multi-GPU: the two exchanges run in the library over RCCL (nts_bf_allreduce_and, nts_mx_allgather); the id of the
+    # communicator travels through torch.distributed's default group.  host_comm: verification mode (see __init__).
+    def init_comm(self):
+        if not self.host_comm and self.comm is None:
+            from .device import Comm
+            self.comm = Comm.from_torch(self.ctx)
+
     def bf_new(self, nbytes, k, world=1, ones=False):
         from .device import BloomFilter, wrap_bloom
-        if world == 1:
-            assert not ones
-            return BloomFilter(self.ctx, nbytes, k)
-        import torch                      # multi-GPU only: a single-GPU run never pays for the import
+        if world == 1 or not self.host_comm:
+            return BloomFilter(self.ctx, nbytes, k, world=world, ones=ones)
+        import torch
         from .dist import padded_len
         buf = torch.zeros(padded_len(nbytes, world), dtype=torch.uint8, device=f"cuda:{self.device}")
         if ones:                      # identity of AND, for a rank that owns no genome
@@ -153,20 +160,27 @@ class GpuBackend:
     # below this many bases per assembly the fixed cost of a launch sequence shows: sketch the assemblies as one batch
     BATCH_BELOW_BP = 1 << 30
 
-    def sketch_batch(self, genomes, k, w, bf):
-        """Whole-genome sketches of several resident genomes with one sequence of launches (Genome.concat): the same
-        lists as sketch() per genome."""
+    def sketch_batch(self, genomes, k, w, bf, masks=None):
+        """Sketches of several resident genomes with one sequence of launches (Genome.concat): the same lists as sketch()
+        per genome.  masks[i]: hard-mask intervals (record, start, end) of genome i (a refinement round, row B5); they
+        address the batch through its record numbering.  The batch genome stays resident for the run: the refinement
+        rounds sketch it again."""
         from .device import Genome, sketch
         if len(genomes) < 2 or max(g.total_bp for g in genomes) >= self.BATCH_BELOW_BP:
-            return [self.sketch(g, k, w, bf) for g in genomes]
-        batch = Genome.concat(self.ctx, genomes)
-        try:
-            mx = sketch(self.ctx, batch, k, w, bf)
-            out = mx.to_numpy()
-            mx.free()
-            return batch.split_minimizers(*out)
-        finally:
-            batch.free()
+            return [self.sketch(g, k, w, bf, masks[i] if masks else None) for i, g in enumerate(genomes)]
+        key = tuple(id(g) for g in genomes)
+        if self._batch is None or self._batch[0] != key:
+            if self._batch is not None:
+                self._batch[1].free()
+            self._batch = (key, Genome.concat(self.ctx, genomes))
+        batch = self._batch[1]
+        joined = None
+        if masks:
+            joined = [(int(r) + int(batch.rec_base[i]), s, e) for i, m in enumerate(masks) for r, s, e in (m or [])]
+        mx = sketch(self.ctx, batch, k, w, bf, joined)
+        out = mx.to_numpy()
+        mx.free()
+        return batch.split_minimizers(*out)
 
     def graph(self, lists, keeps, list_ids):
         from .graph import build_graph_device
@@ -188,19 +202,39 @@ class GpuBackend:
         return torch.empty(n, dtype=dtype, device="cpu" if self.host_comm else f"cuda:{self.device}")
 
     def allreduce_and(self, bf):
-        "common filter = AND over the ranks' filters, in place"
+        "exchange 1: common filter = AND over the ranks' filters, in place"
+        self.ctx.sync()
+        if not self.host_comm:
+            self.comm.allreduce_and(bf)
+            return
         import torch
         from .dist import allreduce_and
-        self.ctx.sync()
-        if self.host_comm:
-            staged = bf.tensor.cpu()
-            allreduce_and(staged, lambda a, b: a.bitwise_and_(b))
-            bf.tensor.copy_(staged)
-        else:
-            allreduce_and(bf.tensor, self.and_into)
+        staged = bf.tensor.cpu()
+        allreduce_and(staged, lambda a, b: a.bitwise_and_(b))
+        bf.tensor.copy_(staged)
         torch.cuda.synchronize(bf.tensor.device)
 
+    def exchange_lists(self, local, n_total):
+        """exchange 2: {genome index: (h1, rec, pos)} of this rank -> the lists of all genomes on every rank, as ONE
+        device all-gather (nts_mx_allgather).  Verification mode: None (the caller gathers host objects)."""
+        if self.host_comm:
+            return None
+        from .device import Minimizers
+        ids = sorted(local)
+        mine = [Minimizers.from_numpy(self.ctx, *local[i]) for i in ids]
+        everything = self.comm.allgather_minimizers(mine, ids, n_total)
+        out = [m.to_numpy() for m in everything]
+        for m in mine + everything:
+            m.free()
+        return out
+
     def close(self):
+        if self._batch is not None:
+            self._batch[1].free()
+            self._batch = None
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
         if self.own_ctx:
             self.ctx.close()
 
@@ -217,27 +251,19 @@ def load_genomes(backend, paths, max_threads=8):
         return {p: backend.upload_host(f.result()) for p, f in zip(paths, pending)}
 
 
-def _bcast_list(backend, owner, payload):
-    """Broadcast one minimizer list (h1 uint64, rec uint32, pos uint64 numpy arrays) from `owner`."""
-    import torch
+def _exchange_lists(backend, local, n_total):
+    """Exchange 2: every rank contributes the minimizer lists of its own genomes ({genome index: (h1,
+    rec, pos)}) and receives those of all genomes, in one all-gather -- on the GPUs through the backend
+    (nts_mx_allgather over RCCL), otherwise (test doubles, verification mode) as host objects."""
     import torch.distributed as dist
-    rank = dist.get_rank()
-    n = backend.to_comm(np.array([len(payload[0]) if rank == owner else 0], dtype=np.int64), np.int64)
-    dist.broadcast(n, src=owner)
-    cnt = int(n.item())
-    if rank == owner:
-        h1 = backend.to_comm(payload[0].astype(np.uint64), np.int64)
-        rec = backend.to_comm(payload[1].astype(np.uint32), np.int32)
-        pos = backend.to_comm(payload[2].astype(np.uint64), np.int64)
-    else:
-        h1 = backend.comm_empty(cnt, torch.int64)
-        rec = backend.comm_empty(cnt, torch.int32)
-        pos = backend.comm_empty(cnt, torch.int64)
-    if cnt:
-        dist.broadcast(h1, src=owner)
-        dist.broadcast(rec, src=owner)
-        dist.broadcast(pos, src=owner)
-    return (h1.cpu().numpy().view(np.uint64), rec.cpu().numpy().view(np.uint32), pos.cpu().numpy().view(np.uint64))
+    if hasattr(backend, "exchange_lists"):
+        out = backend.exchange_lists(local, n_total)
+        if out is not None:
+            return out
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, {i: tuple(np.ascontiguousarray(x) for x in v) for i, v in local.items()})
+    merged = {i: v for part in box for i, v in part.items()}
+    return [merged[i] for i in range(n_total)]
 
 
 def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000, merge=10000,
@@ -257,6 +283,8 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     own_backend = backend is None
     backend = backend or GpuBackend(device, ctx)
     st = Stages()
+    if world > 1 and hasattr(backend, "init_comm"):
+        backend.init_comm()
     owner = {p: i % world for i, p in enumerate(fastas)}
     mine = [p for p in fastas if owner[p] == rank]
 
@@ -323,22 +351,18 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         st.stop()
 
     st.start("indexlr")
-    tsv_names, initial = [], []
-    batched = None
+    tsv_names = [f"{fa.basename(p)}.k{k}.w{w}.tsv" for p in fastas]
     if world == 1 and hasattr(backend, "sketch_batch"):
-        batched = dict(zip(fastas, backend.sketch_batch([genomes[p] for p in fastas], k, w, bf)))
-    for p in fastas:
-        if batched is not None:
-            out = batched[p]
-        else:
-            out = backend.sketch(genomes[p], k, w, bf) if owner[p] == rank else None
-        tsv = f"{fa.basename(p)}.k{k}.w{w}.tsv"
-        if owner[p] == rank and write_mx_tsv:
-            pending_files.append(writers.submit(write_indexlr_tsv, tsv, genomes[p].recs, out[0], out[1], out[2], k, mx_with_seq))
-        if world > 1:
-            out = _bcast_list(backend, owner[p], out)
-        tsv_names.append(tsv)
-        initial.append(out)
+        initial = backend.sketch_batch([genomes[p] for p in fastas], k, w, bf)
+    else:
+        local = {i: backend.sketch(genomes[p], k, w, bf) for i, p in enumerate(fastas) if owner[p] == rank}
+        initial = _exchange_lists(backend, local, len(fastas)) if world > 1 else [local[i] for i in range(len(fastas))]
+    if write_mx_tsv:
+        for i, p in enumerate(fastas):
+            if owner[p] == rank:
+                out = initial[i]
+                pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], genomes[p].recs, out[0], out[1], out[2], k,
+                                                    mx_with_seq))
     st.stop()
     if bf is not None and rank == 0:
         # filter file: device -> host copy on the library's copy stream + write, on a writer thread, started once the
@@ -348,9 +372,21 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     st.start("ntsynt_synteny")
 
     def sketch_fn(i, masks, new_w):
-        p = fastas[i]
-        out = backend.sketch(genomes[p], k, new_w, bf, masks) if owner[p] == rank else None
-        return _bcast_list(backend, owner[p], out) if world > 1 else out
+        return sketch_round({i: masks}, new_w)[i]
+
+    def sketch_round(masks_by_asm, new_w):
+        "re-sketch of a refinement round for the assemblies given: each owner sketches its own, one exchange hands them round"
+        if world == 1 and hasattr(backend, "sketch_batch") and len(masks_by_asm) == len(fastas):
+            got = backend.sketch_batch([genomes[p] for p in fastas], k, new_w, bf, [masks_by_asm[i] for i in range(len(fastas))])
+            return dict(enumerate(got))
+        local = {i: backend.sketch(genomes[fastas[i]], k, new_w, bf, m) for i, m in masks_by_asm.items() if owner[fastas[i]] == rank}
+        if world == 1:
+            return local
+        ids = sorted(masks_by_asm)
+        # (the exchange numbers lists 0..n-1: positions in `ids`)
+        got = _exchange_lists(backend, {ids.index(i): v for i, v in local.items()}, len(ids))
+        return {i: got[j] for j, i in enumerate(ids)}
+    sketch_fn.all_at_once = sketch_round
 
     if rank != 0:                       # replicas compute, only rank 0 leaves files behind
         scratch = os.path.join(os.getcwd(), f".ntsynt_rank{rank}")
@@ -380,6 +416,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     st.stop()
     if benchmark and rank == 0:
         st.write(f"{prefix}.stage_times.tsv")
+    if getattr(backend, "_batch", None) is not None:
+        backend._batch[1].free()
+        backend._batch = None
     for g in genomes.values():
         if hasattr(g, "free"):
             g.free()

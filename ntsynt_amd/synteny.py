@@ -63,7 +63,8 @@ class SyntenyEngine:
     """files: minimizer-TSV names identifying the assemblies (any order; sorted descending like
     S:34); contig_names[a]: record names of assembly a (indexable by record id);
     graph_fn(lists, keep, list_ids) -> GraphArrays with lists[a] = (h1, rec, pos) arrays;
-    sketch_fn(a, masks, w) -> (h1, rec, pos) of assembly a re-sketched with hard masks [(rec, s, e)];
+    sketch_fn(a, masks, w) -> (h1, rec, pos) of assembly a re-sketched with hard masks [(rec, s, e)]; if it carries an
+    attribute all_at_once({a: masks}, w) -> {a: (h1, rec, pos)}, a refinement round calls that once instead;
     walk_fn / scan_fn: chain walk and per-path scan (native host helpers nts_walk_chains / nts_path_scan)."""
 
     def __init__(self, files, contig_names, k, w, w_rounds, bp, collinear_merge, z, prefix, graph_fn, sketch_fn,
@@ -121,6 +122,8 @@ class SyntenyEngine:
                 finally:
                     self.times[name] = self.times.get(name, 0.0) + time.perf_counter() - t0
             timed.oriented = getattr(fn, "oriented", False)
+            if getattr(fn, "all_at_once", None) is not None:
+                timed.all_at_once = wrap(name, fn.all_at_once)
             return timed
         for name in ("graph_fn", "sketch_fn", "walk_fn", "scan_fn") + (("degree_fn",) if self.degree_fn else ()):
             setattr(self, name, wrap(name, getattr(self, name)))
@@ -497,8 +500,14 @@ class SyntenyEngine:
         hs, hid = self._live_index()
         uh = hs[internal[hid]]                             # hashes of the live internal vertices, ascending
         lists, keeps, list_ids = [], [], []
+        # all assemblies of the round at once when the caller can (one batch on the GPU, one exchange across GPUs)
+        sketched = None
+        if getattr(self.sketch_fn, "all_at_once", None) is not None:
+            by_input = {self.input_order[a]: masks[a] for a in range(self.G)}
+            res = self.sketch_fn.all_at_once(by_input, new_w)
+            sketched = [res[self.input_order[a]] for a in range(self.G)]
         for a in range(self.G):
-            h1, rec, pos = self.sketch_fn(self.input_order[a], masks[a], new_w)
+            h1, rec, pos = sketched[a] if sketched is not None else self.sketch_fn(self.input_order[a], masks[a], new_w)
             h1 = np.asarray(h1, np.uint64)
             rec = np.asarray(rec, np.int64)
             pos = np.asarray(pos, np.int64)

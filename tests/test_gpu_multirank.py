@@ -28,15 +28,16 @@ def _torchrun(n, script_args, env_extra, cwd):
 
 
 def test_bench_two_ranks(tmp_path):
-    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mbp", "6", "--contigs", "2",
-                      "--no-cpu-baseline"], {"NTS_BENCH_BACKEND": "gloo"}, tmp_path)
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c4", "--genomes", "4",
+                      "--mbp", "6", "--contigs", "2"], {"NTS_BENCH_BACKEND": "gloo"}, tmp_path)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 2
-    assert out["config"]["genomes_per_gpu"] == 3 and "6 genomes" in out["config"]["workload"]
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and out["steps"] == 2
+    assert out["config"]["genomes_on_rank0"] == 2 and "c4: 4 synthetic" in out["config"]["workload"]
     assert out["bloom"]["allreduce_and_s"] > 0
+    assert "e2e" not in out and "cpu_baseline" not in out          # single-GPU legs only
 
 
 def test_pipeline_two_ranks_matches_single_rank(tmp_path):
