@@ -2889,28 +2889,43 @@ T* host_copy(nts_ctx* ctx, const T* d, uint64_t n)
 
 } // namespace
 
-extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* lists, nts_graph* out)
+namespace {
+
+// Device-side result of one build, in the context's scratch (valid until the next build on this context)
+struct GraphDev
 {
-  if (!ctx || !out || n_asm == 0 || !lists) return fail(ctx, NTS_EINVAL, "nts_graph_build: bad arguments");
-  memset(out, 0, sizeof(*out));
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  uint64_t n = 0;
-  for (uint32_t a = 0; a < n_asm; ++a) {
-    if (lists[a].n && (!lists[a].h1 || !lists[a].rec || !lists[a].pos)) return fail(ctx, NTS_EINVAL, "nts_graph_build: NULL list arrays");
-    n += lists[a].n;
-  }
-  if (n >= 0xFFFFFFFFULL) return fail(ctx, NTS_ERANGE, "nts_graph_build: more than 2^32 minimizers");
-  auto finish_empty = [&]() {
-    out->v_hash = (uint64_t*)malloc(8);
-    out->occ_rec = (uint32_t*)malloc(8);
-    out->occ_pos = (uint64_t*)malloc(8);
-    out->e_u = (uint32_t*)malloc(8);
-    out->e_v = (uint32_t*)malloc(8);
-    out->e_w = (uint32_t*)malloc(8);
-    out->e_first = (uint64_t*)malloc(8);
-    return NTS_OK;
-  };
-  if (n == 0) return finish_empty();
+  uint64_t n = 0;   // elements given
+  uint64_t nv = 0, ne = 0;
+  uint64_t* v_hash = nullptr; // [nv] ascending
+  uint32_t* occ_rec = nullptr; // [n_asm * nv]
+  uint64_t* occ_pos = nullptr;
+  uint32_t *e_u = nullptr, *e_v = nullptr, *e_w = nullptr; // [ne] dict order
+  uint64_t* e_first = nullptr;
+};
+
+// Hook between duplicate removal and the cross-assembly intersection: given valid[e] per element (in element order),
+// a caller may rewrite the list ids (refinement rounds cut lists between consecutive *kept* minimizers, row C11).
+struct ListHook
+{
+  virtual int operator()(nts_ctx* ctx, uint64_t n, const uint8_t* d_valid_elem, const uint32_t* d_asm, const uint32_t* d_rec, const uint64_t* d_pos,
+                         uint32_t* d_list) = 0;
+  virtual ~ListHook() {}
+};
+
+__global__ __launch_bounds__(256) void k_g_valid_scatter(const uint64_t* __restrict__ idx_sorted, const uint8_t* __restrict__ valid, uint64_t n,
+                                                         uint8_t* __restrict__ valid_elem)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) valid_elem[idx_sorted[i]] = valid[i];
+}
+
+// The build proper.  Expects the concatenated elements (assembly-major) already in the scratch buffers g_h / g_rec / g_pos /
+// g_keep / g_list / g_asm / g_idx (filled by the callers below); leaves the graph in scratch and describes it in `G`.
+int graph_build_core(nts_ctx* ctx, uint32_t n_asm, uint64_t n, GraphDev* G, ListHook* hook)
+{
+  *G = GraphDev();
+  G->n = n;
+  if (n == 0) return NTS_OK;
 #define G_WS(ptr, type, name, bytes)                                                                \
   type ptr = (type)ws_get(ctx, name, bytes);                                                        \
   if (!ptr) return NTS_ENOMEM
@@ -2927,24 +2942,6 @@ extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* l
   G_WS(d_flag, uint64_t*, "g_flag", n * 8);
   G_WS(d_scan, uint64_t*, "g_scan", (n + 1) * 8);
   G_WS(d_evid, uint32_t*, "g_evid", n * 4);
-  // assembly-major concatenation; element numbers and assembly ids are generated on the device (each assembly's range is
-  // one launch), the keep mask is uploaded only where a list brings one
-  uint64_t o = 0;
-  for (uint32_t a = 0; a < n_asm; ++a) {
-    const uint64_t m = lists[a].n;
-    if (m) {
-      HIP_TRY(ctx, hipMemcpyAsync(d_h + o, lists[a].h1, m * 8, hipMemcpyHostToDevice, ctx->stream));
-      HIP_TRY(ctx, hipMemcpyAsync(d_rec + o, lists[a].rec, m * 4, hipMemcpyHostToDevice, ctx->stream));
-      HIP_TRY(ctx, hipMemcpyAsync(d_pos + o, lists[a].pos, m * 8, hipMemcpyHostToDevice, ctx->stream));
-      HIP_TRY(ctx, hipMemcpyAsync(d_list + o, lists[a].list_id ? lists[a].list_id : lists[a].rec, m * 4, hipMemcpyHostToDevice, ctx->stream));
-      if (lists[a].keep)
-        HIP_TRY(ctx, hipMemcpyAsync(d_keep + o, lists[a].keep, m, hipMemcpyHostToDevice, ctx->stream));
-      else
-        HIP_TRY(ctx, hipMemsetAsync(d_keep + o, 1, m, ctx->stream));
-      hipLaunchKernelGGL(k_g_number, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_idx + o, d_asm + o, m, o, a);
-    }
-    o += m;
-  }
   const uint32_t nb = (uint32_t)((n + 255) / 256);
   size_t tmp_sort = 0, tmp_scan = 0;
   HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort, d_h, d_h2, d_idx, d_idx2, n, 0, 64, ctx->stream));
@@ -2955,6 +2952,14 @@ extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* l
     // C1 + keep mask
     HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp, tmp_sort, d_h, d_h2, d_idx, d_idx2, n, 0, 64, ctx->stream));
     hipLaunchKernelGGL(k_g_valid, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_idx2, d_asm, d_keep, n, d_valid);
+  }
+  if (hook) {
+    G_WS(d_valid_elem, uint8_t*, "g_valid_elem", n);
+    hipLaunchKernelGGL(k_g_valid_scatter, dim3(nb), dim3(256), 0, ctx->stream, d_idx2, d_valid, n, d_valid_elem);
+    if (int rc = (*hook)(ctx, n, d_valid_elem, d_asm, d_rec, d_pos, d_list)) return rc;
+  }
+  {
+    ScopedTimer t(ctx, "graph_build");
     // C2a
     hipLaunchKernelGGL(k_g_common, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_valid, n, n_asm, d_flag);
     HIP_TRY(ctx, rocprim::exclusive_scan(d_tmp, tmp_scan, d_flag, d_scan, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
@@ -2964,8 +2969,8 @@ extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* l
   HIP_TRY(ctx, hipMemcpyAsync(&last_scan, d_scan + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const uint64_t nv = last_scan + last_flag;
-  out->nv = nv;
-  if (nv == 0) return finish_empty();
+  G->nv = nv;
+  if (nv == 0) return NTS_OK;
   G_WS(d_vhash, uint64_t*, "g_vhash", nv * 8);
   G_WS(d_orec, uint32_t*, "g_orec", (uint64_t)n_asm * nv * 4);
   G_WS(d_opos, uint64_t*, "g_opos", (uint64_t)n_asm * nv * 8);
@@ -3005,7 +3010,7 @@ extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* l
   HIP_TRY(ctx, hipMemcpyAsync(&last_scan, d_es + (m - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const uint64_t ne = last_scan + last_flag;
-  out->ne = ne;
+  G->ne = ne;
   G_WS(d_eu, uint32_t*, "g_eu", std::max<uint64_t>(ne, 1) * 4);
   G_WS(d_ev, uint32_t*, "g_ev", std::max<uint64_t>(ne, 1) * 4);
   G_WS(d_ew, uint32_t*, "g_ew", std::max<uint64_t>(ne, 1) * 4);
@@ -3030,20 +3035,105 @@ extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* l
     hipLaunchKernelGGL(k_g_permute_edges, dim3(eb), dim3(256), 0, ctx->stream, d_seq2, ne, d_eu0, d_ev0, d_ew0, d_ef0, d_eu, d_ev, d_ew, d_ef);
   }
   HIP_TRY(ctx, hipGetLastError());
-  out->v_hash = host_copy(ctx, d_vhash, nv);
-  out->occ_rec = host_copy(ctx, d_orec, (uint64_t)n_asm * nv);
-  out->occ_pos = host_copy(ctx, d_opos, (uint64_t)n_asm * nv);
-  out->e_u = host_copy(ctx, d_eu, ne);
-  out->e_v = host_copy(ctx, d_ev, ne);
-  out->e_w = host_copy(ctx, d_ew, ne);
-  out->e_first = host_copy(ctx, d_ef, ne);
+  G->v_hash = d_vhash;
+  G->occ_rec = d_orec;
+  G->occ_pos = d_opos;
+  G->e_u = d_eu;
+  G->e_v = d_ev;
+  G->e_w = d_ew;
+  G->e_first = d_ef;
+  return NTS_OK;
+#undef G_WS
+}
+
+// scratch buffers of the concatenation, sized for n elements
+struct GraphIn
+{
+  uint64_t* h = nullptr;
+  uint64_t* idx = nullptr;
+  uint32_t* asm_id = nullptr;
+  uint32_t* rec = nullptr;
+  uint64_t* pos = nullptr;
+  uint8_t* keep = nullptr;
+  uint32_t* list = nullptr;
+};
+
+int graph_inputs(nts_ctx* ctx, uint64_t n, GraphIn* in)
+{
+  const uint64_t c = std::max<uint64_t>(n, 1);
+  in->h = (uint64_t*)ws_get(ctx, "g_h", c * 8);
+  in->idx = (uint64_t*)ws_get(ctx, "g_idx", c * 8);
+  in->asm_id = (uint32_t*)ws_get(ctx, "g_asm", c * 4);
+  in->rec = (uint32_t*)ws_get(ctx, "g_rec", c * 4);
+  in->pos = (uint64_t*)ws_get(ctx, "g_pos", c * 8);
+  in->keep = (uint8_t*)ws_get(ctx, "g_keep", c);
+  in->list = (uint32_t*)ws_get(ctx, "g_list", c * 4);
+  return (in->h && in->idx && in->asm_id && in->rec && in->pos && in->keep && in->list) ? NTS_OK : NTS_ENOMEM;
+}
+
+} // namespace
+
+extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* lists, nts_graph* out)
+{
+  if (!ctx || !out || n_asm == 0 || !lists) return fail(ctx, NTS_EINVAL, "nts_graph_build: bad arguments");
+  memset(out, 0, sizeof(*out));
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t n = 0;
+  for (uint32_t a = 0; a < n_asm; ++a) {
+    if (lists[a].n && (!lists[a].h1 || !lists[a].rec || !lists[a].pos)) return fail(ctx, NTS_EINVAL, "nts_graph_build: NULL list arrays");
+    n += lists[a].n;
+  }
+  if (n >= 0xFFFFFFFFULL) return fail(ctx, NTS_ERANGE, "nts_graph_build: more than 2^32 minimizers");
+  auto finish_empty = [&]() {
+    out->v_hash = (uint64_t*)malloc(8);
+    out->occ_rec = (uint32_t*)malloc(8);
+    out->occ_pos = (uint64_t*)malloc(8);
+    out->e_u = (uint32_t*)malloc(8);
+    out->e_v = (uint32_t*)malloc(8);
+    out->e_w = (uint32_t*)malloc(8);
+    out->e_first = (uint64_t*)malloc(8);
+    return NTS_OK;
+  };
+  if (n == 0) return finish_empty();
+  GraphIn in;
+  if (graph_inputs(ctx, n, &in) != NTS_OK) return NTS_ENOMEM;
+  // assembly-major concatenation; element numbers and assembly ids are generated on the device (each assembly's range is
+  // one launch), the keep mask is uploaded only where a list brings one
+  uint64_t o = 0;
+  for (uint32_t a = 0; a < n_asm; ++a) {
+    const uint64_t m = lists[a].n;
+    if (m) {
+      HIP_TRY(ctx, hipMemcpyAsync(in.h + o, lists[a].h1, m * 8, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(in.rec + o, lists[a].rec, m * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(in.pos + o, lists[a].pos, m * 8, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(in.list + o, lists[a].list_id ? lists[a].list_id : lists[a].rec, m * 4, hipMemcpyHostToDevice, ctx->stream));
+      if (lists[a].keep)
+        HIP_TRY(ctx, hipMemcpyAsync(in.keep + o, lists[a].keep, m, hipMemcpyHostToDevice, ctx->stream));
+      else
+        HIP_TRY(ctx, hipMemsetAsync(in.keep + o, 1, m, ctx->stream));
+      hipLaunchKernelGGL(k_g_number, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, ctx->stream, in.idx + o, in.asm_id + o, m, o, a);
+    }
+    o += m;
+  }
+  GraphDev G;
+  if (int rc = graph_build_core(ctx, n_asm, n, &G, nullptr)) return rc;
+  const uint64_t nv = G.nv, ne = G.ne;
+  out->nv = nv;
+  out->ne = ne;
+  if (nv == 0) return finish_empty();
+  out->v_hash = host_copy(ctx, G.v_hash, nv);
+  out->occ_rec = host_copy(ctx, G.occ_rec, (uint64_t)n_asm * nv);
+  out->occ_pos = host_copy(ctx, G.occ_pos, (uint64_t)n_asm * nv);
+  out->e_u = host_copy(ctx, G.e_u, ne);
+  out->e_v = host_copy(ctx, G.e_v, ne);
+  out->e_w = host_copy(ctx, G.e_w, ne);
+  out->e_first = host_copy(ctx, G.e_first, ne);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (!out->v_hash || !out->occ_rec || !out->occ_pos || !out->e_u || !out->e_v || !out->e_w || !out->e_first) {
     nts_graph_free(out);
     return fail(ctx, NTS_ENOMEM, "nts_graph_build: host allocation failed");
   }
   return NTS_OK;
-#undef G_WS
 }
 
 extern "C" void nts_graph_free(nts_graph* g)

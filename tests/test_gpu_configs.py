@@ -289,3 +289,57 @@ def test_comm_layer_on_one_rank(ctx):
         h.free()
     g.free()
     comm.close()
+
+
+# ------------------------------------------------------------------------------------------------ unpinned btllib details
+@pytest.mark.parametrize("rounding", ["down", "none"])
+def test_bloom_rounding_switch_matches_oracle(ctx, tmp_path, rounding):
+    """SURVEY.md 8(c) u1 as a switch: with the constructor rounding 'down' or 'none' the modulus of every bit index
+    changes; HIP and oracle must agree on the filter bits, the sketch and the whole pipeline for each setting."""
+    from ntsynt_amd import pipeline, synth
+    from ntsynt_amd.device import BloomFilter, bf_size_bytes
+    from tests.helpers import oracle_flat, to_device
+    from ntsynt_amd.device import sketch
+    paths = synth.make_family(str(tmp_path), 2, 1_200_003, 2, 0.01, seed=91, micro=4)
+    genomes = [O.read_fasta(p) for p in paths]
+    approx, nbytes = bf_size_bytes(genomes[0].total_bp, 0.025, rounding)
+    assert nbytes == O.bf_ctor_bytes(approx, rounding)
+    assert nbytes != bf_size_bytes(genomes[0].total_bp, 0.025)[1]
+    if rounding == "none":
+        assert nbytes % 8 != 0                                   # the case the default rounding never produces
+    for mode in ("atomic", "binned"):
+        ctx.bf_build_mode(mode)
+        dev = [to_device(ctx, g.names, [g.record(i) for i in range(len(g.names))]) for g in genomes]
+        bf = BloomFilter(ctx, nbytes, 24)
+        bf.insert(dev[0])
+        other = BloomFilter(ctx, nbytes, 24)
+        other.insert(dev[1])
+        bf.and_(other)
+        want = O.bf_build(genomes[1], 24, nbytes, prev=O.bf_build(genomes[0], 24, nbytes))
+        assert np.array_equal(bf.to_numpy(), want), mode
+        for d, g in zip(dev, genomes):
+            for sk_mode in ("pruned", "dense"):
+                ctx.sketch_mode(sk_mode)
+                got = sketch(ctx, d, 24, 300, bf).to_numpy()
+                exp = oracle_flat(O.minimize(g, 24, 300, want))
+                assert np.array_equal(got[0], exp[0]) and np.array_equal(got[2], exp[2])
+        ctx.sketch_mode("auto")
+        other.free()
+        bf.free()
+        for d in dev:
+            d.free()
+    ctx.bf_build_mode("auto")
+    kw = dict(k=24, w=300, w_rounds=[100, 10], indel=500, merge=3000, block_size=300, bf_rounding=rounding)
+    cwd = os.getcwd()
+    try:
+        os.makedirs(tmp_path / "hip")
+        os.makedirs(tmp_path / "ora")
+        os.chdir(tmp_path / "hip")
+        eng = pipeline.run(paths, prefix="r", log=lambda *x: None, ctx=ctx, **kw)
+        os.chdir(tmp_path / "ora")
+        ora = SO.run_pipeline(paths, prefix="r", **kw)
+    finally:
+        os.chdir(cwd)
+    assert eng.outputs["r.synteny_blocks.tsv"] == ora.outputs["r.synteny_blocks.tsv"]
+    bits, _ = pipeline.read_bf(str(tmp_path / "hip" / "r.common.bf"))
+    assert np.array_equal(bits, ora.bf) and bits.size == nbytes
