@@ -217,6 +217,9 @@ int nts_mx_export(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, v
 /* the same without waiting: the copies are queued on the context's stream; nts_sync() before the buffers are read
  * by another stream and before the list is freed (several lists, one wait) */
 int nts_mx_export_async(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, void* pos_dev);
+/* the list of a batch genome (nts_genome_concat) taken apart on the device: out[p] = the minimizers of records
+ * [rec_base[p], rec_base[p+1]) with record ids rebased to the part (rec_base has n_parts + 1 entries) */
+int nts_mx_split(nts_ctx* ctx, const nts_mx* mx, uint32_t n_parts, const uint32_t* rec_base, nts_mx** out);
 /* build a device list from host arrays (receiving side of the all-gather, tests) */
 int nts_mx_upload(nts_ctx* ctx,
                   const uint64_t* h1,
@@ -276,6 +279,72 @@ typedef struct
 } nts_graph;
 int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* lists, nts_graph* out);
 void nts_graph_free(nts_graph* g);
+
+/* ---- C1-C9, C11, C12 (erosion): the minimizer graph of a run, resident in HBM across rounds ---------------------------
+ * replaces the graph object the reference's stage 3 keeps in igraph / Python dicts (bin/ntsynt_synteny.py:31-32, ntJoin's
+ * Ntjoin.graph) and every walk over it; only block tables (a few numbers per synteny block) and the rare-event lists of
+ * the bubble rule return to the host.  Kernels and rule-by-rule citations: ntsynt_amd/csrc/nts_dgraph.inc; host driver:
+ * ntsynt_amd/synteny_device.py.
+ *
+ * nts_engine_create(n_asm, ref_asm): assemblies in the reference's order (descending file name, S:34); ref_asm = the one
+ *     whose positions orient the paths (ntJoin: the last = lexicographically smallest file).
+ * nts_engine_add: build_graph(..., graph=self.graph, black_list=terminals) (S:483, S:612) from minimizer lists resident
+ *     in HBM (nts_sketch / nts_mx_allgather results go in without touching the host).  spans == NULL: initial round.
+ *     Refinement round (S:476-491, S:256-290): spans[a] = the block interiors of assembly a as composite keys
+ *     record * 2^40 + position sorted by `start`, `end_max` = running maximum of the composite ends.
+ * nts_engine_bubbles / nts_engine_apply: input and outcome of run_graph_simplification (S:566-590); the rule is order
+ *     dependent and touches a handful of edges, it runs on the host over this table.
+ * nts_engine_filter: filter_graph_global(_flag_overlaps) (S:292-303, S:491, S:617).
+ * nts_engine_erode: refine_graph / erode_edges (S:305-362) over the pairs flagged by the last filter.
+ * nts_engine_blocks: find_paths (ntJoin, called at S:492, S:620) by pointer jumping, then find_synteny_blocks,
+ *     determine_orientations, check_for_indels, filter_synteny_blocks (S:66-106, synteny_block.py:48-70, S:364-426);
+ *     per kept block: first / last vertex, number of minimizers, and per assembly [a * n_blocks + b] the contig, first and
+ *     last position and orientation code (0 '+', 1 '-').
+ * nts_engine_read: field read-back for tests ("v_hash", "v_alive", "v_rec", "v_pos", "internal", "terminal", "e_u",
+ *     "e_v", "e_w", "e_alive", "path_verts", "path_off"). */
+typedef struct nts_engine nts_engine;
+typedef struct
+{
+  const uint64_t* start;
+  const uint64_t* end_max;
+  uint64_t n;
+} nts_spans;
+typedef struct
+{
+  uint64_t n_cand;
+  uint32_t* cand_edge; /* candidate edges, ascending = the reference's edge order */
+  uint64_t n_inc;      /* live edges incident to a candidate's end point */
+  uint32_t* inc_edge;
+  uint32_t* inc_u;
+  uint32_t* inc_v;
+  uint32_t* inc_w;
+} nts_bubbles;
+typedef struct
+{
+  uint64_t n_blocks;
+  uint32_t* first_vid;
+  uint32_t* last_vid;
+  uint32_t* n_mx;
+  uint32_t* rec;       /* [n_asm * n_blocks] */
+  uint64_t* first_pos;
+  uint64_t* last_pos;
+  uint8_t* ori;
+  uint64_t stats_paths, stats_unoriented, stats_indel_cuts, stats_small;
+} nts_blocks;
+int nts_engine_create(nts_ctx* ctx, uint32_t n_asm, uint32_t ref_asm, nts_engine** out);
+void nts_engine_free(nts_ctx* ctx, nts_engine* eng);
+int nts_engine_size(const nts_engine* eng, uint64_t* nv, uint64_t* ne);
+int nts_engine_add(nts_ctx* ctx, nts_engine* eng, const nts_mx* const* lists, const nts_spans* spans, uint64_t* nv, uint64_t* ne);
+int nts_engine_bubbles(nts_ctx* ctx, nts_engine* eng, nts_bubbles* out);
+void nts_bubbles_free(nts_bubbles* b);
+int nts_engine_apply(nts_ctx* ctx, nts_engine* eng, const uint32_t* dead_vertices, uint64_t n_dead, const uint32_t* promote_edges,
+                     uint64_t n_promote, uint32_t weight);
+int nts_engine_filter(nts_ctx* ctx, nts_engine* eng, uint32_t min_weight, int flag, uint64_t* n_light);
+int nts_engine_erode(nts_ctx* ctx, nts_engine* eng, uint32_t k, uint64_t* n_dead_edges);
+int nts_engine_blocks(nts_ctx* ctx, nts_engine* eng, int64_t bp, double m_percent, uint32_t min_mx, nts_blocks* out);
+void nts_blocks_free(nts_blocks* b);
+int nts_engine_paths(const nts_engine* eng, uint64_t* n_paths, uint64_t* n_verts);
+int nts_engine_read(nts_ctx* ctx, const nts_engine* eng, const char* field, void* dst, uint64_t bytes);
 
 /* Host-side helper (no GPU work): connected components of an undirected graph given as edge arrays
  * that are simple paths (two degree-1 ends, everything else degree 2, at least 2 vertices) -- what

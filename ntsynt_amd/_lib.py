@@ -36,6 +36,21 @@ class Graph(ctypes.Structure):
                 ("ne", u64), ("e_u", c_u32p), ("e_v", c_u32p), ("e_w", c_u32p), ("e_first", c_u64p)]
 
 
+class Spans(ctypes.Structure):
+    _fields_ = [("start", c_vp), ("end_max", c_vp), ("n", u64)]
+
+
+class Bubbles(ctypes.Structure):
+    _fields_ = [("n_cand", u64), ("cand_edge", c_u32p), ("n_inc", u64), ("inc_edge", c_u32p), ("inc_u", c_u32p),
+                ("inc_v", c_u32p), ("inc_w", c_u32p)]
+
+
+class Blocks(ctypes.Structure):
+    _fields_ = [("n_blocks", u64), ("first_vid", c_u32p), ("last_vid", c_u32p), ("n_mx", c_u32p), ("rec", c_u32p),
+                ("first_pos", c_u64p), ("last_pos", c_u64p), ("ori", c_u8p), ("stats_paths", u64), ("stats_unoriented", u64),
+                ("stats_indel_cuts", u64), ("stats_small", u64)]
+
+
 # every symbol include/ntsynt_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("nts_init", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_vp)]),
@@ -93,9 +108,23 @@ SYMBOLS = [
     ("nts_mx_download", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("nts_mx_device_ptrs", ctypes.c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                                           ctypes.POINTER(c_vp)]),
+    ("nts_mx_split", ctypes.c_int, [c_vp, c_vp, u32, c_u32p, ctypes.POINTER(c_vp)]),
     ("nts_mx_upload", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, u64, ctypes.POINTER(c_vp)]),
     ("nts_hash_all", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_u64p), c_u64p]),
     ("nts_graph_build", ctypes.c_int, [c_vp, u32, ctypes.POINTER(MxList), ctypes.POINTER(Graph)]),
+    ("nts_engine_create", ctypes.c_int, [c_vp, u32, u32, ctypes.POINTER(c_vp)]),
+    ("nts_engine_free", None, [c_vp, c_vp]),
+    ("nts_engine_size", ctypes.c_int, [c_vp, c_u64p, c_u64p]),
+    ("nts_engine_add", ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(Spans), c_u64p, c_u64p]),
+    ("nts_engine_bubbles", ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(Bubbles)]),
+    ("nts_bubbles_free", None, [ctypes.POINTER(Bubbles)]),
+    ("nts_engine_apply", ctypes.c_int, [c_vp, c_vp, c_vp, u64, c_vp, u64, u32]),
+    ("nts_engine_filter", ctypes.c_int, [c_vp, c_vp, u32, ctypes.c_int, c_u64p]),
+    ("nts_engine_erode", ctypes.c_int, [c_vp, c_vp, u32, c_u64p]),
+    ("nts_engine_blocks", ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_double, u32, ctypes.POINTER(Blocks)]),
+    ("nts_blocks_free", None, [ctypes.POINTER(Blocks)]),
+    ("nts_engine_paths", ctypes.c_int, [c_vp, c_u64p, c_u64p]),
+    ("nts_engine_read", ctypes.c_int, [c_vp, c_vp, ctypes.c_char_p, c_vp, u64]),
     ("nts_walk_chains", ctypes.c_int, [u64, u64, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_u32p), c_u64p]),
     ("nts_walk_paths", ctypes.c_int, [u64, u64, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_i64p), c_u64p]),
     ("nts_edge_degrees", ctypes.c_int, [u64, u64, c_vp, c_vp, c_vp, c_vp]),

@@ -3136,6 +3136,8 @@ extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* l
   return NTS_OK;
 }
 
+#include "nts_dgraph.inc"
+
 extern "C" void nts_graph_free(nts_graph* g)
 {
   if (!g) return;

@@ -365,6 +365,15 @@ class Minimizers:
                                         ctypes.byref(h)), "nts_mx_upload")
         return cls(ctx, h)
 
+    def split(self, rec_base):
+        """The list of a Genome.concat() batch taken apart on the device (nts_mx_split): one Minimizers per part, record ids
+        local to the part; rec_base = Genome.rec_base of the batch."""
+        n = len(rec_base) - 1
+        base = (ctypes.c_uint32 * (n + 1))(*[int(x) for x in rec_base])
+        out = (c_vp * n)()
+        self.ctx.check(self.ctx.lib.nts_mx_split(self.ctx.h, self.h, n, base, out), "nts_mx_split")
+        return [Minimizers(self.ctx, c_vp(out[p])) for p in range(n)]
+
     def device_ptrs(self):
         a, b, c = c_vp(), c_vp(), c_vp()
         self.ctx.lib.nts_mx_device_ptrs(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))

@@ -182,6 +182,38 @@ class GpuBackend:
         mx.free()
         return batch.split_minimizers(*out)
 
+    def sketch_dev(self, genomes, k, w, bf, masks=None):
+        """sketch_batch with the lists left in HBM: [Minimizers] (one per genome) for the device-resident graph stage; a
+        batch genome's list is taken apart on the device (nts_mx_split)."""
+        from .device import Genome, sketch
+        if len(genomes) < 2 or max(g.total_bp for g in genomes) >= self.BATCH_BELOW_BP:
+            return [sketch(self.ctx, g, k, w, bf, masks[i] if masks else None) for i, g in enumerate(genomes)]
+        key = tuple(id(g) for g in genomes)
+        if self._batch is None or self._batch[0] != key:
+            if self._batch is not None:
+                self._batch[1].free()
+            self._batch = (key, Genome.concat(self.ctx, genomes))
+        batch = self._batch[1]
+        joined = None
+        if masks:
+            joined = [(int(r) + int(batch.rec_base[i]), s, e) for i, m in enumerate(masks) for r, s, e in (m or [])]
+        mx = sketch(self.ctx, batch, k, w, bf, joined)
+        parts = mx.split(batch.rec_base)
+        mx.free()
+        return parts
+
+    def exchange_dev(self, local, n_total):
+        "exchange 2 on device handles: {genome index: Minimizers} of this rank -> [Minimizers of every genome], all in HBM"
+        from .device import Minimizers
+        ids = sorted(local)
+        if not self.host_comm:
+            return self.comm.allgather_minimizers([local[i] for i in ids], ids, n_total)
+        import torch.distributed as dist               # verification mode: through host objects
+        box = [None] * dist.get_world_size()
+        dist.all_gather_object(box, {i: local[i].to_numpy() for i in ids})
+        merged = {i: v for part in box for i, v in part.items()}
+        return [Minimizers.from_numpy(self.ctx, *merged[i]) for i in range(n_total)]
+
     def graph(self, lists, keeps, list_ids):
         from .graph import build_graph_device
         return build_graph_device(self.ctx, lists, keeps, list_ids)
@@ -350,54 +382,91 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
         st.stop()
 
-    st.start("indexlr")
+    # Graph stage: resident in HBM (ntsynt_amd/synteny_device.py) on the GPU backend; NTS_ENGINE=host selects the
+    # host-array twin (ntsynt_amd/synteny.py), which test doubles without a GPU use as well.
+    device_engine = isinstance(backend, GpuBackend) and os.environ.get("NTS_ENGINE", "device") != "host"
     tsv_names = [f"{fa.basename(p)}.k{k}.w{w}.tsv" for p in fastas]
-    if world == 1 and hasattr(backend, "sketch_batch"):
-        initial = backend.sketch_batch([genomes[p] for p in fastas], k, w, bf)
-    else:
-        local = {i: backend.sketch(genomes[p], k, w, bf) for i, p in enumerate(fastas) if owner[p] == rank}
-        initial = _exchange_lists(backend, local, len(fastas)) if world > 1 else [local[i] for i in range(len(fastas))]
-    if write_mx_tsv:
-        for i, p in enumerate(fastas):
-            if owner[p] == rank:
-                out = initial[i]
-                pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], genomes[p].recs, out[0], out[1], out[2], k,
-                                                    mx_with_seq))
-    st.stop()
-    if bf is not None and rank == 0:
-        # filter file: device -> host copy on the library's copy stream + write, on a writer thread, started once the
-        # whole-genome sketches are out of the way (their small read-backs would queue behind the bulk copy)
-        pending_files.append(writers.submit(lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k, signature=bf_signature)))
-
-    st.start("ntsynt_synteny")
-
-    def sketch_fn(i, masks, new_w):
-        return sketch_round({i: masks}, new_w)[i]
-
-    def sketch_round(masks_by_asm, new_w):
-        "re-sketch of a refinement round for the assemblies given: each owner sketches its own, one exchange hands them round"
-        if world == 1 and hasattr(backend, "sketch_batch") and len(masks_by_asm) == len(fastas):
-            got = backend.sketch_batch([genomes[p] for p in fastas], k, new_w, bf, [masks_by_asm[i] for i in range(len(fastas))])
-            return dict(enumerate(got))
-        local = {i: backend.sketch(genomes[fastas[i]], k, new_w, bf, m) for i, m in masks_by_asm.items() if owner[fastas[i]] == rank}
-        if world == 1:
-            return local
-        ids = sorted(masks_by_asm)
-        # (the exchange numbers lists 0..n-1: positions in `ids`)
-        got = _exchange_lists(backend, {ids.index(i): v for i, v in local.items()}, len(ids))
-        return {i: got[j] for j, i in enumerate(ids)}
-    sketch_fn.all_at_once = sketch_round
-
     if rank != 0:                       # replicas compute, only rank 0 leaves files behind
         scratch = os.path.join(os.getcwd(), f".ntsynt_rank{rank}")
         os.makedirs(scratch, exist_ok=True)
         out_prefix = os.path.join(scratch, os.path.basename(prefix))
     else:
         out_prefix = prefix
-    eng = SyntenyEngine(tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size, out_prefix,
-                        backend.graph, sketch_fn, backend.walk, simplify=simplify, log=log, degree_fn=edge_degrees)
+
+    def write_bf_later():
+        if bf is not None and rank == 0:
+            # filter file: device -> host copy on the library's copy stream + write, on a writer thread, started once the
+            # whole-genome sketches are out of the way (their small read-backs would queue behind the bulk copy)
+            pending_files.append(writers.submit(lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k, signature=bf_signature)))
+
+    if device_engine:
+        from .synteny_device import DeviceSyntenyEngine
+        mine_idx = [i for i, p in enumerate(fastas) if owner[p] == rank]
+
+        def sketch_dev_round(masks_by_asm, new_w):
+            "device lists of all assemblies: every rank sketches its own genomes (one batch when they are small), one all-gather"
+            ml = [masks_by_asm[i] for i in mine_idx] if masks_by_asm is not None else None
+            got = backend.sketch_dev([genomes[fastas[i]] for i in mine_idx], k, new_w, bf, ml)
+            local = dict(zip(mine_idx, got))
+            if world == 1:
+                return local
+            everything = backend.exchange_dev(local, len(fastas))
+            for m in got:
+                m.free()
+            return dict(enumerate(everything))
+
+        st.start("indexlr")
+        initial_dev = sketch_dev_round(None, w)
+        if write_mx_tsv:
+            for i in mine_idx:
+                out = initial_dev[i].to_numpy()
+                pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], genomes[fastas[i]].recs, out[0], out[1], out[2], k,
+                                                    mx_with_seq))
+        st.stop()
+        write_bf_later()
+        st.start("ntsynt_synteny")
+        eng = DeviceSyntenyEngine(backend.ctx, tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size,
+                                  out_prefix, sketch_dev_round, simplify=simplify, log=log)
+        first = [initial_dev[i] for i in range(len(fastas))]
+    else:
+        st.start("indexlr")
+        if world == 1 and hasattr(backend, "sketch_batch"):
+            initial = backend.sketch_batch([genomes[p] for p in fastas], k, w, bf)
+        else:
+            local = {i: backend.sketch(genomes[p], k, w, bf) for i, p in enumerate(fastas) if owner[p] == rank}
+            initial = _exchange_lists(backend, local, len(fastas)) if world > 1 else [local[i] for i in range(len(fastas))]
+        if write_mx_tsv:
+            for i, p in enumerate(fastas):
+                if owner[p] == rank:
+                    out = initial[i]
+                    pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], genomes[p].recs, out[0], out[1], out[2], k,
+                                                        mx_with_seq))
+        st.stop()
+        write_bf_later()
+        st.start("ntsynt_synteny")
+
+        def sketch_fn(i, masks, new_w):
+            return sketch_round({i: masks}, new_w)[i]
+
+        def sketch_round(masks_by_asm, new_w):
+            "re-sketch of a refinement round for the assemblies given: each owner sketches its own, one exchange hands them round"
+            if world == 1 and hasattr(backend, "sketch_batch") and len(masks_by_asm) == len(fastas):
+                got = backend.sketch_batch([genomes[p] for p in fastas], k, new_w, bf, [masks_by_asm[i] for i in range(len(fastas))])
+                return dict(enumerate(got))
+            local = {i: backend.sketch(genomes[fastas[i]], k, new_w, bf, m) for i, m in masks_by_asm.items() if owner[fastas[i]] == rank}
+            if world == 1:
+                return local
+            ids = sorted(masks_by_asm)
+            # (the exchange numbers lists 0..n-1: positions in `ids`)
+            got = _exchange_lists(backend, {ids.index(i): v for i, v in local.items()}, len(ids))
+            return {i: got[j] for j, i in enumerate(ids)}
+        sketch_fn.all_at_once = sketch_round
+
+        eng = SyntenyEngine(tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size, out_prefix,
+                            backend.graph, sketch_fn, backend.walk, simplify=simplify, log=log, degree_fn=edge_degrees)
+        first = initial
     try:
-        eng.run(initial)
+        eng.run(first)
     except BaseException:
         # a run that dies after its first round must not leave a plausible-looking block table behind
         for name in (f"{out_prefix}.synteny_blocks.tsv", f"{out_prefix}.pre-collinear-merge.synteny_blocks.tsv"):

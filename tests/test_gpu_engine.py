@@ -1,0 +1,216 @@
+"""The graph stage resident in HBM (ntsynt_amd/synteny_device.py over nts_engine_*, csrc/nts_dgraph.inc) against its
+host-array twin (ntsynt_amd/synteny.py), state by state, on the same minimizer lists -- vertex tables, edge arrays in
+the reference's order, liveness after every rule, the path order of the list ranking, block tables, the marks the next
+refinement round filters by -- and both against the oracle pipeline's bytes."""
+import os
+
+import numpy as np
+import pytest
+
+from ntsynt_amd import synth
+from oracle import nts_oracle as O
+from oracle import synteny_oracle as SO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ntsynt_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _state_equal(host, dev, what):
+    g = dev.graph
+    nv, ne = g.size()
+    assert nv == host.v_hash.size and ne == host.e_u.size, (what, nv, host.v_hash.size, ne, host.e_u.size)
+    assert np.array_equal(g.read("v_hash"), host.v_hash), what
+    assert np.array_equal(g.read("v_alive").astype(bool), host.v_alive), what
+    # tables of dead vertices are never read again; compare the live ones
+    live = host.v_alive
+    assert np.array_equal(g.read("v_rec").astype(np.int64)[:, live], host.v_rec[:, live]), what
+    assert np.array_equal(g.read("v_pos").astype(np.int64)[:, live], host.v_pos[:, live]), what
+    assert np.array_equal(g.read("e_u").astype(np.int64), host.e_u), what
+    assert np.array_equal(g.read("e_v").astype(np.int64), host.e_v), what
+    assert np.array_equal(g.read("e_alive").astype(bool), host.e_alive), what
+    alive = host.e_alive
+    assert np.array_equal(g.read("e_w").astype(np.int64)[alive], host.e_w[alive]), what
+
+
+def _blocks_equal(host, hb, dev, db, what):
+    host._finish_all(hb)
+    a = sorted((tuple(b.rec), tuple(b.ori), tuple(b.first_pos), tuple(b.last_pos), b.n_mx) for b in hb)
+    b = sorted((tuple(x.rec), tuple(x.ori), tuple(x.first_pos), tuple(x.last_pos), x.n_mx) for x in db)
+    assert a == b, what
+    # the marks the next refinement round filters by
+    term = np.zeros(host.v_hash.size, bool)
+    inner = np.zeros(host.v_hash.size, bool)
+    for blk in hb:
+        term[blk.vids[0]] = term[blk.vids[-1]] = True
+        inner[blk.vids[1:-1]] = True
+    assert np.array_equal(dev.graph.read("terminal").astype(bool), term), what
+    assert np.array_equal(dev.graph.read("internal").astype(bool), inner), what
+
+
+def _round_blocks_both(host, dev, what):
+    """One round's paths and blocks on both engines: the host walk and the device's list ranking see the same graph; the
+    path order is compared as a set of oriented paths, then the block rules' outcome."""
+    verts, off = host._paths()
+    want = sorted(tuple(verts[off[i]:off[i + 1]].tolist()) for i in range(off.size - 1))
+    db = dev._blocks()
+    pv, po = dev.graph.read("path_verts"), dev.graph.read("path_off")
+    got = sorted(tuple(pv[int(po[i]):int(po[i + 1])].tolist()) for i in range(po.size - 1))
+    assert got == want, what + ": paths"
+    hb = host._drop_small(host._blocks_of_paths((verts, off)), 4)
+    _state_equal(host, dev, what)
+    _blocks_equal(host, hb, dev, db, what)
+    return hb, db
+
+
+CASES = [
+    # (n_genomes, total_bp, contigs, divergence, seed, k, w, w_rounds, indel, merge, block, micro, n_runs)
+    (3, 3_000_000, 3, 0.01, 21, 24, 1000, [100, 10], 500, 3000, 500, 0, True),
+    (2, 2_000_000, 2, 0.005, 9, 24, 200, [50, 10], 5000, 20000, 300, 12, False),
+    (4, 1_600_000, 2, 0.02, 33, 20, 500, [250, 100], 50000, "100w", 1000, 6, True),
+    (3, 2_400_000, 40, 0.01, 5, 24, 150, [40, 10], 300, "40w", 200, 20, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_device_engine_in_lockstep_with_host_engine(ctx, tmp_path, case):
+    from ntsynt_amd import fasta as fa
+    from ntsynt_amd.device import BloomFilter, Genome, Minimizers, bf_size_bytes, sketch
+    from ntsynt_amd.graph import build_graph_device, edge_degrees, walk_paths
+    from ntsynt_amd.synteny import SyntenyEngine
+    from ntsynt_amd.synteny_device import DeviceSyntenyEngine
+    n, bp_total, ctg, div, seed, k, w, rounds, indel, merge, block, micro, n_runs = case
+    paths = synth.make_family(str(tmp_path), n, bp_total, ctg, div, seed=seed, micro=micro, n_runs=n_runs)
+    recs = [fa.read_fasta(p) for p in paths]
+    genomes = [Genome(ctx, r.names, r.seq, r.rec_off, r.rec_len) for r in recs]
+    _, nbytes = bf_size_bytes(genomes[sorted(range(n), key=lambda i: paths[i])[0]].total_bp, 0.025)
+    bf = BloomFilter(ctx, nbytes, k)
+    tmp = BloomFilter(ctx, nbytes, k)
+    for j, g in enumerate(genomes):
+        if j == 0:
+            bf.insert(g)
+        else:
+            tmp.clear()
+            tmp.insert(g)
+            bf.and_(tmp)
+    tmp.free()
+    tsvs = [f"{os.path.basename(p)}.k{k}.w{w}.tsv" for p in paths]
+    names = [r.names for r in recs]
+
+    def sketch_np(i, masks, new_w):
+        mx = sketch(ctx, genomes[i], k, new_w, bf, masks)
+        out = mx.to_numpy()
+        mx.free()
+        return out
+
+    def sketch_dev(masks_by_asm, new_w):
+        return {i: sketch(ctx, genomes[i], k, new_w, bf, m) for i, m in masks_by_asm.items()}
+
+    cwd = os.getcwd()
+    os.makedirs(tmp_path / "h")
+    os.makedirs(tmp_path / "d")
+    try:
+        os.chdir(tmp_path / "h")
+        host = SyntenyEngine(tsvs, names, k, w, rounds, indel, merge, block, "p", lambda ls, kp, li: build_graph_device(ctx, ls, kp, li),
+                             sketch_np, walk_paths, degree_fn=edge_degrees)
+        os.chdir(tmp_path / "d")
+        dev = DeviceSyntenyEngine(ctx, tsvs, names, k, w, rounds, indel, merge, block, "p", sketch_dev)
+        assert host.input_order == dev.input_order
+        initial = [sketch_np(i, None, w) for i in range(n)]
+        # ---- initial round
+        host._add_graph(host.graph_fn([initial[i] for i in host.input_order], None, None))
+        handles = [Minimizers.from_numpy(ctx, *initial[i]) for i in dev.input_order]
+        dev._add(handles, None)
+        for h in handles:
+            h.free()
+        _state_equal(host, dev, "initial add")
+        host._simplify(apply_deletions=True)
+        dev._simplify_dev(apply_deletions=True)
+        assert host.stats["bubbles"] == dev.stats["bubbles"]
+        _state_equal(host, dev, "initial simplify")
+        host.e_alive &= host.e_w >= host.n
+        dev._filter(flag=False)
+        _state_equal(host, dev, "initial filter")
+        hb, db = _round_blocks_both(host, dev, "initial blocks")
+        prev_w = w
+        for new_w in rounds:
+            assert [sorted(m) for m in host._mask_intervals(hb, prev_w)] == [sorted(m) for m in dev._mask_intervals(db, prev_w)]
+            host._new_round_graph(hb, new_w, prev_w)
+            masks = dev._mask_intervals(db, prev_w)
+            lists = dev._sketch_round(masks, new_w)
+            dev._add(lists, dev._spans(db))
+            for mx in lists:
+                mx.free()
+            _state_equal(host, dev, f"add w={new_w}")
+            host._simplify(apply_deletions=False)
+            dev._simplify_dev(apply_deletions=False)
+            _state_equal(host, dev, f"simplify w={new_w}")
+            last = new_w == rounds[-1]
+            light = host.e_alive & (host.e_w < host.n)
+            flagged = (host.e_u[light], host.e_v[light])
+            host.e_alive &= ~light
+            dev._filter(flag=last)
+            _state_equal(host, dev, f"filter w={new_w}")
+            if last:
+                host._refine_graph(flagged)
+                dev._erode()
+                assert host.stats["eroded_edges"] == dev.stats["eroded_edges"]
+                _state_equal(host, dev, "erosion")
+            hb, db = _round_blocks_both(host, dev, f"blocks w={new_w}")
+            prev_w = new_w
+        for key in ("bubbles", "unoriented", "indel_cuts", "small_blocks", "eroded_edges"):
+            assert host.stats[key] == dev.stats[key], key
+    finally:
+        os.chdir(cwd)
+        for g in genomes:
+            g.free()
+        bf.free()
+
+
+@pytest.mark.parametrize("engine", ["device", "host"])
+def test_both_engines_through_the_pipeline_match_the_oracle(tmp_path, monkeypatch, engine):
+    from ntsynt_amd import pipeline
+    monkeypatch.setenv("NTS_ENGINE", engine)
+    paths = synth.make_family(str(tmp_path), 3, 2_500_000, 30, 0.01, seed=12, micro=15, n_runs=True, soft_mask=True)
+    kw = dict(k=24, w=300, w_rounds=[100, 20], indel=400, merge="10w", block_size=300)
+    cwd = os.getcwd()
+    try:
+        os.makedirs(tmp_path / "hip")
+        os.makedirs(tmp_path / "ora")
+        os.chdir(tmp_path / "hip")
+        eng = pipeline.run(paths, prefix="p", log=lambda *a: None, **kw)
+        os.chdir(tmp_path / "ora")
+        ora = SO.run_pipeline(paths, prefix="p", **kw)
+    finally:
+        os.chdir(cwd)
+    assert type(eng).__name__ == ("DeviceSyntenyEngine" if engine == "device" else "SyntenyEngine")
+    for name in ("p.synteny_blocks.tsv", "p.pre-collinear-merge.synteny_blocks.tsv"):
+        assert eng.outputs[name] == ora.outputs[name], name
+    assert len(eng.outputs["p.synteny_blocks.tsv"].splitlines()) > 30
+    for p in paths:
+        tsv = f"{os.path.basename(p)}.k24.w300.tsv"
+        assert open(tmp_path / "hip" / tsv).read() == open(tmp_path / "ora" / tsv).read()
+
+
+def test_mx_split_matches_host_split(ctx):
+    from ntsynt_amd.device import Genome, sketch
+    parts = [Genome.synth(ctx, 3_000_000 + 1000 * j, 3 + j, 5, 60 + j, 0.01) for j in range(3)]
+    batch = Genome.concat(ctx, parts)
+    mx = sketch(ctx, batch, 24, 200)
+    want = batch.split_minimizers(*mx.to_numpy())
+    got = mx.split(batch.rec_base)
+    assert len(got) == 3
+    for a, b in zip(got, want):
+        for x, y in zip(a.to_numpy(), b):
+            assert np.array_equal(x, y)
+        a.free()
+    mx.free()
+    batch.free()
+    for g in parts:
+        g.free()
