@@ -132,6 +132,10 @@ int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other);
 int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set);
 int nts_bf_download(nts_ctx* ctx, const nts_bf* bf, uint8_t* host, uint64_t bytes);
 int nts_bf_upload(nts_ctx* ctx, nts_bf* bf, const uint8_t* host, uint64_t bytes);
+/* bf->save(path) (cpp:164) straight out of HBM: `header` (the caller's btllib-style text header), then the bit array, written
+ * through a shared file mapping by n_threads host threads (0 = default) with pinned staging -- no host copy of the filter.
+ * Like nts_bf_download it sees everything queued before the call and may run on a second host thread. */
+int nts_bf_save(nts_ctx* ctx, const nts_bf* bf, const char* path, const void* header, uint64_t header_bytes, uint32_t n_threads);
 /* Microbenchmark: n_probes pseudo-random single-bit reads of the filter with the access shape of the sketch's
  * probe batches and no hashing -- the empirical ceiling for sector-granular random reads on this GPU. */
 int nts_bench_random_probe(nts_ctx* ctx, const nts_bf* bf, uint64_t n_probes, uint32_t repeats, double* avg_ms, uint64_t* hits);
@@ -203,6 +207,12 @@ int nts_sketch(nts_ctx* ctx,
  * (ntsynt_amd/csrc/nts_pruned.inc).  prune_c = 0: c is chosen per call from the filter's occupancy
  * (c = 12 / accepted share, at least 8); otherwise c = prune_c. */
 int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c);
+/* Dense sketch over a sparse filter (many divergent genomes: nearly no k-mer is common to all): when occupancy x 2^shift is
+ * small, a summary of the filter with one bit per 2^shift filter bits (<= 1 MiB, L2-resident; built once per filter state) is
+ * consulted first and only a set summary bit leads to a read of the filter; key tiles without an accepted k-mer are skipped
+ * by the window kernel.  Identical output.  mode 0 = auto (default), 1 = never, -1 = leave as is; last_shift = the shift the
+ * last nts_sketch call used (0: it did not use a summary). */
+int nts_sketch_summary(nts_ctx* ctx, int mode, uint32_t* last_shift);
 /* of the last nts_sketch call: accepted candidates, uncovered ranges handed to the dense kernels, the number of
  * k-mers in them, and the c that was used (all 0 for a dense-mode call) */
 int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers, uint32_t* prune_c_used);

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("nts_bf_popcount", ctypes.c_int, [c_vp, c_vp, c_u64p]),
     ("nts_bf_download", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
     ("nts_bf_upload", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
+    ("nts_bf_save", ctypes.c_int, [c_vp, c_vp, ctypes.c_char_p, c_vp, u64, u32]),
     ("nts_bench_random_probe", ctypes.c_int, [c_vp, c_vp, u64, u32, ctypes.POINTER(ctypes.c_double), c_u64p]),
     ("nts_bench_valu", ctypes.c_int, [c_vp, ctypes.c_int, u32, u32, ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
@@ -102,6 +103,7 @@ SYMBOLS = [
     ("nts_sketch", ctypes.c_int, [c_vp, c_vp, u32, u32, c_vp, ctypes.POINTER(Interval), u64,
                                   ctypes.POINTER(c_vp)]),
     ("nts_sketch_mode", ctypes.c_int, [c_vp, ctypes.c_int, u32]),
+    ("nts_sketch_summary", ctypes.c_int, [c_vp, ctypes.c_int, c_u32p]),
     ("nts_sketch_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u64p, c_u32p]),
     ("nts_mx_count", u64, [c_vp]),
     ("nts_mx_free", None, [c_vp, c_vp]),

@@ -13,6 +13,11 @@
 //   bloom    : bit idx = h0 % bits at byte idx/8, bit idx%8 (LSB first).
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <thread>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -83,6 +88,12 @@ struct nts_ctx
   uint32_t prune_c = 0; // 0 = adaptive (from the filter's occupancy), else fixed
   uint32_t last_c = 0;
   uint64_t last_candidates = 0, last_gaps = 0, last_gap_kmers = 0;
+  // dense sketch over a sparse filter: summary consulted before the filter, key tiles without an accepted k-mer skipped
+  const uint32_t* cur_summary = nullptr;
+  uint32_t cur_summary_shift = 0;
+  uint32_t* cur_tile_any = nullptr;
+  int summary_mode = 0; // 0 auto, 1 never (tests)
+  uint32_t last_summary = 0;
 };
 
 struct nts_genome
@@ -110,6 +121,14 @@ struct nts_bf
   uint32_t* d_words = nullptr;
   bool owned = true;
   mutable int64_t popcnt = -1; // cached number of set bits, -1 = unknown (any write invalidates it)
+  uint64_t version = 0;        // bumped by every write through the library
+  // summary of a sparse filter (built on demand by the dense sketch): bit g = "some bit of filter bits [g << shift, (g+1) << shift)
+  // is set"; small enough to stay in the L2, so that a probe of an all-but-empty filter ends there (nts_sketch)
+  mutable uint32_t* d_summary = nullptr;
+  mutable uint64_t summary_words = 0;
+  mutable uint32_t summary_shift = 0;
+  mutable uint64_t summary_version = ~0ULL;
+  mutable double summary_density = 1.0;
 };
 
 struct nts_mx
@@ -482,6 +501,175 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
   }
 }
 
+// ---- dense sketch over a sparse filter ------------------------------------------------------------------------------
+// When the common filter is all but empty (many divergent genomes: BASELINE's 8 x 3 Gbp at 10 % leaves 3e-6 of the bits),
+// almost every probe of the every-k-mer-probed path fetches a 128-byte line of zeros from HBM.  A summary with one bit per
+// 2^shift filter bits (<= 1 MiB, resident in the L2) answers those probes; only where the summary bit is set is the filter
+// itself read.  Same keys as k_hash<MODE_KEYS> bit for bit; key tiles without a single accepted k-mer are not written at all
+// and flagged in tile_any, so that the window kernel skips them.
+__global__ __launch_bounds__(256) void k_bf_summary(const uint4* __restrict__ words, uint64_t n16, uint32_t shift, uint32_t* __restrict__ summary)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 v = words[i];
+    if (v.x | v.y | v.z | v.w) {
+      const uint64_t g = (i * 128u) >> shift; // shift >= 7: the 128 bits of a word share one granule
+      atomicOr(&summary[g >> 5], 1u << (g & 31u));
+    }
+  }
+}
+
+__global__ __launch_bounds__(HASH_THREADS) void k_hash_keys_sparse(const uint8_t* __restrict__ code, const uint64_t* __restrict__ run_pos,
+                                                                   const uint64_t* __restrict__ run_vstart, uint32_t n_runs, uint64_t n_valid,
+                                                                   HashParams hp, const uint32_t* __restrict__ bf_in, FastMod fm,
+                                                                   const uint32_t* __restrict__ summary, uint32_t shift,
+                                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ tile_any)
+{
+  __shared__ uint64_t s_tab[36];
+  __shared__ uint32_t s_seq[SEQ_LDS_DWORDS];
+  const uint32_t tid = threadIdx.x;
+  if (tid < 16) {
+    s_tab[tid] = hp.roll_f[tid];
+    s_tab[16 + tid] = hp.roll_r[tid];
+  }
+  if (tid < 4) s_tab[32 + tid] = hp.seed[tid];
+  const uint32_t k = hp.k;
+  const uint64_t J0 = (uint64_t)blockIdx.x * KEY_TILE;
+  const uint32_t tile_len = (uint32_t)min((uint64_t)KEY_TILE, n_valid - J0);
+  uint32_t lo = 0, hi = n_runs;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (run_vstart[mid] <= J0)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const uint64_t v0 = run_vstart[lo], v1 = run_vstart[lo + 1];
+  const bool single = (J0 + tile_len <= v1) && (k <= FAST_K_MAX);
+  auto accepted = [&](uint64_t h) -> bool {
+    const uint64_t idx = fm(h);
+    const uint64_t g = idx >> shift;
+    if (!((summary[g >> 5] >> (g & 31u)) & 1u)) return false;
+    return (bf_in[idx >> 5] >> ((uint32_t)idx & 31u)) & 1u;
+  };
+  if (single) {
+    const uint64_t P0 = run_pos[lo] + (J0 - v0);
+    const uint32_t a = (uint32_t)(P0 & 15u);
+    const uint8_t* src = code + (P0 - a);
+    const uint32_t n_bytes = a + tile_len + k - 1;
+    const uint32_t n16 = (n_bytes + 15u) >> 4;
+    for (uint32_t c = tid; c < n16; c += HASH_THREADS) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + 16u * c);
+      const uint32_t d = 4u * c + (c >> 1);
+      s_seq[d] = v.x;
+      s_seq[d + 1] = v.y;
+      s_seq[d + 2] = v.z;
+      s_seq[d + 3] = v.w;
+    }
+    __syncthreads();
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_seq);
+    auto base_at = [&](uint32_t s) -> uint32_t { return sb[s + 4u * (s >> 5)] & 3u; };
+    const uint32_t first = 32u * tid;
+    const uint32_t n_mine = first < tile_len ? min(32u, tile_len - first) : 0u;
+    uint32_t s = a + first;
+    uint64_t f = 0, r = 0;
+    if (n_mine) hash_init(hp, [&](uint32_t i) { return base_at(s + i); }, f, r);
+    uint32_t acc_mask = 0;
+    uint64_t acc_h[4]; // the lane's first accepted hashes (accepted k-mers are rare here); more: recomputed below
+    uint32_t n_acc = 0;
+#pragma unroll 1
+    for (uint32_t b0 = 0; b0 < 32; b0 += 8) {
+      uint64_t h[8], idx[8];
+      uint32_t sw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        h[u] = f + r;
+        const uint32_t cout = base_at(s), cin = base_at(s + k);
+        f = srol1(f) ^ s_tab[cin * 4 + cout];
+        r = sror1(r ^ s_tab[16 + cin * 4 + cout]);
+        ++s;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        idx[u] = fm(h[u]);
+        sw[u] = summary[idx[u] >> (shift + 5)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (b0 + u < n_mine && ((sw[u] >> ((idx[u] >> shift) & 31u)) & 1u)) {
+          if ((bf_in[idx[u] >> 5] >> ((uint32_t)idx[u] & 31u)) & 1u) {
+            acc_mask |= 1u << (b0 + u);
+            if (n_acc < 4) acc_h[n_acc] = h[u];
+            ++n_acc;
+          }
+        }
+      }
+    }
+    const int any = __syncthreads_or(acc_mask != 0);
+    if (tid == 0) tile_any[blockIdx.x] = any ? 1u : 0u;
+    if (!any) return;
+    // (rare) the tile holds accepted k-mers: all of its keys are written
+    uint64_t* out = keys + J0 + tid;
+    if (n_acc <= 4) {
+      uint32_t q = 0;
+      for (uint32_t u = 0; u < n_mine; ++u) {
+        uint64_t key = KEY_MAX;
+        if ((acc_mask >> u) & 1u) key = acc_h[q++];
+        out[(uint64_t)u * 256u] = key;
+      }
+    } else {
+      // more accepted k-mers in one lane than were kept: hash the lane's k-mers once more
+      uint32_t s2 = a + first;
+      uint64_t f2 = 0, r2 = 0;
+      hash_init(hp, [&](uint32_t i) { return base_at(s2 + i); }, f2, r2);
+      for (uint32_t u = 0; u < n_mine; ++u) {
+        out[(uint64_t)u * 256u] = ((acc_mask >> u) & 1u) ? f2 + r2 : KEY_MAX;
+        const uint32_t cout = base_at(s2), cin = base_at(s2 + k);
+        f2 = srol1(f2) ^ s_tab[cin * 4 + cout];
+        r2 = sror1(r2 ^ s_tab[16 + cin * 4 + cout]);
+        ++s2;
+      }
+    }
+    return;
+  }
+  // ---- generic path (tile crosses runs): every key written, the tile flagged ---------------------------------------
+  __syncthreads();
+  if (tid == 0) tile_any[blockIdx.x] = 1u;
+  uint64_t j = J0 + 32ull * tid;
+  if (j >= n_valid) return;
+  const uint64_t j_end = min(j + (uint64_t)HASH_PER_THREAD, n_valid);
+  lo = 0;
+  hi = n_runs;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (run_vstart[mid] <= j)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  uint32_t ri = lo;
+  while (j < j_end) {
+    const uint64_t rv0 = run_vstart[ri], rv1 = run_vstart[ri + 1];
+    const uint64_t seg_end = min(j_end, rv1);
+    uint64_t p = run_pos[ri] + (j - rv0);
+    uint64_t f = 0, r = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+      f = srol1(f) ^ s_tab[32 + code[p + i]];
+      r = srol1(r) ^ s_tab[32 + 3 - code[p + k - 1 - i]];
+    }
+    for (;;) {
+      const uint64_t h = f + r;
+      keys[key_phys(j)] = accepted(h) ? h : KEY_MAX;
+      ++j;
+      if (j >= seg_end) break;
+      const uint32_t cout = code[p], cin = code[p + k];
+      f = srol1(f) ^ s_tab[cin * 4 + cout];
+      r = sror1(r ^ s_tab[16 + cin * 4 + cout]);
+      ++p;
+    }
+    ++ri;
+  }
+}
+
 // plain (untransposed) copy of the keys, for the nts_hash_all test hook
 __global__ __launch_bounds__(256) void k_keys_linear(const uint64_t* __restrict__ keys, uint64_t n, uint64_t* __restrict__ out)
 {
@@ -520,6 +708,9 @@ struct WinParams
   // collector sees the count) -- tiles are in index order, so no sort is needed afterwards
   uint32_t* tile_cnt;
   uint32_t tile_cap;
+  // if not null (whole-genome dense pass over a sparse filter): tile_any[t] == 0 <=> key tile t holds no accepted k-mer and
+  // was not written; its keys count as KEY_MAX
+  const uint32_t* tile_any;
 };
 constexpr uint32_t N_SEG = 64;
 
@@ -576,6 +767,13 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
   const uint32_t c = P.chunk;
   const uint32_t n_chunks = (E + c - 1) / c;
 
+  const uint64_t ja = P.rec_vstart[rec] + tf, jb = ja + E;
+  if (P.tile_any != nullptr) {
+    // no accepted k-mer anywhere in the span: no window of this tile has a minimizer
+    bool any = false;
+    for (uint64_t tile = ja / KEY_TILE; tile * KEY_TILE < jb; ++tile) any |= P.tile_any[tile] != 0;
+    if (!any) return;
+  }
   uint64_t* s_key = reinterpret_cast<uint64_t*>(smem);
   uint32_t* s_ctl = reinterpret_cast<uint32_t*>(s_key + pe(E) + 1); // [0] emitted count, [1..2] reserved base
   uint16_t* s_list = reinterpret_cast<uint16_t*>(s_ctl + 4);         // winners of this tile (<= n_win)
@@ -583,9 +781,9 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
   if (threadIdx.x == 0) s_ctl[0] = 0;
 
   // ---- load: walk the key tiles the range [ja, jb) touches, one transposed row at a time -----------
-  const uint64_t ja = P.rec_vstart[rec] + tf, jb = ja + E;
   for (uint64_t tile = ja / KEY_TILE; tile * KEY_TILE < jb; ++tile) {
     const uint64_t tb = tile * KEY_TILE;
+    const bool written = P.tile_any == nullptr || P.tile_any[tile] != 0;
     const uint32_t r_lo = (uint32_t)(max(ja, tb) - tb);
     const uint32_t r_hi = (uint32_t)(min(jb, tb + KEY_TILE) - 1 - tb);
     const uint32_t col_lo = r_lo >> 5, col_hi = r_hi >> 5;
@@ -598,7 +796,7 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
       const int64_t e0 = (int64_t)(tb + 32ull * col) - (int64_t)ja; // element index of row 0
       uint64_t v[ROWS];
 #pragma unroll
-      for (int i = 0; i < ROWS; ++i) v[i] = g[(uint64_t)(row0 + i) * 256u];
+      for (int i = 0; i < ROWS; ++i) v[i] = written ? g[(uint64_t)(row0 + i) * 256u] : KEY_MAX;
 #pragma unroll
       for (int i = 0; i < ROWS; ++i) {
         const int64_t e = e0 + row0 + i;
@@ -1208,6 +1406,13 @@ int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const Genom
   const uint64_t blocks = d_tile_ids ? n_tile_ids : (rt.n_valid + per_block - 1) / per_block;
   if (blocks > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
   ScopedTimer t(ctx, name, true);
+  if (MODE == MODE_KEYS && bf_in && !d_tile_ids && ctx->cur_summary && ctx->cur_tile_any) {
+    hipLaunchKernelGGL(k_hash_keys_sparse, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, T.d_run_pos,
+                       T.d_run_vstart, T.n_runs, rt.n_valid, hp, bf_in->d_words, fm, ctx->cur_summary, ctx->cur_summary_shift, keys,
+                       ctx->cur_tile_any);
+    HIP_TRY(ctx, hipGetLastError());
+    return NTS_OK;
+  }
   hipLaunchKernelGGL(k_hash<MODE>, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, T.d_run_pos,
                      T.d_run_vstart, T.n_runs, rt.n_valid, hp, bf_in ? bf_in->d_words : nullptr, bf_out ? bf_out->d_words : nullptr,
                      fm, keys, d_tile_ids);
@@ -1618,6 +1823,7 @@ int nts_bf_fill_ones(nts_ctx* ctx, nts_bf* bf)
   if (!ctx || !bf) return fail(ctx, NTS_EINVAL, "nts_bf_fill_ones: bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   bf->popcnt = -1;
+  ++bf->version;
   HIP_TRY(ctx, hipMemsetAsync(bf->d_words, 0xFF, bf->bytes, ctx->stream)); // the pad behind `bytes` stays zero
   return NTS_OK;
 }
@@ -1627,6 +1833,7 @@ void nts_bf_free(nts_ctx* ctx, nts_bf* bf)
   if (!bf) return;
   if (ctx) hipSetDevice(ctx->device);
   if (bf->d_words && bf->owned) hipFree(bf->d_words);
+  if (bf->d_summary) hipFree(bf->d_summary);
   delete bf;
 }
 
@@ -1671,6 +1878,7 @@ int nts_bf_clear(nts_ctx* ctx, nts_bf* bf)
 {
   if (!ctx || !bf) return fail(ctx, NTS_EINVAL, "nts_bf_clear: bad arguments");
   bf->popcnt = 0;
+  ++bf->version;
   HIP_TRY(ctx, hipMemsetAsync(bf->d_words, 0, (bf->bytes + 15) / 16 * 16, ctx->stream));
   return NTS_OK;
 }
@@ -1680,6 +1888,7 @@ static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nt
   if (!ctx || !next || !g || k == 0) return fail(ctx, NTS_EINVAL, "bloom pass: bad arguments");
   if (prev && prev->bytes != next->bytes) return fail(ctx, NTS_EINVAL, "bloom pass: filters differ in size");
   next->popcnt = -1;
+  ++next->version;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   GenomeTables scratch;
   const GenomeTables* T = nullptr;
@@ -1718,6 +1927,7 @@ int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other)
 {
   if (!ctx || !acc || !other || acc->bytes != other->bytes) return fail(ctx, NTS_EINVAL, "nts_bf_and: filters differ in size");
   acc->popcnt = -1;
+  ++acc->version;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t n16 = (acc->bytes + 15) / 16;
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
@@ -1848,9 +2058,92 @@ int nts_bf_upload(nts_ctx* ctx, nts_bf* bf, const uint8_t* host, uint64_t bytes)
 {
   if (!ctx || !bf || !host || bytes != bf->bytes) return fail(ctx, NTS_EINVAL, "nts_bf_upload: size mismatch");
   bf->popcnt = -1;
+  ++bf->version;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipMemcpyAsync(bf->d_words, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return NTS_OK;
+}
+
+// bf->save(path) (src/ntsynt_make_common_bf.cpp:164) without a host copy of the filter: `header` first, then the bit array
+// streamed out of HBM by a few host threads, each with its own pinned staging buffer and HIP stream -- a device -> host copy
+// of the next chunk runs while the previous one is copied into the file's mapping.  Sees everything queued on the context's
+// stream before the call; safe to run on a second host thread while the first keeps sketching.
+int nts_bf_save(nts_ctx* ctx, const nts_bf* bf, const char* path, const void* header, uint64_t header_bytes, uint32_t n_threads)
+{
+  if (!ctx || !bf || !path || (header_bytes && !header)) return fail(ctx, NTS_EINVAL, "nts_bf_save: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipEvent_t ready;
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventRecord(ready, ctx->stream));
+  const int fd = open(path, O_CREAT | O_TRUNC | O_RDWR, 0644);
+  if (fd < 0) {
+    hipEventDestroy(ready);
+    return fail(ctx, NTS_EINVAL, std::string("nts_bf_save: cannot create ") + path);
+  }
+  const uint64_t total = header_bytes + bf->bytes;
+  bool ok = ftruncate(fd, (off_t)total) == 0;
+  uint8_t* map = ok ? (uint8_t*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : (uint8_t*)MAP_FAILED;
+  if (map == (uint8_t*)MAP_FAILED) ok = false;
+  if (ok && header_bytes) memcpy(map, header, header_bytes);
+  std::atomic<uint64_t> next(0);
+  std::atomic<bool> failed(false);
+  const uint64_t CHUNK = (uint64_t)16 << 20;
+  const uint64_t n_chunks = (bf->bytes + CHUNK - 1) / CHUNK;
+  const uint8_t* src = (const uint8_t*)bf->d_words;
+  const int device = ctx->device;
+  auto worker = [&]() {
+    if (hipSetDevice(device) != hipSuccess) {
+      failed.store(true);
+      return;
+    }
+    hipStream_t st = nullptr;
+    uint8_t* stage[2] = { nullptr, nullptr };
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipHostMalloc((void**)&stage[0], CHUNK) != hipSuccess ||
+        hipHostMalloc((void**)&stage[1], CHUNK) != hipSuccess || hipStreamWaitEvent(st, ready, 0) != hipSuccess) {
+      failed.store(true);
+    } else {
+      // two chunks in flight per thread: while chunk c is copied into the mapping, chunk c' is on its way from HBM
+      uint64_t cur = next.fetch_add(1), cur_len = 0;
+      int slot = 0;
+      if (cur < n_chunks) {
+        cur_len = std::min(CHUNK, bf->bytes - cur * CHUNK);
+        if (hipMemcpyAsync(stage[slot], src + cur * CHUNK, cur_len, hipMemcpyDeviceToHost, st) != hipSuccess) failed.store(true);
+      }
+      while (cur < n_chunks && !failed.load()) {
+        if (hipStreamSynchronize(st) != hipSuccess) {
+          failed.store(true);
+          break;
+        }
+        const uint64_t nxt = next.fetch_add(1);
+        uint64_t nxt_len = 0;
+        if (nxt < n_chunks) {
+          nxt_len = std::min(CHUNK, bf->bytes - nxt * CHUNK);
+          if (hipMemcpyAsync(stage[slot ^ 1], src + nxt * CHUNK, nxt_len, hipMemcpyDeviceToHost, st) != hipSuccess) failed.store(true);
+        }
+        memcpy(map + header_bytes + cur * CHUNK, stage[slot], cur_len);
+        cur = nxt;
+        cur_len = nxt_len;
+        slot ^= 1;
+      }
+    }
+    if (st) {
+      hipStreamSynchronize(st);
+      hipStreamDestroy(st);
+    }
+    if (stage[0]) hipHostFree(stage[0]);
+    if (stage[1]) hipHostFree(stage[1]);
+  };
+  if (ok) {
+    const unsigned T = std::max(1u, std::min<unsigned>(n_threads ? n_threads : 6, (unsigned)std::max<uint64_t>(n_chunks, 1)));
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t) pool.emplace_back(worker);
+    for (auto& th : pool) th.join();
+  }
+  if (map != (uint8_t*)MAP_FAILED) munmap(map, total);
+  close(fd);
+  hipEventDestroy(ready);
+  if (!ok || failed.load()) return fail(ctx, NTS_EHIP, std::string("nts_bf_save: writing ") + path + " failed");
   return NTS_OK;
 }
 
@@ -1945,6 +2238,7 @@ int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_
   P.seg_cap = out.seg_cap;
   P.tile_cnt = out.d_tile_cnt;
   P.tile_cap = out.tile_cap;
+  P.tile_any = (d_tile_ids == nullptr && out.d_tile_cnt == nullptr) ? ctx->cur_tile_any : nullptr;
   ScopedTimer t(ctx, tag);
   hipLaunchKernelGGL(k_window_min, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
@@ -2470,6 +2764,14 @@ extern "C" int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c)
   return NTS_OK;
 }
 
+extern "C" int nts_sketch_summary(nts_ctx* ctx, int mode, uint32_t* last_shift)
+{
+  if (!ctx || mode < -1 || mode > 1) return fail(ctx, NTS_EINVAL, "nts_sketch_summary: mode is -1 (query), 0 (auto) or 1 (never)");
+  if (mode >= 0) ctx->summary_mode = mode;
+  if (last_shift) *last_shift = ctx->last_summary;
+  return NTS_OK;
+}
+
 extern "C" int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers, uint32_t* prune_c_used)
 {
   if (!ctx) return NTS_EINVAL;
@@ -2501,6 +2803,8 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   auto bail = [&](int code) {
     hipStreamSynchronize(ctx->stream);
     nts_mx_free(ctx, mx);
+    ctx->cur_summary = nullptr;
+    ctx->cur_tile_any = nullptr;
     return code;
   };
 #define SK_TRY(expr)                                                                                \
@@ -2564,6 +2868,44 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
     if (ctx->sketch_mode == 0 && want > cap) pruned = false;
   }
   ctx->last_c = pruned ? prune_c : 0;
+  // Dense pass over a sparse filter: with occupancy o, a summary bit covering 2^shift filter bits is set with probability
+  // ~ o * 2^shift; when that is small the summary answers nearly every probe from the L2 (k_hash_keys_sparse).
+  ctx->cur_summary = nullptr;
+  ctx->cur_tile_any = nullptr;
+  ctx->last_summary = 0;
+  if (!pruned && filter && filter->owned && ctx->summary_mode == 0) {
+    uint64_t pc = 0;
+    SK_TRY(nts_bf_popcount(ctx, filter, &pc));
+    const double bits = (double)filter->bytes * 8.0;
+    uint32_t shift = 7;
+    while ((bits / (double)(1ull << shift)) > (double)(1u << 23) && shift < 30) ++shift; // summary <= 2^23 bits = 1 MiB
+    if ((double)pc / bits * (double)(1ull << shift) < 0.3) {
+      if (filter->summary_version != filter->version || filter->summary_shift != shift) {
+        const uint64_t n_gran = ((uint64_t)filter->bytes * 8 + (1ull << shift) - 1) >> shift;
+        const uint64_t words = (n_gran + 31) / 32 + 4;
+        if (filter->summary_words < words) {
+          if (filter->d_summary) hipFree(filter->d_summary);
+          filter->d_summary = nullptr;
+          filter->summary_words = 0;
+          SK_HIP(hipMalloc((void**)&filter->d_summary, words * 4));
+          filter->summary_words = words;
+        }
+        SK_HIP(hipMemsetAsync(filter->d_summary, 0, filter->summary_words * 4, ctx->stream));
+        const uint64_t n16 = (filter->bytes + 15) / 16;
+        ScopedTimer t(ctx, "bf_summary");
+        hipLaunchKernelGGL(k_bf_summary, dim3((uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 16)), dim3(256), 0, ctx->stream,
+                           (const uint4*)filter->d_words, n16, shift, filter->d_summary);
+        filter->summary_shift = shift;
+        filter->summary_version = filter->version;
+      }
+      const uint64_t key_tiles = (rt.n_valid + KEY_TILE - 1) / KEY_TILE;
+      SK_WS(d_any, uint32_t*, "tile_any", (key_tiles + 4) * 4);
+      ctx->cur_summary = filter->d_summary;
+      ctx->cur_summary_shift = shift;
+      ctx->cur_tile_any = d_any;
+      ctx->last_summary = shift;
+    }
+  }
 
   for (int attempt = 0;; ++attempt) {
     SortedOut res;
@@ -2611,6 +2953,8 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
     ctx->small_gap_path = false;
   }
   ctx->small_gap_path = true;
+  ctx->cur_summary = nullptr;
+  ctx->cur_tile_any = nullptr;
   *out = mx;
   return NTS_OK;
 #undef SK_TRY

@@ -54,6 +54,14 @@ class Context:
         code = {"auto": 0, "dense": 1, "pruned": 2}[mode]
         self.check(self.lib.nts_sketch_mode(self.h, code, int(prune_c)), "nts_sketch_mode")
 
+    def sketch_summary(self, mode=None):
+        """Summary-first probing of sparse filters in the dense sketch (nts_sketch_summary): mode 'auto' / 'never' / None
+        (leave as is).  Returns the granule shift the last sketch call used (0: no summary)."""
+        last = ctypes.c_uint32()
+        code = {None: -1, "auto": 0, "never": 1}[mode]
+        self.check(self.lib.nts_sketch_summary(self.h, code, ctypes.byref(last)), "nts_sketch_summary")
+        return last.value
+
     def bf_build_mode(self, mode="auto"):
         """How BloomFilter.insert sets the bits: 'auto' (partitioned streaming build for large genomes), 'atomic'
         (one atomic OR per k-mer) or 'binned' (partitioned whenever the filter layout allows); same filter."""
@@ -259,6 +267,10 @@ class BloomFilter:
         out = np.empty(self.bytes, dtype=np.uint8)
         self.ctx.check(self.ctx.lib.nts_bf_download(self.ctx.h, self.h, out.ctypes.data, self.bytes), "nts_bf_download")
         return out
+
+    def save(self, path, header=b"", threads=0):
+        "bf->save(path): header bytes + the bit array streamed out of HBM into the file (nts_bf_save), no host copy"
+        self.ctx.check(self.ctx.lib.nts_bf_save(self.ctx.h, self.h, os.fsencode(path), header, len(header), int(threads)), "nts_bf_save")
 
     def from_numpy(self, arr):
         arr = np.ascontiguousarray(arr, dtype=np.uint8)

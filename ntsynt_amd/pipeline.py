@@ -26,15 +26,18 @@ from .synteny import SyntenyEngine
 BF_SIGNATURE = "[BTLKmerBloomFilter_v5]"
 
 
+def bf_header(nbytes, k, hash_num=1, signature=BF_SIGNATURE):
+    return (f"{signature}\nbytes = {nbytes}\nhash_fn = \"ntHash_v2\"\n"
+            f"hash_num = {hash_num}\nk = {k}\n\n[HeaderEnd]\n").encode()
+
+
 def write_bf(path, bits, k, hash_num=1, signature=BF_SIGNATURE):
     """btllib KmerBloomFilter file: TOML-style header + raw bit array.  The layout (table name `signature`, keys
     bytes / hash_fn / hash_num / k, terminator [HeaderEnd]) is recalled from btllib's BloomFilter::save, which is not in
     the reference tree: the file is NOT guaranteed to load in a stock btllib (`indexlr -s`).
     The table name is a parameter (`--bf-signature`) so that a maintainer holding a real btllib file can match it."""
-    header = (f"{signature}\nbytes = {bits.size}\nhash_fn = \"ntHash_v2\"\n"
-              f"hash_num = {hash_num}\nk = {k}\n\n[HeaderEnd]\n")
     with open(path, "wb") as fh:
-        fh.write(header.encode())
+        fh.write(bf_header(bits.size, k, hash_num, signature))
         bits.tofile(fh)
 
 
@@ -393,10 +396,12 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     else:
         out_prefix = prefix
 
-    def write_bf_later():
-        if bf is not None and rank == 0:
-            # filter file: device -> host copy on the library's copy stream + write, on a writer thread, started once the
-            # whole-genome sketches are out of the way (their small read-backs would queue behind the bulk copy)
+    if bf is not None and rank == 0:
+        # filter file, behind everything that follows: straight out of HBM on the library's own copy threads where the filter
+        # has a save() (the GPU backend), else device -> host copy + write
+        if hasattr(bf, "save"):
+            pending_files.append(writers.submit(bf.save, f"{prefix}.common.bf", bf_header(bf.bytes, k, signature=bf_signature)))
+        else:
             pending_files.append(writers.submit(lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k, signature=bf_signature)))
 
     if device_engine:
@@ -423,7 +428,6 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], genomes[fastas[i]].recs, out[0], out[1], out[2], k,
                                                     mx_with_seq))
         st.stop()
-        write_bf_later()
         st.start("ntsynt_synteny")
         eng = DeviceSyntenyEngine(backend.ctx, tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size,
                                   out_prefix, sketch_dev_round, simplify=simplify, log=log)
@@ -442,7 +446,6 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                     pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], genomes[p].recs, out[0], out[1], out[2], k,
                                                         mx_with_seq))
         st.stop()
-        write_bf_later()
         st.start("ntsynt_synteny")
 
         def sketch_fn(i, masks, new_w):

@@ -210,8 +210,15 @@ def test_c4_one_gpu_share_of_eight_divergent_3gbp_genomes(ctx):
     for mode in ("auto", "dense", "pruned"):
         ctx.sketch_mode(mode)
         out[mode] = sketch(ctx, mine, k, w, common).to_numpy()
+        if mode == "auto":
+            assert ctx.sketch_summary() >= 7            # the all-but-empty filter is probed through its L2-resident summary
+    ctx.sketch_summary("never")
+    ctx.sketch_mode("dense")
+    out["plain"] = sketch(ctx, mine, k, w, common).to_numpy()      # every k-mer probed in HBM
+    assert ctx.sketch_summary() == 0
+    ctx.sketch_summary("auto")
     ctx.sketch_mode("auto")
-    for mode in ("dense", "pruned"):
+    for mode in ("dense", "pruned", "plain"):
         for x, y in zip(out["auto"], out[mode]):
             assert np.array_equal(x, y)
     h1, rec, pos = out["auto"]
@@ -228,6 +235,63 @@ def test_c4_one_gpu_share_of_eight_divergent_3gbp_genomes(ctx):
         assert np.array_equal(pos[m], exp[1][:n]) and np.array_equal(h1[m], exp[0][:n])
     assert seen > 50
     mine.free()
+    common.free()
+
+
+def test_sparse_filter_summary_path_matches_oracle(ctx):
+    "the summary-first dense pass (csrc: k_hash_keys_sparse) on ragged records with N runs, against the plain pass and the oracle"
+    from ntsynt_amd import synth
+    from ntsynt_amd.device import BloomFilter, bf_size_bytes, sketch
+    from tests.helpers import oracle_flat, to_device
+    k = 24
+    anc = synth.make_ancestor(1_500_000, 5, seed=71)
+    anc += [anc[0][:30], anc[1][:23], anc[2][:1023]]                    # records around k and around a window
+    fam = [synth.derive_genome(anc, 0.10, j, seed=71, structural=False, n_runs=True) for j in range(4)]
+    dev, ora = [], []
+    for contigs in fam:
+        seqs = [c.tobytes() for c in contigs]
+        names = [f"c{i}" for i in range(len(seqs))]
+        dev.append(to_device(ctx, names, seqs))
+        ora.append(O.Genome(names, seqs))
+    _, nbytes = bf_size_bytes(dev[0].total_bp, 0.025)
+    common = BloomFilter(ctx, nbytes, k)
+    common.insert(dev[0])
+    tmp = BloomFilter(ctx, nbytes, k)
+    for g in dev[1:]:
+        tmp.clear()
+        tmp.insert(g)
+        common.and_(tmp)
+    tmp.free()
+    bits = common.to_numpy()
+    assert 0 < O.bf_fpr(bits) < 0.002
+    ctx.sketch_mode("dense")
+    for w in (40, 300, 1000):
+        for d, o in zip(dev[:2], ora[:2]):
+            ctx.sketch_summary("auto")
+            a = sketch(ctx, d, k, w, common).to_numpy()
+            assert ctx.sketch_summary() >= 7
+            ctx.sketch_summary("never")
+            b = sketch(ctx, d, k, w, common).to_numpy()
+            exp = oracle_flat(O.minimize(o, k, w, bits))
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+            assert np.array_equal(a[0], exp[0]) and np.array_equal(a[2], exp[2]) and a[0].size > 0
+    # masked re-sketch (refinement rounds) through the same path
+    ctx.sketch_summary("auto")
+    masks = [(0, 1000, 200_000), (3, 0, 50_000)]
+    got = sketch(ctx, dev[0], k, 40, common, masks).to_numpy()
+    seqs = []
+    for r in range(len(ora[0].names)):
+        buf = bytearray(ora[0].record(r))
+        for mr, s0, e0 in masks:
+            if mr == r:
+                buf[s0:e0] = b"N" * (min(e0, len(buf)) - s0)
+        seqs.append(bytes(buf))
+    exp = oracle_flat(O.minimize(O.Genome(ora[0].names, seqs), k, 40, bits))
+    assert np.array_equal(got[0], exp[0]) and np.array_equal(got[2], exp[2])
+    ctx.sketch_mode("auto")
+    for g in dev:
+        g.free()
     common.free()
 
 
