@@ -133,7 +133,7 @@ int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set);
 int nts_bf_download(nts_ctx* ctx, const nts_bf* bf, uint8_t* host, uint64_t bytes);
 int nts_bf_upload(nts_ctx* ctx, nts_bf* bf, const uint8_t* host, uint64_t bytes);
 /* bf->save(path) (cpp:164) straight out of HBM: `header` (the caller's btllib-style text header), then the bit array, written
- * through a shared file mapping by n_threads host threads (0 = default) with pinned staging -- no host copy of the filter.
+ * by n_threads host threads (0 = default) through pinned staging and positional writes -- no host copy of the filter.
  * Like nts_bf_download it sees everything queued before the call and may run on a second host thread. */
 int nts_bf_save(nts_ctx* ctx, const nts_bf* bf, const char* path, const void* header, uint64_t header_bytes, uint32_t n_threads);
 /* Microbenchmark: n_probes pseudo-random single-bit reads of the filter with the access shape of the sketch's
@@ -227,6 +227,9 @@ int nts_mx_export(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, v
 /* the same without waiting: the copies are queued on the context's stream; nts_sync() before the buffers are read
  * by another stream and before the list is freed (several lists, one wait) */
 int nts_mx_export_async(nts_ctx* ctx, const nts_mx* mx, void* h1_dev, void* rec_dev, void* pos_dev);
+/* k-mer text (upper case, k bytes per minimizer, no separators) of a list sketched from `g`, to a host buffer of
+ * nts_mx_count() * k bytes: what `indexlr --seq` prints (smk:81) when the host never held the bases (nts_genome_from_fasta) */
+int nts_mx_kmers(nts_ctx* ctx, const nts_genome* g, const nts_mx* mx, uint32_t k, uint8_t* host);
 /* the list of a batch genome (nts_genome_concat) taken apart on the device: out[p] = the minimizers of records
  * [rec_base[p], rec_base[p+1]) with record ids rebased to the part (rec_base has n_parts + 1 entries) */
 int nts_mx_split(nts_ctx* ctx, const nts_mx* mx, uint32_t n_parts, const uint32_t* rec_base, nts_mx** out);
@@ -413,6 +416,16 @@ typedef struct
   uint32_t* fai_linewidth;
 } nts_fasta;
 int nts_fasta_read(const char* path, nts_fasta* out);
+/* The same ingest with the parse on the GPU: the file's bytes (plain: mapped; .gz: inflated on the
+ * host) go to HBM through pinned staging, kernels find the header lines, drop line ends, compact and encode the bases into
+ * a resident genome and produce the record table and the faidx columns; the host reads only the header lines.  `meta` as
+ * nts_fasta_read fills it, except seq == NULL (the bases never exist on the host; nts_mx_kmers serves `--seq` output).
+ * Same rules as nts_fasta_read; in addition a blank or tab inside a sequence line is NTS_EFORMAT instead of a base. */
+int nts_genome_from_fasta(nts_ctx* ctx, const char* path, nts_genome** out, nts_fasta* meta);
+/* nts_write_indexlr_tsv for records whose bases are not on the host (fa->seq == NULL): `kmers` = nts_mx_kmers' output, or
+ * NULL without --seq */
+int nts_write_indexlr_tsv_kmers(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,
+                                uint64_t n, uint32_t k, const uint8_t* kmers);
 void nts_fasta_free(nts_fasta* f);
 int nts_write_indexlr_tsv(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,
                           uint64_t n, uint32_t k, int with_seq);

@@ -115,6 +115,30 @@ struct FileBytes
   }
 };
 
+} // namespace
+
+// internal (not part of the C ABI in include/ntsynt_hip.h): the bytes of an input file for the device-side FASTA parse in
+// ntsynt_hip.hip -- mapped for plain files, inflated for .gz; released with nts_internal_file_close
+extern "C" int nts_internal_file_open(const char* path, const uint8_t** p, uint64_t* n, void** handle)
+{
+  FileBytes* f = new FileBytes();
+  if (!f->open(path)) {
+    delete f;
+    return NTS_EINVAL;
+  }
+  *p = f->p;
+  *n = f->n;
+  *handle = f;
+  return NTS_OK;
+}
+
+extern "C" void nts_internal_file_close(void* handle)
+{
+  delete (FileBytes*)handle;
+}
+
+namespace {
+
 // Large host buffers (a genome's bases): 2 MiB-aligned and advised to use huge pages, so that first touch costs
 // thousands of page faults rather than millions.  Released with free().
 void* big_alloc(size_t bytes)
@@ -252,9 +276,25 @@ extern "C" void nts_fasta_free(nts_fasta* f)
   memset(f, 0, sizeof(*f));
 }
 
+static int write_indexlr_tsv_impl(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,
+                                  uint64_t n, uint32_t k, int with_seq, const uint8_t* kmers);
+
 // `indexlr --long --pos [--seq]`: one line per record, "id \t hash:pos[:KMER] hash:pos[:KMER] ...\n"
 extern "C" int nts_write_indexlr_tsv(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,
                                      uint64_t n, uint32_t k, int with_seq)
+{
+  if (fa && with_seq && !fa->seq) return NTS_EINVAL; // bases not on the host: nts_write_indexlr_tsv_kmers
+  return write_indexlr_tsv_impl(path, fa, h1, rec, pos, n, k, with_seq, nullptr);
+}
+
+extern "C" int nts_write_indexlr_tsv_kmers(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,
+                                           uint64_t n, uint32_t k, const uint8_t* kmers)
+{
+  return write_indexlr_tsv_impl(path, fa, h1, rec, pos, n, k, kmers != nullptr, kmers);
+}
+
+static int write_indexlr_tsv_impl(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,
+                                  uint64_t n, uint32_t k, int with_seq, const uint8_t* kmers)
 {
   if (!path || !fa || (n && (!h1 || !rec || !pos))) return NTS_EINVAL;
   FILE* f = fopen(path, "wb");
@@ -284,7 +324,7 @@ extern "C" int nts_write_indexlr_tsv(const char* path, const nts_fasta* fa, cons
       p = put_u64(p, pos[i]);
       if (with_seq) {
         *p++ = ':';
-        const uint8_t* s = fa->seq + fa->rec_off[r] + pos[i];
+        const uint8_t* s = kmers ? kmers + i * (uint64_t)k : fa->seq + fa->rec_off[r] + pos[i];
         for (uint32_t q = 0; q < k; ++q) {
           const uint8_t c = s[q];
           *p++ = (char)((c >= 'a' && c <= 'z') ? c - 32 : c);

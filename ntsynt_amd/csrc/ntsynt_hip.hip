@@ -1535,6 +1535,80 @@ int nts_bf_size_bytes(uint64_t genome_bp, double fpr, uint64_t* approx_bytes, ui
   return nts_bf_size_bytes_ex(genome_bp, fpr, NTS_BF_ROUND_UP, approx_bytes, ctor_bytes);
 }
 
+// The part of a genome's set-up that needs its codes in HBM: maximal stretches of valid bases (clipped to records) and the
+// record table on the device.  g->n, g->n_rec, g->rec_off, g->rec_len and g->d_code are in place.
+static int genome_finish(nts_ctx* ctx, nts_genome* g)
+{
+  const uint64_t n = g->n;
+  const uint32_t n_rec = g->n_rec;
+  // valid stretches: count, append, sort
+  unsigned long long* d_cnt = nullptr;
+  if (hipMalloc((void**)&d_cnt, 3 * sizeof(unsigned long long)) != hipSuccess) return fail(ctx, NTS_ENOMEM, "hipMalloc counters");
+  hipMemsetAsync(d_cnt, 0, 3 * sizeof(unsigned long long), ctx->stream);
+  const uint64_t sblocks = (n + 1 + 4095) / 4096;
+  hipLaunchKernelGGL(k_stretch<0>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, nullptr, nullptr,
+                     nullptr);
+  unsigned long long n_st = 0;
+  hipMemcpyAsync(&n_st, d_cnt, sizeof(n_st), hipMemcpyDeviceToHost, ctx->stream);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    hipFree(d_cnt);
+    return fail(ctx, NTS_EHIP, std::string("encode/stretch count: ") + hipGetErrorString(hipGetLastError()));
+  }
+  std::vector<uint64_t> hs(n_st), he(n_st);
+  if (n_st) {
+    uint64_t *d_s = nullptr, *d_e = nullptr, *d_s2 = nullptr, *d_e2 = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    bool ok = hipMalloc((void**)&d_s, n_st * 8) == hipSuccess && hipMalloc((void**)&d_e, n_st * 8) == hipSuccess &&
+              hipMalloc((void**)&d_s2, n_st * 8) == hipSuccess && hipMalloc((void**)&d_e2, n_st * 8) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(k_stretch<1>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, d_s, d_e,
+                         d_cnt + 1);
+      rocprim::radix_sort_keys(nullptr, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
+      ok = hipMalloc(&d_tmp, tmp_bytes) == hipSuccess;
+    }
+    if (ok) {
+      rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
+      rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_e, d_e2, n_st, 0, 64, ctx->stream);
+      hipMemcpyAsync(hs.data(), d_s2, n_st * 8, hipMemcpyDeviceToHost, ctx->stream);
+      hipMemcpyAsync(he.data(), d_e2, n_st * 8, hipMemcpyDeviceToHost, ctx->stream);
+      ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    hipFree(d_s);
+    hipFree(d_e);
+    hipFree(d_s2);
+    hipFree(d_e2);
+    hipFree(d_tmp);
+    if (!ok) {
+      hipFree(d_cnt);
+      return fail(ctx, NTS_EHIP, "stretch detection failed");
+    }
+  }
+  hipFree(d_cnt);
+  // clip stretches to records (k-mers never span two records)
+  uint32_t r = 0;
+  for (size_t s = 0; s < hs.size(); ++s) {
+    uint64_t a = hs[s];
+    const uint64_t b = he[s];
+    while (a < b) {
+      while (r < n_rec && g->rec_off[r] + g->rec_len[r] <= a) ++r;
+      if (r >= n_rec) break;
+      const uint64_t ra = g->rec_off[r], rb = ra + g->rec_len[r];
+      const uint64_t x = std::max(a, ra), y = std::min(b, rb);
+      if (y > x) {
+        g->st_a.push_back(x);
+        g->st_b.push_back(y);
+      }
+      if (b <= rb) break;
+      a = rb;
+    }
+  }
+  if (hipMalloc((void**)&g->d_rec_off, std::max<uint32_t>(n_rec, 1) * 8) != hipSuccess ||
+      (n_rec && hipMemcpy(g->d_rec_off, g->rec_off.data(), n_rec * 8, hipMemcpyHostToDevice) != hipSuccess))
+    return fail(ctx, NTS_ENOMEM, "hipMalloc record offsets");
+  return NTS_OK;
+}
+
 int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64_t* rec_off, const uint64_t* rec_len,
                       uint32_t n_rec, nts_genome** out)
 {
@@ -1572,71 +1646,12 @@ int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64
     const uint64_t blocks = (n + 4095) / 4096;
     hipLaunchKernelGGL(k_encode, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n);
   }
-  // valid stretches: count, append, sort
-  unsigned long long* d_cnt = nullptr;
-  if (hipMalloc((void**)&d_cnt, 3 * sizeof(unsigned long long)) != hipSuccess) return bail(NTS_ENOMEM, "hipMalloc counters");
-  hipMemsetAsync(d_cnt, 0, 3 * sizeof(unsigned long long), ctx->stream);
-  const uint64_t sblocks = (n + 1 + 4095) / 4096;
-  hipLaunchKernelGGL(k_stretch<0>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, nullptr, nullptr,
-                     nullptr);
-  unsigned long long n_st = 0;
-  hipMemcpyAsync(&n_st, d_cnt, sizeof(n_st), hipMemcpyDeviceToHost, ctx->stream);
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    hipFree(d_cnt);
-    return bail(NTS_EHIP, std::string("encode/stretch count: ") + hipGetErrorString(hipGetLastError()));
+  if (int rc = genome_finish(ctx, g)) {
+    hipFree(g->d_code);
+    hipFree(g->d_rec_off);
+    delete g;
+    return rc;
   }
-  std::vector<uint64_t> hs(n_st), he(n_st);
-  if (n_st) {
-    uint64_t *d_s = nullptr, *d_e = nullptr, *d_s2 = nullptr, *d_e2 = nullptr;
-    void* d_tmp = nullptr;
-    size_t tmp_bytes = 0;
-    bool ok = hipMalloc((void**)&d_s, n_st * 8) == hipSuccess && hipMalloc((void**)&d_e, n_st * 8) == hipSuccess &&
-              hipMalloc((void**)&d_s2, n_st * 8) == hipSuccess && hipMalloc((void**)&d_e2, n_st * 8) == hipSuccess;
-    if (ok) {
-      hipLaunchKernelGGL(k_stretch<1>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, d_s, d_e,
-                         d_cnt + 1);
-      rocprim::radix_sort_keys(nullptr, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
-      ok = hipMalloc(&d_tmp, tmp_bytes) == hipSuccess;
-    }
-    if (ok) {
-      rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
-      rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_e, d_e2, n_st, 0, 64, ctx->stream);
-      hipMemcpyAsync(hs.data(), d_s2, n_st * 8, hipMemcpyDeviceToHost, ctx->stream);
-      hipMemcpyAsync(he.data(), d_e2, n_st * 8, hipMemcpyDeviceToHost, ctx->stream);
-      ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
-    }
-    hipFree(d_s);
-    hipFree(d_e);
-    hipFree(d_s2);
-    hipFree(d_e2);
-    hipFree(d_tmp);
-    if (!ok) {
-      hipFree(d_cnt);
-      return bail(NTS_EHIP, "stretch detection failed");
-    }
-  }
-  hipFree(d_cnt);
-  // clip stretches to records (k-mers never span two records)
-  uint32_t r = 0;
-  for (size_t s = 0; s < hs.size(); ++s) {
-    uint64_t a = hs[s];
-    const uint64_t b = he[s];
-    while (a < b) {
-      while (r < n_rec && g->rec_off[r] + g->rec_len[r] <= a) ++r;
-      if (r >= n_rec) break;
-      const uint64_t ra = g->rec_off[r], rb = ra + g->rec_len[r];
-      const uint64_t x = std::max(a, ra), y = std::min(b, rb);
-      if (y > x) {
-        g->st_a.push_back(x);
-        g->st_b.push_back(y);
-      }
-      if (b <= rb) break;
-      a = rb;
-    }
-  }
-  if (hipMalloc((void**)&g->d_rec_off, std::max<uint32_t>(n_rec, 1) * 8) != hipSuccess ||
-      (n_rec && hipMemcpy(g->d_rec_off, g->rec_off.data(), n_rec * 8, hipMemcpyHostToDevice) != hipSuccess))
-    return bail(NTS_ENOMEM, "hipMalloc record offsets");
   *out = g;
   return NTS_OK;
 }
@@ -2067,7 +2082,7 @@ int nts_bf_upload(nts_ctx* ctx, nts_bf* bf, const uint8_t* host, uint64_t bytes)
 
 // bf->save(path) (src/ntsynt_make_common_bf.cpp:164) without a host copy of the filter: `header` first, then the bit array
 // streamed out of HBM by a few host threads, each with its own pinned staging buffer and HIP stream -- a device -> host copy
-// of the next chunk runs while the previous one is copied into the file's mapping.  Sees everything queued on the context's
+// of the next chunk runs while the previous one is written to the file.  Sees everything queued on the context's
 // stream before the call; safe to run on a second host thread while the first keeps sketching.
 int nts_bf_save(nts_ctx* ctx, const nts_bf* bf, const char* path, const void* header, uint64_t header_bytes, uint32_t n_threads)
 {
@@ -2081,11 +2096,20 @@ int nts_bf_save(nts_ctx* ctx, const nts_bf* bf, const char* path, const void* he
     hipEventDestroy(ready);
     return fail(ctx, NTS_EINVAL, std::string("nts_bf_save: cannot create ") + path);
   }
-  const uint64_t total = header_bytes + bf->bytes;
-  bool ok = ftruncate(fd, (off_t)total) == 0;
-  uint8_t* map = ok ? (uint8_t*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : (uint8_t*)MAP_FAILED;
-  if (map == (uint8_t*)MAP_FAILED) ok = false;
-  if (ok && header_bytes) memcpy(map, header, header_bytes);
+  // (positional writes from a few threads; a shared file mapping was tried and took twice as long -- 3.6 M first-touch
+  // faults on the mapping for a 14.8 GB filter)
+  auto write_at = [fd](const void* src, uint64_t len, uint64_t at) {
+    const uint8_t* p = (const uint8_t*)src;
+    while (len) {
+      const ssize_t got = pwrite(fd, p, len, (off_t)at);
+      if (got <= 0) return false;
+      p += got;
+      at += (uint64_t)got;
+      len -= (uint64_t)got;
+    }
+    return true;
+  };
+  bool ok = header_bytes == 0 || write_at(header, header_bytes, 0);
   std::atomic<uint64_t> next(0);
   std::atomic<bool> failed(false);
   const uint64_t CHUNK = (uint64_t)16 << 20;
@@ -2121,7 +2145,7 @@ int nts_bf_save(nts_ctx* ctx, const nts_bf* bf, const char* path, const void* he
           nxt_len = std::min(CHUNK, bf->bytes - nxt * CHUNK);
           if (hipMemcpyAsync(stage[slot ^ 1], src + nxt * CHUNK, nxt_len, hipMemcpyDeviceToHost, st) != hipSuccess) failed.store(true);
         }
-        memcpy(map + header_bytes + cur * CHUNK, stage[slot], cur_len);
+        if (!write_at(stage[slot], cur_len, header_bytes + cur * CHUNK)) failed.store(true);
         cur = nxt;
         cur_len = nxt_len;
         slot ^= 1;
@@ -2140,7 +2164,6 @@ int nts_bf_save(nts_ctx* ctx, const nts_bf* bf, const char* path, const void* he
     for (unsigned t = 0; t < T; ++t) pool.emplace_back(worker);
     for (auto& th : pool) th.join();
   }
-  if (map != (uint8_t*)MAP_FAILED) munmap(map, total);
   close(fd);
   hipEventDestroy(ready);
   if (!ok || failed.load()) return fail(ctx, NTS_EHIP, std::string("nts_bf_save: writing ") + path + " failed");
@@ -3058,6 +3081,7 @@ void nts_free(void* p)
 } // extern "C"
 
 #include "nts_comm.inc"
+#include "nts_fasta_dev.inc"
 
 // ---- minimizer graph build (rows C1, C2a, C2b) --------------------------------------------------------
 namespace {

@@ -377,6 +377,13 @@ class Minimizers:
                                         ctypes.byref(h)), "nts_mx_upload")
         return cls(ctx, h)
 
+    def kmers(self, genome, k):
+        "k-mer text of every minimizer (uint8 array of len(self) * k upper-case bytes) gathered from the resident genome"
+        out = np.empty(len(self) * int(k), dtype=np.uint8)
+        if len(self):
+            self.ctx.check(self.ctx.lib.nts_mx_kmers(self.ctx.h, genome.h, self.h, int(k), out.ctypes.data), "nts_mx_kmers")
+        return out
+
     def split(self, rec_base):
         """The list of a Genome.concat() batch taken apart on the device (nts_mx_split): one Minimizers per part, record ids
         local to the part; rec_base = Genome.rec_base of the batch."""

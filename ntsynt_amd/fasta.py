@@ -64,6 +64,57 @@ def read_fasta(path):
     return FastaRecords(names, seq, rec_off, rec_len, fai, native=f)
 
 
+def _records_from_native(f, with_seq):
+    n_rec, n = int(f.n_rec), int(f.n)
+    seq = np.ctypeslib.as_array(f.seq, shape=(max(n, 1),))[:n] if with_seq else None
+    rec_off = np.ctypeslib.as_array(f.rec_off, shape=(max(n_rec, 1),))[:n_rec]
+    rec_len = np.ctypeslib.as_array(f.rec_len, shape=(max(n_rec, 1),))[:n_rec]
+    raw = ctypes.string_at(f.names, int(f.names_bytes))
+    names = [x.decode() for x in raw.split(b"\0")[:n_rec]]
+    fo = np.ctypeslib.as_array(f.fai_offset, shape=(max(n_rec, 1),))[:n_rec]
+    fb = np.ctypeslib.as_array(f.fai_linebases, shape=(max(n_rec, 1),))[:n_rec]
+    fw = np.ctypeslib.as_array(f.fai_linewidth, shape=(max(n_rec, 1),))[:n_rec]
+    fai = [(names[i], int(rec_len[i]), int(fo[i]), int(fb[i]), int(fw[i])) for i in range(n_rec)]
+    return FastaRecords(names, seq, rec_off, rec_len, fai, native=f)
+
+
+def read_fasta_device(ctx, path):
+    """FASTA file -> (resident Genome, FastaRecords without bases) with the parse on the GPU (nts_genome_from_fasta,
+    csrc/nts_fasta_dev.inc): the host reads only the header lines."""
+    from .device import Genome
+    f = _lib.Fasta()
+    h = _lib.c_vp()
+    rc = ctx.lib.nts_genome_from_fasta(ctx.h, os.fsencode(path), ctypes.byref(h), ctypes.byref(f))
+    if rc == -74:
+        raise ValueError(f"{path!r} is not a FASTA file: {ctx.lib.nts_last_error(ctx.h).decode()}")
+    ctx.check(rc, "nts_genome_from_fasta")
+    recs = _records_from_native(f, with_seq=False)
+    g = Genome.__new__(Genome)
+    g.ctx, g.h, g.names = ctx, h, recs.names
+    g.rec_off = np.array(recs.rec_off, dtype=np.uint64)
+    g.rec_len = np.array(recs.rec_len, dtype=np.uint64)
+    g.n_bytes = int(f.n)
+    g.recs = recs
+    return g, recs
+
+
+def write_indexlr_tsv_kmers(path, recs, h1, rec, pos, k, kmers):
+    "write_indexlr_tsv for records whose bases are not on the host: `kmers` (uint8, len(h1) * k) from Minimizers.kmers(), or None"
+    h1 = np.ascontiguousarray(h1, dtype=np.uint64)
+    rec = np.ascontiguousarray(rec, dtype=np.uint32)
+    pos = np.ascontiguousarray(pos, dtype=np.uint64)
+    kp = None
+    if kmers is not None:
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint8)
+        if kmers.size != h1.size * int(k):
+            raise ValueError("kmers must hold k bytes per minimizer")
+        kp = kmers.ctypes.data
+    rc = _lib.load().nts_write_indexlr_tsv_kmers(os.fsencode(path), ctypes.byref(recs._native), h1.ctypes.data, rec.ctypes.data,
+                                                 pos.ctypes.data, h1.size, int(k), kp)
+    if rc != 0:
+        raise OSError(f"cannot write {path!r} (code {rc})")
+
+
 def write_indexlr_tsv(path, recs, h1, rec, pos, k, with_seq=True):
     """`indexlr --long --pos [--seq]` text: one line per FASTA record."""
     if recs._native is None:

@@ -106,7 +106,11 @@ class GpuBackend:
         return g
 
     def load_genome(self, path):
-        return self.upload_host(self.read_host(path))
+        "FASTA file -> resident genome with the parse on the GPU (fasta.read_fasta_device); NTS_FASTA=host: the host reader"
+        if os.environ.get("NTS_FASTA", "device") == "host":
+            return self.upload_host(self.read_host(path))
+        g, _ = fa.read_fasta_device(self.ctx, path)
+        return g
 
     # multi-GPU: the two exchanges run in the library over RCCL (nts_bf_allreduce_and, nts_mx_allgather); the id of the
     # communicator travels through torch.distributed's default group.  host_comm: verification mode (see __init__).
@@ -278,8 +282,9 @@ def load_genomes(backend, paths, max_threads=8):
     """FASTA files -> resident genomes.  The files are parsed concurrently on host threads (the reference runs one
     indexlr/faidx process per file under Snakemake); uploads happen in order on the caller's thread while later
     files are still being read."""
-    if len(paths) < 2 or not hasattr(backend, "read_host"):
-        return {p: backend.load_genome(p) for p in paths}
+    if len(paths) < 2 or not hasattr(backend, "read_host") or \
+            (isinstance(backend, GpuBackend) and os.environ.get("NTS_FASTA", "device") != "host"):
+        return {p: backend.load_genome(p) for p in paths}      # (the device parse spreads one file over host threads itself)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(max_threads, len(paths))) as pool:
         pending = [pool.submit(backend.read_host, p) for p in paths]
@@ -425,8 +430,12 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         if write_mx_tsv:
             for i in mine_idx:
                 out = initial_dev[i].to_numpy()
-                pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], genomes[fastas[i]].recs, out[0], out[1], out[2], k,
-                                                    mx_with_seq))
+                recs = genomes[fastas[i]].recs
+                if recs.seq is None:                           # bases never left HBM: the k-mer text is gathered there
+                    km = initial_dev[i].kmers(genomes[fastas[i]], k) if mx_with_seq else None
+                    pending_files.append(writers.submit(fa.write_indexlr_tsv_kmers, tsv_names[i], recs, out[0], out[1], out[2], k, km))
+                else:
+                    pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], recs, out[0], out[1], out[2], k, mx_with_seq))
         st.stop()
         st.start("ntsynt_synteny")
         eng = DeviceSyntenyEngine(backend.ctx, tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size,
@@ -443,8 +452,17 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
             for i, p in enumerate(fastas):
                 if owner[p] == rank:
                     out = initial[i]
-                    pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], genomes[p].recs, out[0], out[1], out[2], k,
-                                                        mx_with_seq))
+                    recs = genomes[p].recs
+                    if getattr(recs, "seq", 0) is None:
+                        from .device import Minimizers
+                        km = None
+                        if mx_with_seq:
+                            tmp_mx = Minimizers.from_numpy(backend.ctx, *out)
+                            km = tmp_mx.kmers(genomes[p], k)
+                            tmp_mx.free()
+                        pending_files.append(writers.submit(fa.write_indexlr_tsv_kmers, tsv_names[i], recs, out[0], out[1], out[2], k, km))
+                    else:
+                        pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], recs, out[0], out[1], out[2], k, mx_with_seq))
         st.stop()
         st.start("ntsynt_synteny")
 
