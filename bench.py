@@ -206,6 +206,8 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir):
     extra = {}
     if getattr(eng, "times", None):                                  # NTS_ENGINE_TIMES=1: wall clock per engine step
         extra["engine_times_s"] = {n: round(v, 3) for n, v in sorted(eng.times.items(), key=lambda kv: -kv[1])}
+    if getattr(eng, "stage_marks", None):
+        extra["time_line_s"] = dict(eng.stage_marks)
     return {**extra, "graph_stage": type(eng).__name__, "engine_stats": eng.stats,
             "what": f"{len(paths)} FASTA files on disk -> final synteny TSV (ntSynt -d {divergence_pct:g}: w_rounds {a.w_rounds}, "
                     f"indel {a.indel}, merge {a.merge}, block {a.block_size}), one GPU, files in the page cache",

@@ -74,6 +74,14 @@ class Stages:
         name, t0 = self._t
         self.rows.append((name, time.time() - t0))
 
+    def mark(self, label):
+        "a point on the run's time line (seconds since the first mark), for e2e breakdowns"
+        now = time.time()
+        if not hasattr(self, "t0"):
+            self.t0 = now
+            self.marks = []
+        self.marks.append((label, round(now - self.t0, 4)))
+
     def write(self, path):
         with open(path, "w", encoding="utf-8") as fh:
             for name, dt in self.rows:
@@ -323,6 +331,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     own_backend = backend is None
     backend = backend or GpuBackend(device, ctx)
     st = Stages()
+    st.mark("start")
     if world > 1 and hasattr(backend, "init_comm"):
         backend.init_comm()
     owner = {p: i % world for i, p in enumerate(fastas)}
@@ -334,6 +343,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
             raise ValueError(f"window size {ww} outside 1..{MAX_W} (limit of the window kernels)")
     st.start("read_fasta+upload")
     genomes = load_genomes(backend, mine)
+    st.mark("genomes_resident")
     for p in mine:
         g = genomes[p]
         if len(g.names) == 0 or g.total_bp == 0:
@@ -389,6 +399,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 allreduce_and(bf.tensor, backend.and_into)
         log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
         st.stop()
+        st.mark("common_filter_done")
 
     # Graph stage: resident in HBM (ntsynt_amd/synteny_device.py) on the GPU backend; NTS_ENGINE=host selects the
     # host-array twin (ntsynt_amd/synteny.py), which test doubles without a GPU use as well.
@@ -405,7 +416,11 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         # filter file, behind everything that follows: straight out of HBM on the library's own copy threads where the filter
         # has a save() (the GPU backend), else device -> host copy + write
         if hasattr(bf, "save"):
-            pending_files.append(writers.submit(bf.save, f"{prefix}.common.bf", bf_header(bf.bytes, k, signature=bf_signature)))
+            def save_filter():
+                st.mark("bf_save_begin")
+                bf.save(f"{prefix}.common.bf", bf_header(bf.bytes, k, signature=bf_signature))
+                st.mark("bf_save_end")
+            pending_files.append(writers.submit(save_filter))
         else:
             pending_files.append(writers.submit(lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k, signature=bf_signature)))
 
@@ -437,6 +452,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 else:
                     pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], recs, out[0], out[1], out[2], k, mx_with_seq))
         st.stop()
+        st.mark("sketches_done")
         st.start("ntsynt_synteny")
         eng = DeviceSyntenyEngine(backend.ctx, tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size,
                                   out_prefix, sketch_dev_round, simplify=simplify, log=log)
@@ -499,6 +515,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         import shutil
         shutil.rmtree(scratch, ignore_errors=True)
     st.stop()
+    st.mark("synteny_done")
     st.start("wait_for_files")
     for f in pending_files:
         f.result()                      # re-raises a writer's exception
@@ -516,5 +533,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         bf.free()
     if own_backend:
         backend.close()
+    st.mark("end")
     eng.stage_times = st.rows
+    eng.stage_marks = st.marks
     return eng
