@@ -17,8 +17,12 @@ import re
 import sys
 
 KEEP = ["k_hash_select", "k_sparse_win", "k_cand_compact", "k_bin1", "k_bin2", "k_bin3", "k_hash<0>", "k_window_min"]
-KMERS = 100.06e6          # one genome (the Bloom build inserts genome by genome)
-BATCH_KMERS = 300.19e6    # the three genomes of a step, sketched as one batch
+import os
+
+# k-mers per launch: NTS_PROF_KMERS for the bench command's genomes (round 2: 3 Gbp genomes, one launch sequence each);
+# round 1's defaults: a 100 Mbp genome for the Bloom build, the batch of three for the sketch kernels
+KMERS = float(os.environ.get("NTS_PROF_KMERS", 100.06e6))
+BATCH_KMERS = float(os.environ.get("NTS_PROF_KMERS", 300.19e6))
 PER_GENOME = ("k_bin1", "k_bin2", "k_bin3")
 
 
