@@ -2548,12 +2548,15 @@ int scan_counts(nts_ctx* ctx, const T* d_in, uint64_t n, uint64_t* d_out)
 
 // Pruned path; see nts_pruned.inc.  `res` gets every minimizer, ordered (sparse winners come out ordered by
 // construction; winners of uncovered ranges, if any, are sorted and merged in).
+// accept_all: the filter is sparse and its summary (ctx->cur_summary) is in place -- every k-mer is looked up, the accepted
+// ones are the candidates (k_hash_accept), windows without one have no minimizer: no uncovered ranges to evaluate
 int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter, uint32_t prune_c,
-               double p_accept, SortedOut& res)
+               double p_accept, SortedOut& res, bool accept_all = false)
 {
   const RunTable& rt = T.rt;
   const uint64_t V = rt.n_valid;
-  const uint64_t n_kt = (V + SEL_TILE - 1) / SEL_TILE; // tiles of the select kernel (16384 indices each)
+  const uint64_t sel_tile = accept_all ? (uint64_t)KEY_TILE : (uint64_t)SEL_TILE;
+  const uint64_t n_kt = (V + sel_tile - 1) / sel_tile; // tiles of the select kernel (16384 indices each; 8192 for k_hash_accept)
   if (n_kt > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
   // threshold: a fraction c/w of all hashes
   const unsigned __int128 full = ((unsigned __int128)1) << 64;
@@ -2561,7 +2564,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   // low 32 bits set: "h0 <= tau" is then a test of the high word alone (k_hash_select's rolling loop relies on it)
   uint64_t tau = t128 >= full - 1 ? KEY_MAX - 1 : ((uint64_t)t128 | 0xFFFFFFFFULL);
   if (tau == KEY_MAX) tau = KEY_MAX - 1;
-  const double frac = std::min(1.0, (double)prune_c / (double)w);
+  const double frac = accept_all ? 1.0 : std::min(1.0, (double)prune_c / (double)w);
 #define PR_WS(ptr, type, name, bytes)                                                               \
   type ptr = (type)ws_get(ctx, name, bytes);                                                        \
   if (!ptr) return NTS_ENOMEM
@@ -2575,7 +2578,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   PR_WS(d_glo, uint64_t*, "gap_lo", gap_cap * 8);
   PR_WS(d_ghi, uint64_t*, "gap_hi", gap_cap * 8);
   // room for the ACCEPTED candidates (share p_accept of the candidates, 1 if unknown); too little is seen and retried
-  uint64_t cseg_cap = (uint64_t)((double)V * frac * std::min(1.0, 1.5 * p_accept + 0.02) * 1.25 / N_SEG) + 8192;
+  uint64_t cseg_cap = (uint64_t)((double)V * frac * std::min(1.0, 1.5 * p_accept + (accept_all ? 1e-4 : 0.02)) * 1.25 / N_SEG) + 8192;
   unsigned long long ctl[N_SEG + 1];
   std::vector<uint64_t> glo(GAP_PEEK), ghi(GAP_PEEK);
   uint64_t m = 0, n_gap = 0, n_sparse = 0;
@@ -2596,7 +2599,9 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     ctx->sel_ctl_clean = false;
     SelParams S;
     S.code = g->d_code + PAD;
-    if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
+    if (!accept_all) {
+      if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
+    }
     S.pack = g->d_pack;
     S.run_pos = T.d_run_pos;
     S.run_vstart = T.d_run_vstart;
@@ -2613,7 +2618,28 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     S.tile_off = d_toff;
     S.tile_cnt = d_tcnt;
     S.tile_ordered = d_tord;
-    {
+    if (accept_all) {
+      AcceptParams A;
+      A.code = S.code;
+      A.run_pos = S.run_pos;
+      A.run_vstart = S.run_vstart;
+      A.n_runs = S.n_runs;
+      A.n_valid = V;
+      A.hp = S.hp;
+      A.bf = S.bf;
+      A.fm = S.fm;
+      A.summary = ctx->cur_summary;
+      A.shift = ctx->cur_summary_shift;
+      A.seg_j = d_sj;
+      A.seg_key = d_sk;
+      A.seg_cap = cseg_cap;
+      A.seg_count = d_ctl;
+      A.tile_off = d_toff;
+      A.tile_cnt = d_tcnt;
+      A.tile_ordered = d_tord;
+      ScopedTimer t(ctx, "hash_accept", true);
+      hipLaunchKernelGGL(k_hash_accept, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, A);
+    } else {
       ScopedTimer t(ctx, filter ? "hash_select" : "hash_select_nofilter", true);
       // a lane rolls 64 k-mers and keeps 64*c/w candidates on average: 8 private slots while that is small, 16 beyond
       // (a lane that runs out sends its tile through the general path, i.e. hashes it twice)
@@ -2699,6 +2725,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     cseg_cap = worst + 1024; // candidate lists were truncated: everything downstream of them is void; run again
   }
   ctx->last_candidates = m;
+  if (accept_all) n_gap = 0; // every accepted k-mer is a candidate: a window without candidates has no minimizer
   ctx->last_gaps = n_gap;
   res.d_j = d_sj;
   res.d_key = d_sk;
@@ -2896,6 +2923,7 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   ctx->cur_summary = nullptr;
   ctx->cur_tile_any = nullptr;
   ctx->last_summary = 0;
+  bool accept_all = false;
   if (!pruned && filter && filter->owned && ctx->summary_mode == 0) {
     uint64_t pc = 0;
     SK_TRY(nts_bf_popcount(ctx, filter, &pc));
@@ -2927,13 +2955,17 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
       ctx->cur_summary_shift = shift;
       ctx->cur_tile_any = d_any;
       ctx->last_summary = shift;
+      // accepted share of the k-mers, for sizing the candidate segments (a retry follows if it was too small)
+      const double own = bits * (1.0 - std::exp(-(double)rt.n_valid / bits));
+      p = own > 0 ? std::min(1.0, (double)pc / own) : 1.0;
+      accept_all = ctx->sketch_mode != 1; // (mode "dense" keeps the key / window kernels, with the summary in front of the probes)
     }
   }
 
   for (int attempt = 0;; ++attempt) {
     SortedOut res;
-    if (pruned)
-      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, prune_c, p, res));
+    if (pruned || accept_all)
+      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, prune_c, p, res, accept_all));
     else
       SK_TRY(run_dense_sorted(ctx, g, *T, k, w, filter, nullptr, nullptr, nullptr, rt.n_valid, "", res));
     const uint64_t count = res.count; // exact, or an upper bound when the count still lives on the device
@@ -2950,7 +2982,7 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
     }
     // the last kernel of the call also clears the pruned pass's control block for the next call (one fill launch less
     // at the head of every sketch)
-    uint64_t* const sel_ctl = pruned ? (uint64_t*)ws_get(ctx, "sel_ctl", (N_SEG + 2) * 8) : nullptr;
+    uint64_t* const sel_ctl = (pruned || accept_all) ? (uint64_t*)ws_get(ctx, "sel_ctl", (N_SEG + 2) * 8) : nullptr;
     if (!res.d_ctl) {
       Mail done(ctx); // nothing to fetch: only the arrival flag
       if (sel_ctl) done.clear_after(sel_ctl, N_SEG + 2);

@@ -264,18 +264,22 @@ def test_sparse_filter_summary_path_matches_oracle(ctx):
     tmp.free()
     bits = common.to_numpy()
     assert 0 < O.bf_fpr(bits) < 0.002
-    ctx.sketch_mode("dense")
     for w in (40, 300, 1000):
         for d, o in zip(dev[:2], ora[:2]):
-            ctx.sketch_summary("auto")
-            a = sketch(ctx, d, k, w, common).to_numpy()
-            assert ctx.sketch_summary() >= 7
-            ctx.sketch_summary("never")
-            b = sketch(ctx, d, k, w, common).to_numpy()
             exp = oracle_flat(O.minimize(o, k, w, bits))
-            for x, y in zip(a, b):
-                assert np.array_equal(x, y)
-            assert np.array_equal(a[0], exp[0]) and np.array_equal(a[2], exp[2]) and a[0].size > 0
+            ctx.sketch_summary("never")
+            ctx.sketch_mode("dense")
+            b = sketch(ctx, d, k, w, common).to_numpy()                # every k-mer probed in HBM
+            ctx.sketch_summary("auto")
+            # "dense": keys + window kernel behind the summary; "auto": the accepted k-mers as the candidate list (k_hash_accept)
+            for mode in ("dense", "auto"):
+                ctx.sketch_mode(mode)
+                a = sketch(ctx, d, k, w, common).to_numpy()
+                assert ctx.sketch_summary() >= 7
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y)
+                assert np.array_equal(a[0], exp[0]) and np.array_equal(a[2], exp[2]) and a[0].size > 0
+    ctx.sketch_mode("auto")
     # masked re-sketch (refinement rounds) through the same path
     ctx.sketch_summary("auto")
     masks = [(0, 1000, 200_000), (3, 0, 50_000)]
