@@ -46,7 +46,7 @@ def main(argv=None):
         rel = []
         for s in seqs:
             a = np.frombuffer(s, dtype=np.uint8).copy()
-            hit = rng.random(a.size) < float(rng.choice([0.005, 0.02, 0.06]))
+            hit = rng.random(a.size) < float(rng.choice([0.005, 0.02, 0.06, 0.15, 0.3]))   # the last two: sparse common filters
             a[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
             rel.append(a.tobytes())
         og2, dg2 = to_oracle(names, rel), to_device(ctx, names, rel)
@@ -75,7 +75,15 @@ def main(argv=None):
             ctx.sketch_mode(mode, c)
             exp = [oracle_flat(O.minimize(o, k, w, want if use_bf else None)) for o in (og, og2)]
             got = [sketch(ctx, d, k, w, bf if use_bf else None).to_numpy() for d in (dg, dg2)]
-            parts = batch.split_minimizers(*sketch(ctx, batch, k, w, bf if use_bf else None).to_numpy())
+            bmx = sketch(ctx, batch, k, w, bf if use_bf else None)
+            parts = batch.split_minimizers(*bmx.to_numpy())
+            dev_parts = bmx.split(batch.rec_base)                  # the same split on the device
+            for hp, dp in zip(parts, dev_parts):
+                if not all(np.array_equal(x, y) for x, y in zip(hp, dp.to_numpy())):
+                    print("SPLIT MISMATCH", dict(k=k, w=w, seed=args.seed, case=n_cases))
+                    sys.exit(1)
+                dp.free()
+            bmx.free()
             n_sketches += 3
             for e, g1, g2 in zip(exp, got, parts):
                 for x, y, z in zip(e, g1, g2):
