@@ -376,8 +376,10 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         log(f"BF size (bytes): {approx}")
         my_sorted = [p for p in ordered if owner[p] == rank]
         bf = backend.bf_new(nbytes, k, world, ones=(world > 1 and not my_sorted))
+        st.mark("bf_allocated")
         if my_sorted:
             backend.bf_insert(bf, genomes[my_sorted[0]])
+            st.mark("bf_first_insert")
             if world == 1:
                 log(f"Bloom filter FPR: {backend.bf_fpr(bf)}")
             if len(my_sorted) > 1:
