@@ -393,10 +393,9 @@ def main():
     valu = None
     if world == 1:
         # VALU roof of the issue-bound kernel: measured issue rate of its instruction mix's slowest member (nts_bench_valu)
-        rows = {kind: ctx.bench_valu(kind, 4, 20000) for kind in ("v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64")}
-        valu = {"cycles_per_wave_instr_per_simd": {n: r["cycles_per_wave_instr_per_simd"] for n, r in rows.items()},
-                "wave_instr_per_s_per_cu": {n: round(r["wave_instr_per_s_per_cu"] / 1e9, 3) for n, r in rows.items()},
-                "unit": "G wave-instructions/s/CU"}
+        rows = {kind: ctx.bench_valu(kind, 8, 20000) for kind in ("v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64")}
+        valu = {"wave_instr_per_s_per_cu": {n: round(r["wave_instr_per_s_per_cu"] / 1e9, 3) for n, r in rows.items()},
+                "unit": "G wave-instructions/s/CU", "how": "nts_bench_valu: 8 waves per SIMD, eight independent chains per lane, wall clock"}
 
     c4_n1 = None
     if world == 1 and name == "c3" and not args.no_c4_leg:
@@ -448,14 +447,24 @@ def main():
             bpb = dense_bpb
         achieved = bpb * per_launch_bases / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
         if valu is not None and pruned_run and a_ms > 0:
-            # 29.7 VALU wave-instructions per 64 k-mers (PMC, profiles/r01_sq_counters.json); the roof: 4 SIMDs per CU each
-            # issuing one wave-instruction every `cycles` shader cycles, as the microbenchmark measures them
-            per_64 = 29.7
+            # VALU wave-instructions per 64 k-mers from the PMC pass (profiles/r02_sq_counters.json); the roof: the issue rate the
+            # microbenchmark measures for the slowest class of the kernel's instruction mix (3-operand / 64-bit integer ops)
+            per_64 = 29.8
+            try:
+                sq = json.load(open(os.path.join(ROOT, "profiles", "r02_sq_counters.json")))
+                per_64 = float(sq["kernels"]["k_hash_select"]["valu_wave_instructions_per_64_kmers"])
+            except (OSError, KeyError, ValueError):
+                pass
             n_cu = 256
             ach_v = per_64 * per_launch_bases / 64.0 / (a_ms * 1e-3) / n_cu / 1e9
-            peak_v = min(valu["wave_instr_per_s_per_cu"].values())
+            # the rolling step is ~12 two-operand 32-bit operations (xor / and / shift class) and ~17 three-operand or 64-bit ones
+            # (alignbit, bfi, lshl_add_u64 class): the roof of that mix
+            fast, slow = valu["wave_instr_per_s_per_cu"]["v_xor_b32"], min(valu["wave_instr_per_s_per_cu"]["v_alignbit_b32"],
+                                                                           valu["wave_instr_per_s_per_cu"]["v_lshl_add_u64"])
+            peak_v = 29.0 / (12.0 / fast + 17.0 / slow)
             valu.update({"kernel": "k_hash_select", "valu_wave_instr_per_64_kmers": per_64, "achieved": round(ach_v, 3),
-                         "peak": peak_v, "frac": round(ach_v / peak_v, 3)})
+                         "peak": round(peak_v, 3), "frac": round(ach_v / peak_v, 3),
+                         "peak_if_all_slow_class": slow, "peak_if_all_fast_class": fast})
         out = {
             "metric": "minimizer-sketch Gbases/s (sketch with common Bloom filter, inputs resident in HBM)",
             "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
