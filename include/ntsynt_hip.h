@@ -359,6 +359,24 @@ void nts_blocks_free(nts_blocks* b);
 int nts_engine_paths(const nts_engine* eng, uint64_t* n_paths, uint64_t* n_verts);
 int nts_engine_read(nts_ctx* ctx, const nts_engine* eng, const char* field, void* dst, uint64_t bytes);
 
+/* ---- block-level rules over flat tables (host side, no GPU work): what is left of the reference's per-object Python once the
+ * graph lives in HBM -- sequential where the reference's rule is order dependent.
+ * nts_bubble_rule : run_graph_simplification (bin/ntsynt_synteny.py:566-590) over nts_engine_bubbles' table; doomed[i] /
+ *     promoted[i] (caller-allocated, n_cand entries) = middle vertex and candidate edge of the i-th bubble, *n_out of them.
+ * nts_blocks_merge: merge_collinear_blocks (S:428-472) in place over blocks sorted like SyntenyBlock.__lt__; tables are
+ *     [a * n + b]; ori 0 '+' 1 '-'; reason 0 None, 1 id_change, 2 ori_change, 3 inconsistent_order, 4 indel, 5 merge.
+ * nts_blocks_text : get_block_string (bin/synteny_block.py:72-85) for a table: blocks shorter than z in any assembly skipped,
+ *     the others numbered from 0, rows in out_order; `reason` != NULL adds the verbose column.  names = NUL-separated
+ *     strings: the G assembly names, then every assembly's contig names; contig_base[a] = index of assembly a's first contig
+ *     among the contig names.  *text is released with nts_free. */
+int nts_bubble_rule(uint64_t n_cand, const uint32_t* cand_edge, uint64_t n_inc, const uint32_t* inc_edge, const uint32_t* inc_u,
+                    const uint32_t* inc_v, const uint32_t* inc_w, uint32_t wmax, uint32_t* doomed, uint32_t* promoted, uint64_t* n_out);
+int nts_blocks_merge(uint32_t n_asm, uint64_t n, int64_t k, int64_t bp, int64_t collinear_merge, uint32_t* rec, int64_t* first,
+                     int64_t* last, uint8_t* ori, int64_t* n_mx, uint8_t* reason, uint64_t* n_out, uint64_t* n_merged);
+int nts_blocks_text(uint32_t n_asm, uint64_t n, int64_t k, int64_t z, const uint32_t* out_order, const char* names, uint64_t names_bytes,
+                    const uint64_t* contig_base, const uint32_t* rec, const int64_t* first, const int64_t* last, const uint8_t* ori,
+                    const int64_t* n_mx, const uint8_t* reason, char** text, uint64_t* text_bytes);
+
 /* Host-side helper (no GPU work): connected components of an undirected graph given as edge arrays
  * that are simple paths (two degree-1 ends, everything else degree 2, at least 2 vertices) -- what
  * Ntjoin.find_paths keeps.  Path i is verts[off[i] .. off[i+1]); each path starts at its end with the

@@ -127,6 +127,11 @@ SYMBOLS = [
     ("nts_blocks_free", None, [ctypes.POINTER(Blocks)]),
     ("nts_engine_paths", ctypes.c_int, [c_vp, c_u64p, c_u64p]),
     ("nts_engine_read", ctypes.c_int, [c_vp, c_vp, ctypes.c_char_p, c_vp, u64]),
+    ("nts_bubble_rule", ctypes.c_int, [u64, c_vp, u64, c_vp, c_vp, c_vp, c_vp, u32, c_vp, c_vp, c_u64p]),
+    ("nts_blocks_merge", ctypes.c_int, [u32, u64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_u64p, c_u64p]),
+    ("nts_blocks_text", ctypes.c_int, [u32, u64, ctypes.c_int64, ctypes.c_int64, c_vp, ctypes.c_char_p, u64, c_vp, c_vp, c_vp, c_vp,
+                                       c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), c_u64p]),
     ("nts_walk_chains", ctypes.c_int, [u64, u64, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_u32p), c_u64p]),
     ("nts_walk_paths", ctypes.c_int, [u64, u64, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_u64p), ctypes.POINTER(c_i64p), c_u64p]),
     ("nts_edge_degrees", ctypes.c_int, [u64, u64, c_vp, c_vp, c_vp, c_vp]),

@@ -647,3 +647,214 @@ extern "C" int nts_path_scan(uint32_t n_asm, uint64_t nv, const int64_t* v_rec, 
   }
   return bad.load() ? NTS_EINVAL : NTS_OK;
 }
+
+// ---- block-level rules of the graph stage as array passes (rows C3, C10, C12-merge) ---------------------------------------------
+// The HBM-resident engine (nts_engine_*) returns tables with a few numbers per block / candidate edge; at 10^5 blocks the
+// reference's per-object Python over them (bin/ntsynt_synteny.py:428-472, 566-590; bin/synteny_block.py:72-109) is what is left
+// of the stage's wall clock.  These helpers are the same rules over flat arrays, sequential where the reference's rule is
+// order dependent.
+
+// run_graph_simplification (bin/ntsynt_synteny.py:566-590) over the table nts_engine_bubbles returns: candidate edges in
+// ascending order (= the reference's edge order), and every live edge incident to one of their end points (ascending too).
+// For a candidate (s, t): if s and t each have exactly one incident edge of weight wmax and exactly one common neighbour m,
+// then m is doomed and the candidate's weight becomes wmax -- which later candidates see (S:586).
+extern "C" int nts_bubble_rule(uint64_t n_cand, const uint32_t* cand_edge, uint64_t n_inc, const uint32_t* inc_edge, const uint32_t* inc_u,
+                               const uint32_t* inc_v, const uint32_t* inc_w, uint32_t wmax, uint32_t* doomed, uint32_t* promoted,
+                               uint64_t* n_out)
+{
+  if (!n_out || (n_cand && (!cand_edge || !doomed || !promoted)) || (n_inc && (!inc_edge || !inc_u || !inc_v || !inc_w))) return NTS_EINVAL;
+  *n_out = 0;
+  if (n_cand == 0 || n_inc == 0) return NTS_OK;
+  // vertices of the table, numbered densely
+  std::vector<uint32_t> verts;
+  verts.reserve(2 * n_inc);
+  for (uint64_t i = 0; i < n_inc; ++i) {
+    verts.push_back(inc_u[i]);
+    verts.push_back(inc_v[i]);
+  }
+  std::sort(verts.begin(), verts.end());
+  verts.erase(std::unique(verts.begin(), verts.end()), verts.end());
+  auto vid = [&](uint32_t v) { return (uint32_t)(std::lower_bound(verts.begin(), verts.end(), v) - verts.begin()); };
+  const size_t nv = verts.size();
+  // adjacency in CSR form; a later edge between the same pair replaces the earlier one (dict assignment), which cannot happen
+  // among live edges but is kept
+  std::vector<uint32_t> deg(nv + 1, 0), lu(n_inc), lv(n_inc);
+  for (uint64_t i = 0; i < n_inc; ++i) {
+    lu[i] = vid(inc_u[i]);
+    lv[i] = vid(inc_v[i]);
+    ++deg[lu[i] + 1];
+    ++deg[lv[i] + 1];
+  }
+  for (size_t v = 0; v < nv; ++v) deg[v + 1] += deg[v];
+  std::vector<uint32_t> fill(deg.begin(), deg.end() - 1), nb(2 * n_inc), ne(2 * n_inc);
+  for (uint64_t i = 0; i < n_inc; ++i) {
+    nb[fill[lu[i]]] = lv[i];
+    ne[fill[lu[i]]++] = (uint32_t)i;
+    nb[fill[lv[i]]] = lu[i];
+    ne[fill[lv[i]]++] = (uint32_t)i;
+  }
+  std::vector<uint32_t> w(inc_w, inc_w + n_inc);
+  auto full_edges = [&](uint32_t v) {
+    uint32_t c = 0;
+    for (uint32_t q = deg[v]; q < deg[v + 1]; ++q) c += w[ne[q]] == wmax;
+    return c;
+  };
+  uint64_t out = 0;
+  for (uint64_t c = 0; c < n_cand; ++c) {
+    const uint32_t* at = std::lower_bound(inc_edge, inc_edge + n_inc, cand_edge[c]);
+    if (at == inc_edge + n_inc || *at != cand_edge[c]) return NTS_EINVAL; // a candidate is incident to its own end points
+    const uint64_t i = (uint64_t)(at - inc_edge);
+    const uint32_t s = lu[i], t = lv[i];
+    if (full_edges(s) != 1 || full_edges(t) != 1) continue;
+    uint32_t n_common = 0, common = 0;
+    for (uint32_t q = deg[s]; q < deg[s + 1]; ++q) {
+      const uint32_t u = nb[q];
+      if (u == t) continue;
+      bool also = false;
+      for (uint32_t r = deg[t]; r < deg[t + 1]; ++r) also |= nb[r] == u;
+      if (also) {
+        ++n_common;
+        common = u;
+      }
+    }
+    if (n_common != 1) continue;
+    doomed[out] = verts[common];
+    promoted[out] = cand_edge[c];
+    ++out;
+    w[i] = wmax;
+  }
+  *n_out = out;
+  return NTS_OK;
+}
+
+namespace {
+inline int64_t blk_start(const int64_t* f, const int64_t* l, uint64_t i) { return std::min(f[i], l[i]); }
+inline int64_t blk_end(const int64_t* f, const int64_t* l, uint64_t i, int64_t k) { return std::max(f[i], l[i]) + k; }
+} // namespace
+
+// merge_collinear_blocks (bin/ntsynt_synteny.py:428-472) over blocks sorted like SyntenyBlock.__lt__: tables are [a * n + b]
+// (assembly-major); ori codes 0 '+', 1 '-'; reason codes 0 None, 1 id_change, 2 ori_change, 3 inconsistent_order, 4 indel,
+// 5 merge.  Works in place: the first *n_out blocks of every table are the result (a merged block keeps its first block's
+// contigs, orientations, first positions and reason, takes the last block's last positions and the sum of the counts).
+extern "C" int nts_blocks_merge(uint32_t G, uint64_t n, int64_t k, int64_t bp, int64_t collinear_merge, uint32_t* rec, int64_t* first,
+                                int64_t* last, uint8_t* ori, int64_t* n_mx, uint8_t* reason, uint64_t* n_out, uint64_t* n_merged)
+{
+  if (!n_out || G == 0 || (n && (!rec || !first || !last || !ori || !n_mx || !reason))) return NTS_EINVAL;
+  uint64_t merged = 0;
+  if (n == 0) {
+    *n_out = 0;
+    if (n_merged) *n_merged = 0;
+    return NTS_OK;
+  }
+  // cur = slot `o` (being built in place: o <= b always, so nothing unread is overwritten)
+  uint64_t o = 0;
+  for (uint64_t b = 1; b < n; ++b) {
+    bool same_ori = true, same_ctg = true, negative = false;
+    int64_t d_min = INT64_MAX, d_max = INT64_MIN;
+    for (uint32_t a = 0; a < G; ++a) {
+      const uint64_t ic = (uint64_t)a * n + o, ib = (uint64_t)a * n + b;
+      same_ori &= ori[ic] == ori[ib];
+      same_ctg &= rec[ic] == rec[ib];
+      const int64_t d = (ori[ic] == 1 && ori[ib] == 1) ? blk_start(first, last, ic) - blk_end(first, last, ib, k)
+                                                       : blk_start(first, last, ib) - blk_end(first, last, ic, k);
+      d_min = std::min(d_min, d);
+      d_max = std::max(d_max, d);
+      negative |= d < 0;
+    }
+    const int64_t spread = d_max - d_min;
+    if (!same_ori || !same_ctg || spread > bp - k || d_max >= collinear_merge) {
+      uint8_t why = reason[b];
+      if (!same_ctg)
+        why = 1;
+      else if (!same_ori)
+        why = 2;
+      else if (negative)
+        why = 3;
+      else if (spread > bp - k)
+        why = 4;
+      else if (d_max >= collinear_merge)
+        why = 5;
+      ++o;
+      for (uint32_t a = 0; a < G; ++a) {
+        const uint64_t io = (uint64_t)a * n + o, ib = (uint64_t)a * n + b;
+        rec[io] = rec[ib];
+        first[io] = first[ib];
+        last[io] = last[ib];
+        ori[io] = ori[ib];
+      }
+      n_mx[o] = n_mx[b];
+      reason[o] = why;
+    } else {
+      for (uint32_t a = 0; a < G; ++a) last[(uint64_t)a * n + o] = last[(uint64_t)a * n + b]; // minimizers.extend(): only ends and count matter
+      n_mx[o] += n_mx[b];
+      ++merged;
+    }
+  }
+  *n_out = o + 1;
+  if (n_merged) *n_merged = merged;
+  return NTS_OK;
+}
+
+// get_block_string (bin/synteny_block.py:72-85) for a whole table: blocks shorter than z in any assembly are skipped, the others
+// numbered from 0; rows of a block in `out_order` (assemblies by name); with `reason` the verbose column.  names: NUL-separated
+// strings -- assembly names [G], then the contig names of assembly 0, 1, ...; contig_base[a] = index of assembly a's first contig
+// name among them.  Returns a malloc'ed buffer (nts_free).
+extern "C" int nts_blocks_text(uint32_t G, uint64_t n, int64_t k, int64_t z, const uint32_t* out_order, const char* names, uint64_t names_bytes,
+                               const uint64_t* contig_base, const uint32_t* rec, const int64_t* first, const int64_t* last, const uint8_t* ori,
+                               const int64_t* n_mx, const uint8_t* reason, char** text, uint64_t* text_bytes)
+{
+  if (!text || !text_bytes || G == 0 || !out_order || !names || !contig_base || (n && (!rec || !first || !last || !ori || !n_mx))) return NTS_EINVAL;
+  std::vector<const char*> str;
+  for (uint64_t i = 0; i < names_bytes;) {
+    str.push_back(names + i);
+    i += strlen(names + i) + 1;
+  }
+  static const char* const REASON[6] = { "None", "id_change", "ori_change", "inconsistent_order", "indel", "merge" };
+  std::string out;
+  out.reserve(n * G * 48);
+  char num[32];
+  uint64_t id = 0;
+  for (uint64_t b = 0; b < n; ++b) {
+    bool keep = true;
+    for (uint32_t a = 0; a < G; ++a) {
+      const int64_t d = first[(uint64_t)a * n + b] - last[(uint64_t)a * n + b];
+      keep &= (d < 0 ? -d : d) >= z - k; // end - start = |first - last| + k
+    }
+    if (!keep) continue;
+    for (uint32_t q = 0; q < G; ++q) {
+      const uint32_t a = out_order[q];
+      const uint64_t i = (uint64_t)a * n + b;
+      const uint64_t ci = G + contig_base[a] + rec[i];
+      if (a >= str.size() || ci >= str.size()) return NTS_EINVAL;
+      char* e = put_u64(num, id);
+      out.append(num, e - num);
+      out.push_back('\t');
+      out.append(str[a]);
+      out.push_back('\t');
+      out.append(str[ci]);
+      out.push_back('\t');
+      e = put_u64(num, (uint64_t)blk_start(first, last, i));
+      out.append(num, e - num);
+      out.push_back('\t');
+      e = put_u64(num, (uint64_t)blk_end(first, last, i, k));
+      out.append(num, e - num);
+      out.push_back('\t');
+      out.push_back(ori[i] == 0 ? '+' : ori[i] == 1 ? '-' : '?');
+      out.push_back('\t');
+      e = put_u64(num, (uint64_t)n_mx[b]);
+      out.append(num, e - num);
+      if (reason) {
+        out.push_back('\t');
+        out.append(REASON[reason[b] < 6 ? reason[b] : 0]);
+      }
+      out.push_back('\n');
+    }
+    ++id;
+  }
+  char* buf = (char*)malloc(std::max<size_t>(out.size(), 1));
+  if (!buf) return NTS_ENOMEM;
+  memcpy(buf, out.data(), out.size());
+  *text = buf;
+  *text_bytes = out.size();
+  return NTS_OK;
+}

@@ -416,9 +416,13 @@ def sketch(ctx, genome, k, w, bf=None, masks=None):
     n_mask, arr = 0, None
     if masks is not None and len(masks):
         n_mask = len(masks)
-        arr = (Interval * n_mask)()
-        for i, (r, s, e) in enumerate(masks):
-            arr[i].rec, arr[i].start, arr[i].end = int(r), int(s), int(e)
+        if isinstance(masks, np.ndarray) and masks.dtype.itemsize == ctypes.sizeof(Interval) and masks.dtype.names:
+            masks = np.ascontiguousarray(masks)                 # already in nts_interval's layout (synteny_device.INTERVAL_DTYPE)
+            arr = ctypes.cast(masks.ctypes.data, ctypes.POINTER(Interval))
+        else:
+            arr = (Interval * n_mask)()
+            for i, (r, s, e) in enumerate(masks):
+                arr[i].rec, arr[i].start, arr[i].end = int(r), int(s), int(e)
     h = c_vp()
     ctx.check(ctx.lib.nts_sketch(ctx.h, genome.h, int(k), int(w), bf.h if bf is not None else None,
                                  arr, n_mask, ctypes.byref(h)), "nts_sketch")

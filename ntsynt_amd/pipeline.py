@@ -211,7 +211,15 @@ class GpuBackend:
         batch = self._batch[1]
         joined = None
         if masks:
-            joined = [(int(r) + int(batch.rec_base[i]), s, e) for i, m in enumerate(masks) for r, s, e in (m or [])]
+            if all(isinstance(m, np.ndarray) for m in masks):   # Interval arrays: shift the record numbers, concatenate
+                parts_iv = []
+                for i, m in enumerate(masks):
+                    m = m.copy()
+                    m["rec"] += np.uint32(batch.rec_base[i])
+                    parts_iv.append(m)
+                joined = np.concatenate(parts_iv) if parts_iv else None
+            else:
+                joined = [(int(r) + int(batch.rec_base[i]), s, e) for i, m in enumerate(masks) for r, s, e in (m if m is not None else [])]
         mx = sketch(self.ctx, batch, k, w, bf, joined)
         parts = mx.split(batch.rec_base)
         mx.free()

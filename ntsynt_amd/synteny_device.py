@@ -14,9 +14,11 @@ import numpy as np
 
 from . import _lib
 from ._lib import c_vp, u64
-from .synteny import Block, SyntenyEngine
+from .synteny import MX_SUFFIX, SyntenyEngine
 
 IV_OFF = np.int64(1) << 40            # composite interval key: record * 2^40 + position (same as synteny.py)
+# memory layout of nts_interval (include/ntsynt_hip.h): hard-mask intervals travel as one array
+INTERVAL_DTYPE = np.dtype({"names": ["rec", "start", "end"], "formats": ["<u4", "<u8", "<u8"], "offsets": [0, 8, 16], "itemsize": 24})
 
 
 class DeviceGraph:
@@ -130,6 +132,8 @@ class DeviceSyntenyEngine(SyntenyEngine):
         self.ctx = ctx
         self.sketch_dev_fn = sketch_dev_fn
         self.graph = DeviceGraph(ctx, self.G, self.ref)
+        self._ctg_rank = None
+        self._blob = None
 
     def _instrument(self):
         import time
@@ -143,7 +147,7 @@ class DeviceSyntenyEngine(SyntenyEngine):
                     self.times[name] = self.times.get(name, 0.0) + time.perf_counter() - t0
             return timed
         for name in ("_add", "_simplify_dev", "_filter", "_erode", "_blocks", "_sorted", "_emit", "_merge", "_mask_intervals", "_spans",
-                     "_sketch_round"):
+                     "_sketch_round", "_long_mask"):
             setattr(self, name, wrap(name, getattr(self, name)))
 
     # ------------------------------------------------------------------ device steps
@@ -151,31 +155,21 @@ class DeviceSyntenyEngine(SyntenyEngine):
         self.graph.add(lists, spans)
 
     def _simplify_dev(self, apply_deletions):
-        "run_graph_simplification (S:548-590) on the table of candidate edges and their neighbourhood"
+        "run_graph_simplification (S:548-590) on the table of candidate edges and their neighbourhood (nts_bubble_rule)"
         cand, inc_e, inc_u, inc_v, inc_w = self.graph.bubbles()
         if cand.size == 0:
             return
         wmax = self.G                                          # sum of the weights, all 1 (S:32, S:571)
-        adj, ends, weight = {}, {}, {}
-        for e, u, v, wt in zip(inc_e.tolist(), inc_u.tolist(), inc_v.tolist(), inc_w.tolist()):   # ascending edge index
-            adj.setdefault(u, {})[v] = e
-            adj.setdefault(v, {})[u] = e
-            ends[e] = (u, v)
-            weight[e] = wt
-        doomed, promoted = [], []
-        for e in sorted(cand.tolist()):                        # ascending edge index = reference edge order
-            s, t = ends[e]
-            if [weight[x] for x in adj[s].values()].count(wmax) != 1:
-                continue
-            if [weight[x] for x in adj[t].values()].count(wmax) != 1:
-                continue
-            common = [u for u in adj[s] if u != t and u in adj[t]]
-            if len(common) == 1:
-                doomed.append(common[0])
-                self.stats["bubbles"] += 1
-                weight[e] = wmax                               # seen by the candidates that follow (S:586)
-                promoted.append(e)
-        self.graph.apply(doomed if apply_deletions else [], promoted, wmax)
+        cand = np.ascontiguousarray(np.sort(cand), dtype=np.uint32)      # ascending edge index = reference edge order
+        doomed = np.empty(cand.size, np.uint32)
+        promoted = np.empty(cand.size, np.uint32)
+        n = u64()
+        rc = self.ctx.lib.nts_bubble_rule(cand.size, cand.ctypes.data, inc_e.size, inc_e.ctypes.data, inc_u.ctypes.data, inc_v.ctypes.data,
+                                          inc_w.ctypes.data, wmax, doomed.ctypes.data, promoted.ctypes.data, ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"nts_bubble_rule failed ({rc})")
+        self.stats["bubbles"] += n.value
+        self.graph.apply(doomed[:n.value] if apply_deletions else [], promoted[:n.value], wmax)
 
     def _filter(self, flag):
         return self.graph.filter(self.n, flag)
@@ -183,26 +177,102 @@ class DeviceSyntenyEngine(SyntenyEngine):
     def _erode(self):
         self.stats["eroded_edges"] += self.graph.erode(self.k)
 
+    # ------------------------------------------------------------------ block tables (arrays, [assembly, block])
+    # A round's blocks stay a table -- rec, first_pos, last_pos, ori (0 '+', 1 '-') per assembly, n_mx and reason per block --
+    # from nts_engine_blocks to the TSV text; sort, length rule, mask intervals and interval keys are array passes, the
+    # order-dependent merge and the text are native (nts_blocks_merge, nts_blocks_text).
     def _blocks(self):
         tb = self.graph.blocks(self.bp, self.m, 4)
         self.stats["unoriented"] += tb["unoriented"]
         self.stats["indel_cuts"] += tb["indel_cuts"]
         self.stats["small_blocks"] += tb["small"]
-        self.last_table = tb
         n = tb["n"]
-        if n == 0:
-            return []
-        sym = "+-?"
-        recs = tb["rec"].T.tolist()
-        oris = tb["ori"].T.tolist()
-        fps = tb["first_pos"].T.tolist()
-        lps = tb["last_pos"].T.tolist()
-        nmx = tb["n_mx"].tolist()
-        return [Block(None, recs[i], [sym[c] for c in oris[i]], None, fps[i], lps[i], nmx[i]) for i in range(n)]
+        return {"n": n, "rec": tb["rec"], "first_pos": tb["first_pos"], "last_pos": tb["last_pos"], "ori": tb["ori"],
+                "n_mx": tb["n_mx"].astype(np.int64), "reason": np.zeros(n, np.uint8)}
 
-    def _spans(self, blocks):
+    @staticmethod
+    def _take(tb, idx):
+        out = {"n": int(len(idx))}
+        for key in ("rec", "first_pos", "last_pos", "ori"):
+            out[key] = np.ascontiguousarray(tb[key][:, idx])
+        for key in ("n_mx", "reason"):
+            out[key] = np.ascontiguousarray(tb[key][idx])
+        return out
+
+    def _sorted(self, tb):
+        "SyntenyBlock.__lt__ (synteny_block.py:102-109): by (contig name, start) in the lexicographically smallest assembly"
+        if tb["n"] == 0:
+            return tb
+        if self._ctg_rank is None:
+            names = self.contigs[self.ref]
+            rank = {nm: i for i, nm in enumerate(sorted(set(names)))}
+            self._ctg_rank = np.array([rank[nm] for nm in names], np.int64)
+        ref = self.ref
+        start = np.minimum(tb["first_pos"][ref], tb["last_pos"][ref])
+        return self._take(tb, np.lexsort((start, self._ctg_rank[tb["rec"][ref]])))
+
+    def _long_mask(self, tb):
+        return (np.abs(tb["first_pos"] - tb["last_pos"]) >= self.z - self.k).all(axis=0)   # end - start = |first - last| + k
+
+    def _names_blob(self):
+        if self._blob is None:
+            asm = []
+            for f in self.files:
+                mt = MX_SUFFIX.search(f)
+                asm.append(mt.group(1) if mt else f)
+            base = np.concatenate(([0], np.cumsum([len(c) for c in self.contigs])[:-1])).astype(np.uint64)
+            text = "\0".join(asm + [nm for c in self.contigs for nm in c]) + "\0"
+            self._blob = (text.encode(), base, np.array(self.out_order, np.uint32))
+        return self._blob
+
+    def _emit(self, name, tb, verbose=False):
+        blob, base, order = self._names_blob()
+        buf, nbytes = c_vp(), u64()
+        n = tb["n"]
+        arrs = [np.ascontiguousarray(tb[key]) for key in ("rec", "first_pos", "last_pos", "ori", "n_mx", "reason")]
+        rc = self.ctx.lib.nts_blocks_text(self.G, n, self.k, self.z, order.ctypes.data, blob, len(blob), base.ctypes.data,
+                                          arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data,
+                                          arrs[4].ctypes.data, arrs[5].ctypes.data if verbose else None, ctypes.byref(buf),
+                                          ctypes.byref(nbytes))
+        if rc != 0:
+            raise RuntimeError(f"nts_blocks_text failed ({rc})")
+        raw = ctypes.string_at(buf, nbytes.value)
+        self.ctx.lib.nts_free(buf)
+        self.outputs[name] = raw.decode()
+        with open(name, "wb") as fh:
+            fh.write(raw)
+
+    def _merge(self, tb):
+        "merge_collinear_blocks (S:428-472) over a sorted table"
+        if tb["n"] == 0:
+            return tb
+        out = {key: np.array(tb[key], copy=True, order="C") for key in ("rec", "first_pos", "last_pos", "ori", "n_mx", "reason")}
+        n_out, n_merged = u64(), u64()
+        rc = self.ctx.lib.nts_blocks_merge(self.G, tb["n"], self.k, self.bp, self.collinear_merge, out["rec"].ctypes.data,
+                                           out["first_pos"].ctypes.data, out["last_pos"].ctypes.data, out["ori"].ctypes.data,
+                                           out["n_mx"].ctypes.data, out["reason"].ctypes.data, ctypes.byref(n_out), ctypes.byref(n_merged))
+        if rc != 0:
+            raise RuntimeError(f"nts_blocks_merge failed ({rc})")
+        self.stats["merged"] += n_merged.value
+        out["n"] = tb["n"]
+        return self._take(out, np.arange(n_out.value))
+
+    def _mask_intervals(self, tb, w):
+        "hard-mask intervals of the next re-sketch (S:134-146) per assembly, as Interval arrays (record, start, end)"
+        lim = max(2 * w, w + self.k + 1)
+        out = []
+        for a in range(self.G):
+            s = np.minimum(tb["first_pos"][a], tb["last_pos"][a])
+            e = np.maximum(tb["first_pos"][a], tb["last_pos"][a]) + self.k
+            s2, e2 = s + (w + self.k), e - (w + self.k)
+            ok = (e - s > lim) & (e2 > s2)
+            iv = np.zeros(int(ok.sum()), dtype=INTERVAL_DTYPE)
+            iv["rec"], iv["start"], iv["end"] = tb["rec"][a][ok], s2[ok], e2[ok]
+            out.append(iv)
+        return out
+
+    def _spans(self, tb):
         "block interiors [min+1, max) per assembly as sorted composite keys + running maximum of the ends (S:194-203)"
-        tb = self.last_table
         out = []
         for a in range(self.G):
             p0, p1 = tb["first_pos"][a], tb["last_pos"][a]
@@ -215,6 +285,14 @@ class DeviceSyntenyEngine(SyntenyEngine):
             comp_mx = np.maximum.accumulate((ir * IV_OFF + iv_e)[order]) if order.size else comp_s
             out.append((comp_s.astype(np.uint64), comp_mx.astype(np.uint64)))
         return out
+
+    @staticmethod
+    def rows(tb):
+        "a table as sorted tuples (tests compare it with the host-array engine's Block objects)"
+        sym = "+-?"
+        return sorted((tuple(tb["rec"][:, i].tolist()), tuple(sym[c] for c in tb["ori"][:, i].tolist()),
+                       tuple(tb["first_pos"][:, i].tolist()), tuple(tb["last_pos"][:, i].tolist()), int(tb["n_mx"][i]))
+                      for i in range(tb["n"]))
 
     def _sketch_round(self, masks, new_w):
         got = self.sketch_dev_fn({self.input_order[a]: masks[a] for a in range(self.G)}, new_w)
@@ -236,7 +314,7 @@ class DeviceSyntenyEngine(SyntenyEngine):
             self._filter(flag=False)
         blocks = self._blocks()
         ordered = self._sorted(blocks)
-        if not ordered:
+        if ordered["n"] == 0:
             print("Error - no paths found. Try adjusting the specified k/w parameters.")
             sys.exit(1)
         self._emit(f"{self.prefix}.synteny_blocks.tsv", ordered)
@@ -259,10 +337,10 @@ class DeviceSyntenyEngine(SyntenyEngine):
             blocks = self._blocks()
             ordered = self._sorted(blocks)
             self._emit(f"{self.prefix}.pre-collinear-merge.synteny_blocks.tsv", ordered)
-            if last and ordered:
+            if last and ordered["n"]:
                 merged = self._merge(ordered)
-                merged = [b for b in merged if self._long_enough(b)]
-                if merged:
+                merged = self._take(merged, np.flatnonzero(self._long_mask(merged)))
+                if merged["n"]:
                     merged = self._merge(merged)
                 self._emit(f"{self.prefix}.synteny_blocks.tsv", merged, verbose=True)
             prev_w = new_w

@@ -314,3 +314,137 @@ def test_unoriented_block_is_deleted_in_situ(tmp_path):
         assert got[name] == exp[name], name
     final = got["p.synteny_blocks.tsv"]
     assert "\tc1\t" not in final and "\tc2\t" in final and "\tc3\t" in final     # the c1 block is gone, the others stay
+
+
+def test_native_block_rules_match_the_python_rules():
+    """nts_blocks_merge / nts_blocks_text / nts_bubble_rule (array passes the HBM-resident engine uses) against the
+    Block-object rules of ntsynt_amd/synteny.py on random tables -- which the oracle tests pin in turn."""
+    import ctypes
+
+    from ntsynt_amd import _lib
+    from ntsynt_amd.synteny import Block
+    lib = _lib.load()
+    rng = np.random.default_rng(12)
+    G, k = 3, 24
+    files = ["c.fa.k24.w100.tsv", "a.fa.k24.w100.tsv", "b.fa.k24.w100.tsv"]
+    contigs = [[f"ctg{j}_{a}" for j in range(5)] for a in range(G)]
+    total_merged = 0
+    for trial in range(30):
+        n = int(rng.integers(1, 60))
+        eng = SyntenyEngine(files, contigs, k, 100, [], int(rng.choice([50, 500, 5000])), [300, 3000, "30w"][trial % 3],
+                            int(rng.choice([100, 400])), "x", None, None, None)
+        # sorted blocks on one or two contigs, mostly collinear with the odd break
+        blocks, pos = [], np.zeros(G, np.int64)
+        for i in range(n):
+            rec = [int(rng.integers(0, 2))] * G if rng.random() < 0.9 else [int(rng.integers(0, 5)) for _ in range(G)]
+            ori = ["+"] * G if rng.random() < 0.8 else [str(rng.choice(["+", "-"])) for _ in range(G)]
+            length = rng.integers(50, 3000, size=G)
+            gap = rng.integers(-30, 2500, size=G) if rng.random() < 0.3 else np.full(G, int(rng.integers(1, 400)))
+            first = pos + gap
+            last = first + length
+            pos = last + k
+            fp = [int(last[a]) if ori[a] == "-" else int(first[a]) for a in range(G)]
+            lp = [int(first[a]) if ori[a] == "-" else int(last[a]) for a in range(G)]
+            blocks.append(Block(None, rec, ori, None, fp, lp, int(rng.integers(4, 50))))
+        ordered = eng._sorted(list(blocks))
+
+        def table(bl):
+            return (np.array([[b.rec[a] for b in bl] for a in range(G)], np.uint32), np.array([[b.first_pos[a] for b in bl] for a in range(G)], np.int64),
+                    np.array([[b.last_pos[a] for b in bl] for a in range(G)], np.int64),
+                    np.array([["+-".index(b.ori[a]) for b in bl] for a in range(G)], np.uint8), np.array([b.n_mx for b in bl], np.int64),
+                    np.zeros(len(bl), np.uint8))
+        # engine index order of the table rows = eng.files order (descending names)
+        eo = [files.index(f) for f in eng.files]
+        for b in ordered:
+            b.rec, b.ori = [b.rec[i] for i in eo], [b.ori[i] for i in eo]
+            b.first_pos, b.last_pos = [b.first_pos[i] for i in eo], [b.last_pos[i] for i in eo]
+        rec, first, last, ori, n_mx, reason = [np.ascontiguousarray(x) for x in table(ordered)]
+        names = [SO.MX_SUFFIX.search(f).group(1) for f in eng.files] + [nm for a in range(G) for nm in eng.contigs[a]]
+        blob = ("\0".join(names) + "\0").encode()
+        base = np.arange(G, dtype=np.uint64) * 5
+        order = np.array(eng.out_order, np.uint32)
+
+        def text(nn, verbose):
+            buf, nb = ctypes.c_void_p(), ctypes.c_uint64()
+            assert lib.nts_blocks_text(G, nn, k, eng.z, order.ctypes.data, blob, len(blob), base.ctypes.data, rec.ctypes.data, first.ctypes.data,
+                                       last.ctypes.data, ori.ctypes.data, n_mx.ctypes.data, reason.ctypes.data if verbose else None,
+                                       ctypes.byref(buf), ctypes.byref(nb)) == 0
+            out = ctypes.string_at(buf, nb.value).decode()
+            lib.nts_free(buf)
+            return out
+        cwd = os.getcwd()
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            os.chdir(td)
+            try:
+                eng._emit("pre.tsv", ordered)
+                assert text(n, False) == eng.outputs["pre.tsv"]
+                merged = eng._merge(ordered)
+                n_out, n_merged = ctypes.c_uint64(), ctypes.c_uint64()
+                assert lib.nts_blocks_merge(G, n, k, eng.bp, eng.collinear_merge, rec.ctypes.data, first.ctypes.data, last.ctypes.data,
+                                            ori.ctypes.data, n_mx.ctypes.data, reason.ctypes.data, ctypes.byref(n_out), ctypes.byref(n_merged)) == 0
+                assert n_out.value == len(merged) and n_merged.value == eng.stats["merged"]
+                total_merged += n_merged.value
+                # the in-place tables keep the stride n: compare through the verbose text of the first n_out blocks
+                rec, first, last, ori = [np.ascontiguousarray(x[:, :n_out.value]) for x in (rec, first, last, ori)]
+                n_mx, reason = np.ascontiguousarray(n_mx[:n_out.value]), np.ascontiguousarray(reason[:n_out.value])
+                eng._emit("post.tsv", merged, verbose=True)
+                assert text(n_out.value, True) == eng.outputs["post.tsv"]
+            finally:
+                os.chdir(cwd)
+    assert total_merged > 50
+    # bubble rule: random small graphs, against the dict-based rule of SyntenyEngine._simplify
+    total_bubbles = 0
+    for trial in range(400):
+        nv = int(rng.integers(6, 40))
+        weights = {}
+        if trial % 2:
+            # a backbone of full-weight edges with bubbles (s - t light, s - m - t) every few steps, adjacent ones included,
+            # plus a little noise: what the minimizer graph looks like around small rearrangements
+            spine, nxt = list(range(nv)), nv
+            for i in range(nv - 1):
+                if rng.random() < 0.35:
+                    weights[(spine[i], spine[i + 1])] = int(rng.integers(1, 3))
+                    weights[(spine[i], nxt)] = int(rng.integers(1, 4))
+                    weights[(spine[i + 1], nxt)] = int(rng.integers(1, 4))
+                    nxt += 1
+                else:
+                    weights[(spine[i], spine[i + 1])] = 3
+            for _ in range(int(rng.integers(0, 4))):
+                u, v = (int(x) for x in rng.integers(0, nxt, 2))
+                if u != v:
+                    weights.setdefault((min(u, v), max(u, v)), int(rng.integers(1, 4)))
+            nv = nxt
+        else:
+            while len(weights) < nv * 2:
+                u, v = (int(x) for x in rng.integers(0, nv, 2))
+                if u != v:
+                    weights[(min(u, v), max(u, v))] = int(rng.integers(1, 4))
+        pairs = sorted(weights)
+        rng.shuffle(pairs)
+        eu = np.array([p[0] for p in pairs], np.int64)
+        ev = np.array([p[1] for p in pairs], np.int64)
+        ew = np.array([weights[tuple(p)] for p in pairs], np.int64)
+        eng = SyntenyEngine(files, contigs, k, 100, [], 500, 3000, 100, "x", None, None, None)
+        eng.v_hash = np.arange(nv, dtype=np.uint64)
+        eng.v_alive = np.ones(nv, bool)
+        eng.e_u, eng.e_v, eng.e_w, eng.e_alive = eu.copy(), ev.copy(), ew.copy(), np.ones(eu.size, bool)
+        deg = np.bincount(eu, minlength=nv) + np.bincount(ev, minlength=nv)
+        cand = np.flatnonzero((deg[eu] == 3) & (deg[ev] == 3)).astype(np.uint32)
+        is_cv = np.zeros(nv, bool)
+        is_cv[eu[cand]] = is_cv[ev[cand]] = True
+        inc = np.flatnonzero(is_cv[eu] | is_cv[ev]).astype(np.uint32)
+        eng._simplify(apply_deletions=True)
+        doomed, promoted, n_out = np.zeros(max(cand.size, 1), np.uint32), np.zeros(max(cand.size, 1), np.uint32), ctypes.c_uint64()
+        iu, iv, iw = eu[inc].astype(np.uint32), ev[inc].astype(np.uint32), ew[inc].astype(np.uint32)
+        assert lib.nts_bubble_rule(cand.size, cand.ctypes.data, inc.size, inc.ctypes.data, iu.ctypes.data, iv.ctypes.data, iw.ctypes.data, G,
+                                   doomed.ctypes.data, promoted.ctypes.data, ctypes.byref(n_out)) == 0
+        assert n_out.value == eng.stats["bubbles"]
+        total_bubbles += n_out.value
+        want_w = ew.copy()
+        want_w[promoted[:n_out.value]] = G
+        assert np.array_equal(want_w, eng.e_w)
+        dead = np.zeros(nv, bool)
+        dead[doomed[:n_out.value]] = True
+        assert np.array_equal(~dead, eng.v_alive)
+    assert total_bubbles > 200
