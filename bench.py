@@ -108,7 +108,34 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(k, w, fpr, sample, bf_np, budget_s=24.0):
+def cpu_graph_stage(k, w, lists):
+    """The reference's stage 3, initial round (load_minimizers -> make_minimizer_graph -> simplification -> filter -> find_paths ->
+    synteny blocks -> TSV text; bin/ntsynt_synteny.py:593-647) as the oracle restates it -- single-threaded Python like the
+    reference's -- on the minimizers of the first contig of every genome (sketched on the GPU beforehand)."""
+    from oracle import synteny_oracle as SO
+    tables = {}
+    n_mx = 0
+    for j, (h1, pos) in enumerate(lists):
+        recs = [("chr1", [(str(h), int(p)) for h, p in zip(h1.tolist(), pos.tolist())])]
+        tables[f"syn{j}.fa.k{k}.w{w}.tsv"] = SO.mx_tables_from_tokens(recs)
+        n_mx += len(h1)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="nts_cpu_graph_")
+    os.chdir(tmp)
+    try:
+        t = time.time()
+        eng = SO.SyntenyOracle(list(tables), {}, k, w, [], 50000, 100000, 1000, "cpu")
+        eng.load(tables)
+        eng.main()
+        dt = time.time() - t
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"seconds": round(dt, 2), "minimizers": n_mx, "minimizers_per_s": round(n_mx / dt), "threads": 1,
+            "what": "initial round of the graph stage on the first contig of every genome (no refinement rounds)"}
+
+
+def cpu_baseline(k, w, fpr, sample, bf_np, budget_s=24.0, graph_lists=None):
     """The CPU oracle (a port of btllib's algorithm class: rolling ntHash, ring-buffer window minimum, byte-atomic Bloom
     insert, one probe per k-mer) on this box's host cores, per stage: Bloom build and sketch, each at the
     reference's default parallelism -- make_common_bf with 12 threads (bin/ntSynt:59), indexlr 5 threads x 2 genomes at
@@ -152,6 +179,8 @@ def cpu_baseline(k, w, fpr, sample, bf_np, budget_s=24.0):
             "sketch_Gbases_s": round(rate(lambda: O.minimize(g_sk, k, w, bf_np, threads=thr_sk, native=native), g_sk, slot), 4),
             "sketch_threads": thr_sk,
         }
+    if graph_lists:
+        stages["graph_stage"] = cpu_graph_stage(k, w, graph_lists)
     return {"value": stages["all_cores"]["sketch_Gbases_s"], "unit": "Gbases/s", "cores": cores, "kind": "port",
             "cpu_model": cpu_model(), "logical_cpus_visible": os.cpu_count(), "stages": stages,
             "sample": f"first {sample.size / 1e6:.0f} Mbp of genome 0 read back from HBM, cut into 4 records per thread "
@@ -507,9 +536,16 @@ def main():
             out["c4_n1"] = c4_n1
     if world == 1:
         sample = bf_np = None
+        graph_lists = None
         if not args.no_cpu_baseline:
             sample = genomes[0].download(0, min(genomes[0].total_bp, 100_000_000))
             bf_np = common.to_numpy()
+            graph_lists = []
+            for g in genomes:                                         # minimizers of every genome's first contig, for the CPU graph stage
+                mx = sketch(ctx, g, k, w, common)
+                h1, rec, pos = mx.to_numpy()
+                mx.free()
+                graph_lists.append((h1[rec == 0], pos[rec == 0]))
         if not args.no_e2e:
             for g in genomes:                                        # everything of the sketch legs goes, the pipeline
                 g.free()                                             # starts from files like a user's run
@@ -523,7 +559,7 @@ def main():
                 if not args.e2e_dir:
                     shutil.rmtree(workdir, ignore_errors=True)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(k, w, args.fpr, sample, bf_np)
+            out["cpu_baseline"] = cpu_baseline(k, w, args.fpr, sample, bf_np, graph_lists=graph_lists)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
