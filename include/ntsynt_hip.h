@@ -128,6 +128,9 @@ int nts_bf_insert(nts_ctx* ctx, nts_bf* bf, const nts_genome* g, uint32_t k);
  * the filter layout allows it (tests). */
 int nts_bf_build_mode(nts_ctx* ctx, int mode);
 int nts_bf_cascade(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nts_genome* g, uint32_t k);
+/* the per-genome loop of the experimental repeat filter (bin/ntsynt_make_repeat_bfs.py:56-67; rule make_repeat_bf,
+ * smk:65-72): `if genome_bf.contains(h): repeat_bf.insert(h) else: genome_bf.insert(h)` over every k-mer of g */
+int nts_bf_insert_repeats(nts_ctx* ctx, nts_bf* genome_bf, nts_bf* repeat_bf, const nts_genome* g, uint32_t k);
 int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other);
 int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set);
 int nts_bf_download(nts_ctx* ctx, const nts_bf* bf, uint8_t* host, uint64_t bytes);

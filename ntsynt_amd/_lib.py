@@ -77,6 +77,7 @@ SYMBOLS = [
     ("nts_bf_insert", ctypes.c_int, [c_vp, c_vp, c_vp, u32]),
     ("nts_bf_build_mode", ctypes.c_int, [c_vp, ctypes.c_int]),
     ("nts_bf_cascade", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, u32]),
+    ("nts_bf_insert_repeats", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, u32]),
     ("nts_bf_and", ctypes.c_int, [c_vp, c_vp, c_vp]),
     ("nts_bf_popcount", ctypes.c_int, [c_vp, c_vp, c_u64p]),
     ("nts_bf_download", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),

@@ -153,7 +153,7 @@ def main(argv=None):
     pipeline.run(fastas, k=args.k, w=args.w, fpr=args.fpr, prefix=args.prefix, w_rounds=args.w_rounds,
                  indel=args.indel, merge=args.merge, block_size=args.block_size, common=not args.no_common,
                  simplify=not args.no_simplify_graph, device=device, benchmark=args.benchmark,
-                 bf_rounding=args.bf_rounding, bf_signature=args.bf_signature or pipeline.BF_SIGNATURE,
+                 dev=args.dev, bf_rounding=args.bf_rounding, bf_signature=args.bf_signature or pipeline.BF_SIGNATURE,
                  log=print if (args.dev and int(os.environ.get("RANK", "0")) == 0) else quiet)
     if world > 1:
         dist.barrier()

@@ -338,9 +338,11 @@ __global__ __launch_bounds__(256) void k_stretch(const uint8_t* __restrict__ cod
 //   MODE_KEYS   : keys[phys(j)] = h0, or KEY_MAX if a filter is given and rejects h0   (rows B1+B2)
 //   MODE_INSERT : bf_out |= bit(h0)                                                   (row A2)
 //   MODE_CASCADE: if bf_in has bit(h0): bf_out |= bit(h0)                             (row A3, literal)
+//   MODE_REPEAT : if bit(h0) was set in bf_in already: bf_out |= bit(h0); bf_in |= bit(h0)   (bin/ntsynt_make_repeat_bfs.py:56-67;
+//                 the returning atomic makes "the second hit of a bit" well defined whatever the order of the lanes)
 // Key layout in HBM is tile-transposed so that both this kernel's stores and the window kernel's loads
 // coalesce: phys(j) = tile*8192 + (j%32)*256 + (j%8192)/32.
-enum { MODE_KEYS = 0, MODE_INSERT = 1, MODE_CASCADE = 2 };
+enum { MODE_KEYS = 0, MODE_INSERT = 1, MODE_CASCADE = 2, MODE_REPEAT = 3 };
 constexpr uint32_t KEY_TILE = HASH_THREADS * HASH_PER_THREAD; // 8192
 constexpr uint32_t FAST_K_MAX = 128;
 constexpr uint32_t SEQ_LDS_DWORDS = 2400; // (15 + 8192 + 127) bytes in the padded layout, rounded up
@@ -363,6 +365,13 @@ __device__ __forceinline__ void hash_emit(uint64_t h0, bool live, uint64_t phys,
     if (live) keys[phys] = key;
   } else if (MODE == MODE_INSERT) {
     if (live) bf_set(bf_out, fm(h0));
+  } else if (MODE == MODE_REPEAT) {
+    if (live) {
+      const uint64_t idx = fm(h0);
+      const uint32_t bit = 1u << (idx & 31);
+      const uint32_t old = atomicOr(const_cast<uint32_t*>(bf_in) + (idx >> 5), bit);
+      if (old & bit) bf_set_unless_set(bf_out, idx);
+    }
   } else {
     const uint64_t idx = fm(h0);
     if (live && bf_test(bf_in, idx)) bf_set(bf_out, idx);
@@ -1918,6 +1927,28 @@ static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nt
   }
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // run table buffers are released on return
+  return NTS_OK;
+}
+
+// bin/ntsynt_make_repeat_bfs.py:56-67 for one genome: every k-mer whose bit is already set in `genome_bf` (a k-mer seen before in
+// this genome, or a collision) sets its bit in `repeat_bf`, otherwise in `genome_bf`.  The outcome -- the bits hit at least
+// twice -- does not depend on the order of the k-mers.
+int nts_bf_insert_repeats(nts_ctx* ctx, nts_bf* genome_bf, nts_bf* repeat_bf, const nts_genome* g, uint32_t k)
+{
+  if (!ctx || !genome_bf || !repeat_bf || !g || k == 0) return fail(ctx, NTS_EINVAL, "nts_bf_insert_repeats: bad arguments");
+  if (genome_bf->bytes != repeat_bf->bytes) return fail(ctx, NTS_EINVAL, "nts_bf_insert_repeats: filters differ in size");
+  genome_bf->popcnt = -1;
+  ++genome_bf->version;
+  repeat_bf->popcnt = -1;
+  ++repeat_bf->version;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  GenomeTables scratch;
+  const GenomeTables* T = nullptr;
+  int rc = get_tables(ctx, g, k, nullptr, 0, scratch, &T);
+  if (rc) return rc;
+  rc = launch_hash<MODE_REPEAT>(ctx, "bf_repeats", g, *T, k, genome_bf, repeat_bf, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return NTS_OK;
 }
 

@@ -238,6 +238,11 @@ class BloomFilter:
         "`if prev.contains(h): self.insert(h)` over every k-mer of genome (cpp:145-153)"
         self.ctx.check(self.ctx.lib.nts_bf_cascade(self.ctx.h, prev.h, self.h, genome.h, self.k), "nts_bf_cascade")
 
+    def insert_repeats_of(self, genome, genome_bf):
+        """self = the repeat filter: every k-mer of `genome` whose bit is set in genome_bf already sets its bit here, the others set
+        it in genome_bf (bin/ntsynt_make_repeat_bfs.py:56-67)"""
+        self.ctx.check(self.ctx.lib.nts_bf_insert_repeats(self.ctx.h, genome_bf.h, self.h, genome.h, self.k), "nts_bf_insert_repeats")
+
     def and_(self, other):
         self.ctx.check(self.ctx.lib.nts_bf_and(self.ctx.h, self.h, other.h), "nts_bf_and")
 

@@ -68,7 +68,7 @@ class SyntenyEngine:
     walk_fn / scan_fn: chain walk and per-path scan (native host helpers nts_walk_chains / nts_path_scan)."""
 
     def __init__(self, files, contig_names, k, w, w_rounds, bp, collinear_merge, z, prefix, graph_fn, sketch_fn,
-                 walk_fn, simplify=True, m=90, n=0, log=None, scan_fn=None, degree_fn=None):
+                 walk_fn, simplify=True, m=90, n=0, log=None, scan_fn=None, degree_fn=None, dev=False):
         order = sorted(range(len(files)), key=lambda i: files[i], reverse=True)
         self.input_order = order                       # engine index a -> caller's assembly index
         self.files = [files[i] for i in order]
@@ -77,6 +77,7 @@ class SyntenyEngine:
         self.k, self.w, self.w_rounds = k, w, list(w_rounds)
         self.bp, self.z, self.prefix, self.m = bp, z, prefix, m
         self.simplify = simplify
+        self.dev = dev                                 # --dev: overlap self-check of the final blocks (S:513-514)
         self.n = n or self.G
         cm = str(collinear_merge)
         if mt := re.search(r"^(\d+)w$", cm):
@@ -462,6 +463,31 @@ class SyntenyEngine:
         out.append(cur)
         return out
 
+    # ------------------------------------------------------------------ --dev: overlap self-check (S:234-253)
+    def _warn_overlaps(self, rec, start, end):
+        """check_non_overlapping over the final blocks (all of them pass the length filter by then): rec / start / end are
+        [assembly][block] in final order; a block warns -- once per assembly -- when its extent overlaps an EARLIER block's
+        extent in the same assembly and contig by at least z.  Per assembly the blocks are swept in (contig, start) order with
+        the few extents still open; the warnings come out in the reference's order (block, then assembly)."""
+        hits = []
+        for a in range(self.G):
+            r, s0, e0 = np.asarray(rec[a]), np.asarray(start[a], np.int64), np.asarray(end[a], np.int64)
+            order = np.lexsort((s0, r)).tolist()
+            rl, sl, el = r.tolist(), s0.tolist(), e0.tolist()
+            warned, active, cur = set(), [], None
+            for i in order:
+                if rl[i] != cur:
+                    cur, active = rl[i], []
+                active = [j for j in active if el[j] > sl[i]]
+                for j in active:
+                    if min(el[j], el[i]) - max(sl[j], sl[i]) >= self.z:
+                        warned.add(max(i, j))                # the later block in the final order is the one being checked
+                active.append(i)
+            hits += [(b, a) for b in warned]
+        for b, a in sorted(hits):
+            print("WARNING: detected overlapping segments for this block:", self.files[a], self.contigs[a][int(rec[a][b])],
+                  int(start[a][b]), int(end[a][b]), "\n", file=sys.stderr, flush=True)
+
     # ------------------------------------------------------------------ B5 + C11: refinement inputs
     def _mask_intervals(self, blocks, w):
         masks = [[] for _ in range(self.G)]
@@ -656,6 +682,10 @@ class SyntenyEngine:
                 merged = [b for b in merged if self._long_enough(b)]
                 if merged:
                     merged = self._merge(merged)
+                if self.dev and merged:
+                    self._warn_overlaps([[b.rec[a] for b in merged] for a in range(self.G)],
+                                        [[self._start(b, a) for b in merged] for a in range(self.G)],
+                                        [[self._end(b, a) for b in merged] for a in range(self.G)])
                 self._emit(f"{self.prefix}.synteny_blocks.tsv", merged, verbose=True)
             prev_w = new_w
         return self.outputs

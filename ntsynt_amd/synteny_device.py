@@ -126,9 +126,9 @@ class DeviceSyntenyEngine(SyntenyEngine):
     for the caller's assembly indices a (device-resident lists; the engine frees them)."""
 
     def __init__(self, ctx, files, contig_names, k, w, w_rounds, bp, collinear_merge, z, prefix, sketch_dev_fn, simplify=True,
-                 m=90, n=0, log=None):
+                 m=90, n=0, log=None, dev=False):
         super().__init__(files, contig_names, k, w, w_rounds, bp, collinear_merge, z, prefix, None, None, None, simplify=simplify,
-                         m=m, n=n, log=log, scan_fn=False)
+                         m=m, n=n, log=log, scan_fn=False, dev=dev)
         self.ctx = ctx
         self.sketch_dev_fn = sketch_dev_fn
         self.graph = DeviceGraph(ctx, self.G, self.ref)
@@ -342,6 +342,9 @@ class DeviceSyntenyEngine(SyntenyEngine):
                 merged = self._take(merged, np.flatnonzero(self._long_mask(merged)))
                 if merged["n"]:
                     merged = self._merge(merged)
+                if self.dev and merged["n"]:
+                    self._warn_overlaps(merged["rec"], np.minimum(merged["first_pos"], merged["last_pos"]),
+                                        np.maximum(merged["first_pos"], merged["last_pos"]) + self.k)
                 self._emit(f"{self.prefix}.synteny_blocks.tsv", merged, verbose=True)
             prev_w = new_w
         self.graph.free()

@@ -280,6 +280,22 @@ nts_o_bf_cascade_seq(const uint8_t* prev,
   }
 }
 
+/* bin/ntsynt_make_repeat_bfs.py:56-67 for one record: if genome_bf.contains(h): rep_bf.insert(h) else genome_bf.insert(h) */
+void
+nts_o_bf_repeats_seq(uint8_t* genome_bf, uint8_t* rep_bf, uint64_t bf_bytes, const char* seq, uint64_t len, unsigned k)
+{
+  roller R;
+  roller_init(&R, (const unsigned char*)seq, len, k);
+  const uint64_t bits = bf_bytes * 8;
+  while (roller_next(&R)) {
+    const uint64_t h = R.fwd + R.rev;
+    if (bf_get(genome_bf, bits, h))
+      bf_set(rep_bf, bits, h);
+    else
+      bf_set(genome_bf, bits, h);
+  }
+}
+
 /*
  * Many records at once, parallel over records like the reference's `#pragma omp parallel`
  * over SeqReader records (src/ntsynt_make_common_bf.cpp:128,145).  prev == NULL => plain insert.

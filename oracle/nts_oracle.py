@@ -43,6 +43,8 @@ def _load(native=False):
     lib.nts_o_bf_records.argtypes = [_u8p, _u8p, _u64, ctypes.c_char_p, _u64p, _u64p,
                                      ctypes.c_uint32, ctypes.c_uint, ctypes.c_int]
     lib.nts_o_bf_records.restype = None
+    lib.nts_o_bf_repeats_seq.argtypes = [_u8p, _u8p, _u64, ctypes.c_char_p, _u64, ctypes.c_uint]
+    lib.nts_o_bf_repeats_seq.restype = None
     lib.nts_o_bf_popcount.argtypes = [_u8p, _u64]
     lib.nts_o_bf_popcount.restype = _u64
     lib.nts_o_bf_contains.argtypes = [_u8p, _u64, _u64]
@@ -158,6 +160,18 @@ def bf_build(genome, k, bf_bytes, prev=None, threads=1, native=False):
     lib(native).nts_o_bf_records(_p8(prev), _p8(out), bf_bytes, genome.blob, _p64(genome.rec_off),
                                  _p64(genome.rec_len), len(genome.names), k, threads)
     return out
+
+
+def repeat_bf(genomes, k, bf_bytes):
+    """bin/ntsynt_make_repeat_bfs.py:53-69: one repeat filter over all genomes, a fresh per-genome filter each; records in
+    order, single thread.  Returns the repeat filter (uint8 array)."""
+    rep = np.zeros(bf_bytes, dtype=np.uint8)
+    for g in genomes:
+        own = np.zeros(bf_bytes, dtype=np.uint8)
+        for r in range(len(g.names)):
+            rec = g.record(r)
+            lib().nts_o_bf_repeats_seq(_p8(own), _p8(rep), bf_bytes, rec, len(rec), k)
+    return rep
 
 
 def bf_popcount(bf):

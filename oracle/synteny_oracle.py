@@ -579,6 +579,23 @@ class SyntenyOracle:
         return g
 
     # -- writers: S:496-503, 516-523, 634-641 (row C10) -------------------------------------------------
+    def check_non_overlapping(self, blocks):                             # S:234-253 (--dev)
+        """Final self-check of developer mode: a warning on stderr for every block whose extent overlaps an earlier block's
+        extent in the same assembly and contig by at least z.  (An intervaltree query [start:end) against the extents
+        inserted so far; blocks below the length filter neither warn nor count.)"""
+        seen = defaultdict(list)                                         # (assembly, contig) -> [(start, end)]
+        for blk in blocks:
+            for a, ab in blk.asm.items():
+                if not all(x.length() >= self.z for x in blk.asm.values()):
+                    continue
+                start, end = ab.start(), ab.end()
+                for s0, e0 in seen[(a, ab.contig_id)]:
+                    if s0 < end and start < e0 and min(end, e0) - max(start, s0) >= self.z:
+                        print("WARNING: detected overlapping segments for this block:", a, ab.contig_id, start, end, "\n",
+                              file=sys.stderr, flush=True)
+                        break
+                seen[(a, ab.contig_id)].append((start, end))
+
     def _emit(self, name, blocks, verbose=False):
         rows, num = [], 0
         for blk in blocks:
@@ -619,6 +636,8 @@ class SyntenyOracle:
                 merged = [b for b in merged if b.long_enough(self.z)]
                 if merged:
                     merged = self.merge_collinear(merged)
+                if getattr(self, "dev", False):                           # S:513-514
+                    self.check_non_overlapping(merged)
                 self._emit(f"{self.prefix}.synteny_blocks.tsv", merged, verbose=True)
             prev_w = new_w
         return blocks

@@ -448,3 +448,33 @@ def test_native_block_rules_match_the_python_rules():
         dead[doomed[:n_out.value]] = True
         assert np.array_equal(~dead, eng.v_alive)
     assert total_bubbles > 200
+
+
+def test_dev_overlap_check_matches_the_oracle(capsys):
+    "--dev: check_non_overlapping (bin/ntsynt_synteny.py:234-253) -- array sweep of the engines against the oracle's restatement"
+    rng = np.random.default_rng(4)
+    files = ["b.fa.k24.w100.tsv", "a.fa.k24.w100.tsv"]
+    contigs = [["x1", "x2"], ["y1", "y2"]]
+    total = 0
+    for trial in range(25):
+        n = int(rng.integers(2, 40))
+        eng = SyntenyEngine(files, contigs, 24, 100, [], 500, 3000, 300, "x", None, None, None, dev=True)
+        ora = SO.SyntenyOracle(files, {}, 24, 100, [], 500, 3000, 300, "x")
+        rec = rng.integers(0, 2, size=(2, n))
+        start = rng.integers(0, 20000, size=(2, n))
+        end = start + rng.integers(300, 4000, size=(2, n))
+        blocks = []
+        for b in range(n):
+            blk = SO.SynBlock(24, 90, ora.files)
+            for a, f in enumerate(ora.files):
+                ab = blk.asm[f]
+                ab.contig_id, ab.ori = contigs[a][rec[a, b]], "+"
+                ab.minimizers = [("h", int(start[a, b])), ("t", int(end[a, b]) - 24)]
+            blocks.append(blk)
+        ora.check_non_overlapping(blocks)
+        want = capsys.readouterr().err
+        eng._warn_overlaps(rec, start, end)
+        got = capsys.readouterr().err
+        assert got == want
+        total += want.count("WARNING")
+    assert total > 50

@@ -411,3 +411,35 @@ def test_bloom_rounding_switch_matches_oracle(ctx, tmp_path, rounding):
     assert eng.outputs["r.synteny_blocks.tsv"] == ora.outputs["r.synteny_blocks.tsv"]
     bits, _ = pipeline.read_bf(str(tmp_path / "hip" / "r.common.bf"))
     assert np.array_equal(bits, ora.bf) and bits.size == nbytes
+
+
+# ------------------------------------------------------------------------------------------------ F4: experimental repeat filter
+def test_repeat_filter_matches_oracle(ctx, tmp_path):
+    """bin/ntsynt_make_repeat_bfs.py:53-69: filter of the k-mers (bits) hit at least twice within a genome, over two genomes,
+    device vs the oracle's sequential restatement; and the command-line tool writes that filter."""
+    import subprocess
+    import sys
+    from ntsynt_amd import synth
+    from ntsynt_amd.device import BloomFilter
+    from ntsynt_amd.pipeline import read_bf
+    from tests.helpers import to_device
+    paths = synth.make_family(str(tmp_path), 2, 600_000, 3, 0.02, seed=31, micro=25, n_runs=True, soft_mask=True)   # micro: copies => repeats
+    genomes = [O.read_fasta(p) for p in paths]
+    k, nbytes = 24, 1 << 20
+    want = O.repeat_bf(genomes, k, nbytes)
+    assert 100 < O.bf_popcount(want) < nbytes * 4
+    rep = BloomFilter(ctx, nbytes, k)
+    own = BloomFilter(ctx, nbytes, k)
+    for g in genomes:
+        d = to_device(ctx, g.names, [g.record(i) for i in range(len(g.names))])
+        own.clear()
+        rep.insert_repeats_of(d, own)
+        d.free()
+    assert np.array_equal(rep.to_numpy(), want)
+    rep.free()
+    own.free()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "bin", "ntsynt_make_repeat_bfs"), "--genome", *paths, "-k", str(k), "--bf", "1048576B",
+                    "-p", str(tmp_path / "rep")], check=True, env=dict(os.environ, PYTHONPATH=root), stdout=subprocess.DEVNULL)
+    bits, kk = read_bf(str(tmp_path / "rep.bf"))
+    assert kk == k and np.array_equal(bits, want)
