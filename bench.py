@@ -276,7 +276,27 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = Context(local_rank)
     ctx.sketch_mode(args.mode, args.prune_c)
-    comm = Comm.from_torch(ctx) if (world > 1 and not host_comm) else None
+    # The two exchanges run inside libntsynt_hip.so over RCCL (nts_bf_allreduce_and, nts_mx_allgather).  Should the library's
+    # communicator not come up on this node (it has only ever been brought up with one rank), the bench still measures the
+    # sketch: the exchanges then go through torch.distributed on device tensors, and the line says so (config.exchanges).
+    comm, exchanges = None, "none (one GPU)"
+    if world > 1 and not host_comm:
+        try:
+            comm = Comm.from_torch(ctx)
+            exchanges = "libntsynt_hip.so over RCCL (nts_bf_allreduce_and, nts_mx_allgather)"
+        except Exception as exc:                              # noqa: BLE001 -- any failure of the communicator set-up
+            exchanges = f"torch.distributed (library communicator failed: {exc})"
+            print(f"[bench] rank {rank}: {exchanges}", file=sys.stderr, flush=True)
+        # every rank must take the same path
+        ok = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+            exchanges = "torch.distributed (library communicator failed on another rank)"
+    elif world > 1:
+        exchanges = "host copies over gloo (verification mode)"
+    torch_comm = world > 1 and comm is None and not host_comm
     k, w = args.k, args.w
     total_bp = int(mbp * 1e6)
 
@@ -293,7 +313,14 @@ def main():
     _, nbytes = bf_size_bytes(genomes[0].total_bp, args.fpr)        # every genome of the family has this size
     ctx.profile(True)
     t0 = time.time()
-    common = BloomFilter(ctx, nbytes, k, world=world if comm is not None else 1)
+    if torch_comm:
+        from ntsynt_amd import dist as ndist
+        from ntsynt_amd.device import and_raw, wrap_bloom
+        buf = torch.zeros(ndist.padded_len(nbytes, world), dtype=torch.uint8, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        common = wrap_bloom(ctx, buf, nbytes, k)
+    else:
+        common = BloomFilter(ctx, nbytes, k, world=world if comm is not None else 1)
     common.insert(genomes[0])
     occ_single = common.get_fpr()
     if len(genomes) > 1:
@@ -310,6 +337,12 @@ def main():
         t1 = time.time()
         if comm is not None:
             comm.allreduce_and(common)
+        elif torch_comm:
+            def and_into(a, b):
+                and_raw(ctx, a.data_ptr(), b.data_ptr(), a.numel())
+                ctx.sync()
+            ndist.allreduce_and(buf, and_into)
+            torch.cuda.synchronize()
         else:                                               # verification mode: the same reduction on host copies
             bits = torch.from_numpy(common.to_numpy())
             gathered = [torch.empty_like(bits) for _ in range(world)]
@@ -501,7 +534,7 @@ def main():
             "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{name}: {n_fam} synthetic {mbp:g} Mbp genomes ({contigs} contigs) at {div * 100:g}% divergence, "
                                    f"k={k} w={w} fpr={args.fpr}, genome g on GPU g mod {world}",
-                       "sketch_mode": args.mode, "prune_c": c_used, "genomes_on_rank0": len(genomes),
+                       "sketch_mode": args.mode, "prune_c": c_used, "genomes_on_rank0": len(genomes), "exchanges": exchanges,
                        "sketch_launch_sequences_per_step_rank0": len(units), "bases_per_step": bases_total(n_fam, genomes),
                        "minimizers_per_step_rank0": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)",
                        "synth_s": round(t_synth, 3)},
