@@ -213,8 +213,10 @@ int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c);
 /* Dense sketch over a sparse filter (many divergent genomes: nearly no k-mer is common to all): when occupancy x 2^shift is
  * small, a summary of the filter with one bit per 2^shift filter bits (<= 1 MiB, L2-resident; built once per filter state) is
  * consulted first and only a set summary bit leads to a read of the filter; key tiles without an accepted k-mer are skipped
- * by the window kernel.  Identical output.  mode 0 = auto (default), 1 = never, -1 = leave as is; last_shift = the shift the
- * last nts_sketch call used (0: it did not use a summary). */
+ * by the window kernel.  In auto mode the accepted k-mers themselves become the candidate list (no keys, no window kernel), and
+ * when the filter holds few enough set bits a copy of it folded onto 2^19 bits is looked at first, from LDS.  Identical output.
+ * mode 0 = auto (default), 1 = never, 2 = auto without the LDS copy, -1 = leave as is; last_shift = the shift the last
+ * nts_sketch call used (0: it did not use a summary). */
 int nts_sketch_summary(nts_ctx* ctx, int mode, uint32_t* last_shift);
 /* of the last nts_sketch call: accepted candidates, uncovered ranges handed to the dense kernels, the number of
  * k-mers in them, and the c that was used (all 0 for a dense-mode call) */

@@ -91,6 +91,9 @@ struct nts_ctx
   uint64_t last_candidates = 0, last_gaps = 0, last_gap_kmers = 0;
   // dense sketch over a sparse filter: summary consulted before the filter, key tiles without an accepted k-mer skipped
   const uint32_t* cur_summary = nullptr;
+  const uint32_t* cur_fold = nullptr; // folded copy of the filter for the LDS first look (k_hash_accept4), or null
+  int fold_mode = 0;                  // 0 auto, 1 never (tests)
+  bool acc4_lds_set = false;
   uint32_t cur_summary_shift = 0;
   uint32_t* cur_tile_any = nullptr;
   int summary_mode = 0; // 0 auto, 1 never (tests)
@@ -130,6 +133,7 @@ struct nts_bf
   mutable uint32_t summary_shift = 0;
   mutable uint64_t summary_version = ~0ULL;
   mutable double summary_density = 1.0;
+  mutable uint32_t* d_fold = nullptr; // the filter folded onto 2^19 bits (bit i mod 2^19), built with the summary: LDS-resident first look
 };
 
 struct nts_mx
@@ -517,13 +521,20 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
 // 2^shift filter bits (<= 1 MiB, resident in the L2) answers those probes; only where the summary bit is set is the filter
 // itself read.  Same keys as k_hash<MODE_KEYS> bit for bit; key tiles without a single accepted k-mer are not written at all
 // and flagged in tile_any, so that the window kernel skips them.
-__global__ __launch_bounds__(256) void k_bf_summary(const uint4* __restrict__ words, uint64_t n16, uint32_t shift, uint32_t* __restrict__ summary)
+__global__ __launch_bounds__(256) void k_bf_summary(const uint4* __restrict__ words, uint64_t n16, uint32_t shift, uint32_t* __restrict__ summary,
+                                                    uint32_t* __restrict__ fold, uint32_t fold_words)
 {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint4 v = words[i];
     if (v.x | v.y | v.z | v.w) {
       const uint64_t g = (i * 128u) >> shift; // shift >= 7: the 128 bits of a word share one granule
       atomicOr(&summary[g >> 5], 1u << (g & 31u));
+      // the folded copy: bit (index mod 2^19) -- whole 32-bit words fold onto whole words (fold_words is a power of two)
+      const uint32_t w0 = (uint32_t)((4 * i) & (fold_words - 1));
+      if (v.x) atomicOr(&fold[w0], v.x);
+      if (v.y) atomicOr(&fold[(w0 + 1) & (fold_words - 1)], v.y);
+      if (v.z) atomicOr(&fold[(w0 + 2) & (fold_words - 1)], v.z);
+      if (v.w) atomicOr(&fold[(w0 + 3) & (fold_words - 1)], v.w);
     }
   }
 }
@@ -1859,6 +1870,7 @@ void nts_bf_free(nts_ctx* ctx, nts_bf* bf)
   if (ctx) hipSetDevice(ctx->device);
   if (bf->d_words && bf->owned) hipFree(bf->d_words);
   if (bf->d_summary) hipFree(bf->d_summary);
+  if (bf->d_fold) hipFree(bf->d_fold);
   delete bf;
 }
 
@@ -2670,7 +2682,17 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       A.tile_cnt = d_tcnt;
       A.tile_ordered = d_tord;
       ScopedTimer t(ctx, "hash_accept", true);
-      hipLaunchKernelGGL(k_hash_accept, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, A);
+      if (ctx->cur_fold) {
+        if (!ctx->acc4_lds_set) {
+          HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(Accept4Lds)));
+          ctx->acc4_lds_set = true;
+        }
+        hipLaunchKernelGGL(k_hash_accept4, dim3((uint32_t)((n_kt + 3) / 4)), dim3(ACC4_THREADS), sizeof(Accept4Lds), ctx->stream, A, ctx->cur_fold,
+                           n_kt);
+      } else {
+        hipLaunchKernelGGL(k_hash_accept, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, A);
+      }
     } else {
       ScopedTimer t(ctx, filter ? "hash_select" : "hash_select_nofilter", true);
       // a lane rolls 64 k-mers and keeps 64*c/w candidates on average: 8 private slots while that is small, 16 beyond
@@ -2848,8 +2870,11 @@ extern "C" int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c)
 
 extern "C" int nts_sketch_summary(nts_ctx* ctx, int mode, uint32_t* last_shift)
 {
-  if (!ctx || mode < -1 || mode > 1) return fail(ctx, NTS_EINVAL, "nts_sketch_summary: mode is -1 (query), 0 (auto) or 1 (never)");
-  if (mode >= 0) ctx->summary_mode = mode;
+  if (!ctx || mode < -1 || mode > 2) return fail(ctx, NTS_EINVAL, "nts_sketch_summary: mode is -1 (query), 0 (auto), 1 (never) or 2 (no LDS copy)");
+  if (mode >= 0) {
+    ctx->summary_mode = mode == 1 ? 1 : 0;
+    ctx->fold_mode = mode == 2 ? 1 : 0;
+  }
   if (last_shift) *last_shift = ctx->last_summary;
   return NTS_OK;
 }
@@ -2953,6 +2978,7 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   // Dense pass over a sparse filter: with occupancy o, a summary bit covering 2^shift filter bits is set with probability
   // ~ o * 2^shift; when that is small the summary answers nearly every probe from the L2 (k_hash_keys_sparse).
   ctx->cur_summary = nullptr;
+  ctx->cur_fold = nullptr;
   ctx->cur_tile_any = nullptr;
   ctx->last_summary = 0;
   bool accept_all = false;
@@ -2974,10 +3000,12 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
           filter->summary_words = words;
         }
         SK_HIP(hipMemsetAsync(filter->d_summary, 0, filter->summary_words * 4, ctx->stream));
+        if (!filter->d_fold) SK_HIP(hipMalloc((void**)&filter->d_fold, FOLD_WORDS * 4));
+        SK_HIP(hipMemsetAsync(filter->d_fold, 0, FOLD_WORDS * 4, ctx->stream));
         const uint64_t n16 = (filter->bytes + 15) / 16;
         ScopedTimer t(ctx, "bf_summary");
         hipLaunchKernelGGL(k_bf_summary, dim3((uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 16)), dim3(256), 0, ctx->stream,
-                           (const uint4*)filter->d_words, n16, shift, filter->d_summary);
+                           (const uint4*)filter->d_words, n16, shift, filter->d_summary, filter->d_fold, FOLD_WORDS);
         filter->summary_shift = shift;
         filter->summary_version = filter->version;
       }
@@ -2991,6 +3019,9 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
       const double own = bits * (1.0 - std::exp(-(double)rt.n_valid / bits));
       p = own > 0 ? std::min(1.0, (double)pc / own) : 1.0;
       accept_all = ctx->sketch_mode != 1; // (mode "dense" keeps the key / window kernels, with the summary in front of the probes)
+      // the folded copy pays while it rejects a good share of the k-mers: set bits / 2^19 below ~1.2 (about 70 % of its bits set)
+      ctx->cur_fold = (ctx->fold_mode == 0 && bits >= (double)(1u << FOLD_BITS_LOG2) && (double)pc < 1.2 * (double)(1u << FOLD_BITS_LOG2))
+                        ? filter->d_fold : nullptr;
     }
   }
 

@@ -55,10 +55,10 @@ class Context:
         self.check(self.lib.nts_sketch_mode(self.h, code, int(prune_c)), "nts_sketch_mode")
 
     def sketch_summary(self, mode=None):
-        """Summary-first probing of sparse filters in the dense sketch (nts_sketch_summary): mode 'auto' / 'never' / None
-        (leave as is).  Returns the granule shift the last sketch call used (0: no summary)."""
+        """Summary-first probing of sparse filters in the dense sketch (nts_sketch_summary): mode 'auto' / 'never' / 'no-lds'
+        (summary, but no folded copy of the filter in LDS) / None (leave as is).  Returns the granule shift the last sketch call used (0: no summary)."""
         last = ctypes.c_uint32()
-        code = {None: -1, "auto": 0, "never": 1}[mode]
+        code = {None: -1, "auto": 0, "never": 1, "no-lds": 2}[mode]
         self.check(self.lib.nts_sketch_summary(self.h, code, ctypes.byref(last)), "nts_sketch_summary")
         return last.value
 

@@ -212,13 +212,15 @@ def test_c4_one_gpu_share_of_eight_divergent_3gbp_genomes(ctx):
         out[mode] = sketch(ctx, mine, k, w, common).to_numpy()
         if mode == "auto":
             assert ctx.sketch_summary() >= 7            # the all-but-empty filter is probed through its L2-resident summary
+    ctx.sketch_summary("no-lds")
+    out["no-lds"] = sketch(ctx, mine, k, w, common).to_numpy()     # summary in the L2, no folded copy in LDS
     ctx.sketch_summary("never")
     ctx.sketch_mode("dense")
     out["plain"] = sketch(ctx, mine, k, w, common).to_numpy()      # every k-mer probed in HBM
     assert ctx.sketch_summary() == 0
     ctx.sketch_summary("auto")
     ctx.sketch_mode("auto")
-    for mode in ("dense", "pruned", "plain"):
+    for mode in ("dense", "pruned", "plain", "no-lds"):
         for x, y in zip(out["auto"], out[mode]):
             assert np.array_equal(x, y)
     h1, rec, pos = out["auto"]
@@ -270,15 +272,17 @@ def test_sparse_filter_summary_path_matches_oracle(ctx):
             ctx.sketch_summary("never")
             ctx.sketch_mode("dense")
             b = sketch(ctx, d, k, w, common).to_numpy()                # every k-mer probed in HBM
-            ctx.sketch_summary("auto")
-            # "dense": keys + window kernel behind the summary; "auto": the accepted k-mers as the candidate list (k_hash_accept)
-            for mode in ("dense", "auto"):
+            # "dense": keys + window kernel behind the summary; "auto": the accepted k-mers as the candidate list, with the folded
+            # copy of the filter in LDS first (k_hash_accept4) or without it (k_hash_accept)
+            for smode, mode in (("auto", "dense"), ("auto", "auto"), ("no-lds", "auto")):
+                ctx.sketch_summary(smode)
                 ctx.sketch_mode(mode)
                 a = sketch(ctx, d, k, w, common).to_numpy()
                 assert ctx.sketch_summary() >= 7
                 for x, y in zip(a, b):
                     assert np.array_equal(x, y)
                 assert np.array_equal(a[0], exp[0]) and np.array_equal(a[2], exp[2]) and a[0].size > 0
+    ctx.sketch_summary("auto")
     ctx.sketch_mode("auto")
     # masked re-sketch (refinement rounds) through the same path
     ctx.sketch_summary("auto")
