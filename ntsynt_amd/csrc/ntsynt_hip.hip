@@ -614,14 +614,19 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash_keys_sparse(const uint8_t
         idx[u] = fm(h[u]);
         sw[u] = summary[idx[u] >> (shift + 5)];
       }
+      uint32_t pass = 0, fw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b0 + u < n_mine && ((sw[u] >> ((idx[u] >> shift) & 31u)) & 1u)) pass |= 1u << u;
+      // the filter reads of the few k-mers that passed, as one round of independent loads (the others re-read word 0)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fw[u] = bf_in[((pass >> u) & 1u) ? (idx[u] >> 5) : 0];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        if (b0 + u < n_mine && ((sw[u] >> ((idx[u] >> shift) & 31u)) & 1u)) {
-          if ((bf_in[idx[u] >> 5] >> ((uint32_t)idx[u] & 31u)) & 1u) {
-            acc_mask |= 1u << (b0 + u);
-            if (n_acc < 4) acc_h[n_acc] = h[u];
-            ++n_acc;
-          }
+        if (((pass >> u) & 1u) && ((fw[u] >> ((uint32_t)idx[u] & 31u)) & 1u)) {
+          acc_mask |= 1u << (b0 + u);
+          if (n_acc < 4) acc_h[n_acc] = h[u];
+          ++n_acc;
         }
       }
     }
