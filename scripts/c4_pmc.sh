@@ -4,10 +4,10 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/c4pmc
 mkdir -p $O
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES --kernel-trace --output-format csv -d $O/p1 -o s -- python scripts/c4_probe.py 2 > $O/p1.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/p2 -o s -- python scripts/c4_probe.py 2 > $O/p2.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM --kernel-trace --output-format csv -d $O/p3 -o s -- python scripts/c4_probe.py 2 > $O/p3.log 2>&1
-timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $O/p4 -o s -- python scripts/c4_probe.py 2 > $O/p4.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES --kernel-trace --output-format csv -d $O/p1 -o s -- python scripts/c4_probe.py 8 > $O/p1.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/p2 -o s -- python scripts/c4_probe.py 8 > $O/p2.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM --kernel-trace --output-format csv -d $O/p3 -o s -- python scripts/c4_probe.py 8 > $O/p3.log 2>&1
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $O/p4 -o s -- python scripts/c4_probe.py 8 > $O/p4.log 2>&1
 python - <<'PY'
 import csv, glob, json, collections
 out = collections.defaultdict(dict)
