@@ -10,14 +10,7 @@ import sys
 
 NTSYNT_VERSION = "ntSynt v1.0.4 (ntsynt_amd / MI355X)"
 
-NTSYNT_ASCII = r"""
-        _    ____                 _
- _ __  | |_ / ___|  _   _  _ __  | |_
-| '_ \ | __|\___ \ | | | || '_ \ | __|
-| | | || |_  ___) || |_| || | | || |_
-|_| |_| \__||____/  \__, ||_| |_| \__|
-                    |___/
-"""
+NTSYNT_BANNER = "ntSynt on MI355X -- minimizer-graph macrosynteny, sketch / Bloom filter / graph stage in HBM"
 
 
 def read_fasta_files(filename):
@@ -28,37 +21,35 @@ def read_fasta_files(filename):
 
 def build_parser():
     epilog = "\n".join([
-        "Default parameter settings for divergence values:",
-        "< 1% divergence:\t--block_size 500 --indel 10000 --merge 10000 --w_rounds 100 10",
-        "1% - 10% divergence:\t--block_size 1000 --indel 50000 --merge 100000 --w_rounds 250 100",
-        "> 10% divergence:\t--block_size 10000 --indel 100000 --merge 1000000 --w_rounds 500 250",
-        "If any of these parameters are set manually, those values will override the above.",
+        "Parameters derived from -d unless given explicitly (the reference's table, bin/ntSynt:89-99):",
+        "  -d below 1      block_size 500    indel 10000    merge 10000     w_rounds 100 10",
+        "  -d 1 to 10      block_size 1000   indel 50000    merge 100000    w_rounds 250 100",
+        "  -d above 10     block_size 10000  indel 100000   merge 1000000   w_rounds 500 250",
     ])
-    p = argparse.ArgumentParser(prog="ntSynt",
-                                description="ntSynt: Multi-genome synteny detection using minimizer graphs",
+    p = argparse.ArgumentParser(prog="ntSynt", description="Macrosynteny blocks of two or more genome assemblies from a minimizer graph "
+                                "(ntSynt's method and command line; all sequence-scale work on the GPU)",
                                 formatter_class=argparse.RawTextHelpFormatter, epilog=epilog)
-    p.add_argument("fastas", help="Input genome fasta files", nargs="*")
-    p.add_argument("--fastas_list", help="File listing input genome fasta files, one per line", required=False, type=str)
-    p.add_argument("-d", "--divergence",
-                   help="Approx. maximum percent sequence divergence between input genomes (Ex. -d 1 for 1%% divergence).\n"
-                        "This will be used to set --indel, --merge, --w_rounds, --block_size",
-                   required=True, type=float)
-    p.add_argument("-p", "--prefix", help="Prefix for ntSynt output files [ntSynt.k<k>.w<w>]", required=False)
-    p.add_argument("-k", help="Minimizer k-mer size [24]", type=int, required=False, default=24)
-    p.add_argument("-w", help="Minimizer window size [1000]", type=int, required=False, default=1000)
-    p.add_argument("-t", help="Number of threads [12] (accepted for compatibility; the GPU path ignores it)", type=int, default=12)
-    p.add_argument("--fpr", help="False positive rate for Bloom filter creation [0.025]", default=0.025, type=float)
-    p.add_argument("-b", "--block_size", help="Minimum synteny block size (bp)", type=int, required=False)
-    p.add_argument("--merge", help="Maximum distance between collinear synteny blocks for merging (bp). \n"
-                                   "Can also specify a multiple of the window size (ex. 3w)", type=str)
-    p.add_argument("--w_rounds", help="List of decreasing window sizes for synteny block refinement", nargs="+", type=int)
-    p.add_argument("--indel", help="Threshold for indel detection (bp)", type=int)
+    p.add_argument("fastas", help="genome assemblies (FASTA, plain or .gz), two or more", nargs="*")
+    p.add_argument("--fastas_list", help="text file naming the assemblies, one path per line (instead of positional arguments)",
+                   required=False, type=str)
+    p.add_argument("-d", "--divergence", help="upper estimate of the sequence divergence between the assemblies, in percent (-d 1 = 1%%);\n"
+                   "selects --indel, --merge, --w_rounds and --block_size (table below)", required=True, type=float)
+    p.add_argument("-p", "--prefix", help="prefix of the output files [ntSynt.k<k>.w<w>]", required=False)
+    p.add_argument("-k", help="k-mer size of the minimizers [24]", type=int, required=False, default=24)
+    p.add_argument("-w", help="window size of the minimizers [1000]", type=int, required=False, default=1000)
+    p.add_argument("-t", help="threads [12]: accepted for compatibility with the reference, the GPU path does not use it", type=int, default=12)
+    p.add_argument("--fpr", help="false positive rate the common Bloom filter is sized for [0.025]", default=0.025, type=float)
+    p.add_argument("-b", "--block_size", help="shortest synteny block reported (bp)", type=int, required=False)
+    p.add_argument("--merge", help="collinear blocks closer than this are merged (bp, or a multiple of the window size such as 3w)", type=str)
+    p.add_argument("--w_rounds", help="window sizes of the refinement rounds, decreasing", nargs="+", type=int)
+    p.add_argument("--indel", help="largest difference between assemblies in the distance of neighbouring minimizers before a block is split (bp)",
+                   type=int)
     p.add_argument("--no-common", help=argparse.SUPPRESS, action="store_true")
     p.add_argument("--no-simplify-graph", help=argparse.SUPPRESS, action="store_true")
-    p.add_argument("-n", "--dry-run", help="Print out the stages that will be executed", action="store_true")
-    p.add_argument("--benchmark", help="Store wall-clock times for each step of the ntSynt pipeline", action="store_true")
-    p.add_argument("-f", "--force", help="Run all ntSynt steps, regardless of existing output files", action="store_true")
-    p.add_argument("--dev", help="Run in developer mode: more verbose logging", action="store_true")
+    p.add_argument("-n", "--dry-run", help="list the stages that would run, then stop", action="store_true")
+    p.add_argument("--benchmark", help="write the wall-clock time of every stage to <prefix>.stage_times.tsv", action="store_true")
+    p.add_argument("-f", "--force", help="accepted for compatibility (every run recomputes everything)", action="store_true")
+    p.add_argument("--dev", help="developer mode: verbose log, overlap self-check of the final blocks", action="store_true")
     p.add_argument("--device", help="GPU index [0]", type=int, default=0)
     # switches for the two btllib details this implementation recalls rather than reads
     p.add_argument("--bf-rounding", help=argparse.SUPPRESS, choices=["up", "down", "none"], default="up")
@@ -103,7 +94,7 @@ def main(argv=None):
     fastas = resolve(parser, args)
     rank0 = int(os.environ.get("RANK", "0")) == 0                # under torchrun every rank runs this; one of them talks
     say = print if rank0 else (lambda *a, **k: None)
-    say(NTSYNT_ASCII)
+    say(NTSYNT_BANNER)
     say("\n".join(["Running ntSynt...",
                      f"Specified percent divergence: {args.divergence}",
                      "Parameter settings:",
@@ -118,6 +109,9 @@ def main(argv=None):
                      f"\t-w {args.w}",
                      f"\t-t {args.t}",
                      f"\t--fpr {args.fpr}"]), flush=True)
+    if not args.no_common:
+        say(f"Note: {args.prefix}.common.bf is written in btllib's Bloom filter layout as recalled from its source "
+            "(header table name: --bf-signature); a stock btllib is not guaranteed to load it.")
     for fasta in fastas:
         if not os.path.isfile(fasta):
             raise FileNotFoundError(f"Input file {fasta} not found.")
