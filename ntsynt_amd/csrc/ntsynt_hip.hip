@@ -96,6 +96,14 @@ struct nts_ctx
   bool acc4_lds_set = false;
   uint32_t cur_summary_shift = 0;
   uint32_t* cur_tile_any = nullptr;
+  // pinned staging buffers + streams of the bulk transfers done by host threads (FASTA bytes up: nts_genome_from_fasta; filter
+  // bits down: nts_bf_save), allocated on first use and kept: allocating pinned memory per call cost more than a small transfer
+  struct IoLane
+  {
+    hipStream_t stream = nullptr;
+    uint8_t* stage[2] = { nullptr, nullptr };
+  };
+  std::vector<IoLane> io_up, io_down;
   int summary_mode = 0; // 0 auto, 1 never (tests)
   uint32_t last_summary = 0;
 };
@@ -195,6 +203,33 @@ void ws_release(nts_ctx* ctx)
   for (auto& kv : ctx->ws)
     if (kv.second.first) hipFree(kv.second.first);
   ctx->ws.clear();
+}
+
+// `want` lanes (stream + two pinned buffers of `chunk` bytes) of a transfer pool, created on first use; fewer if memory is short
+constexpr uint64_t IO_CHUNK = (uint64_t)8 << 20;
+unsigned io_lanes(nts_ctx* ctx, std::vector<nts_ctx::IoLane>& pool, unsigned want)
+{
+  while (pool.size() < want) {
+    nts_ctx::IoLane l;
+    if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) break;
+    if (hipHostMalloc((void**)&l.stage[0], IO_CHUNK) != hipSuccess || hipHostMalloc((void**)&l.stage[1], IO_CHUNK) != hipSuccess) {
+      if (l.stage[0]) hipHostFree(l.stage[0]);
+      hipStreamDestroy(l.stream);
+      break;
+    }
+    pool.push_back(l);
+  }
+  return (unsigned)std::min<size_t>(pool.size(), want);
+}
+
+void io_release(std::vector<nts_ctx::IoLane>& pool)
+{
+  for (auto& l : pool) {
+    hipStreamDestroy(l.stream);
+    hipHostFree(l.stage[0]);
+    hipHostFree(l.stage[1]);
+  }
+  pool.clear();
 }
 
 // ---- timing: HIP events on the context's stream around each kernel ---------------------------
@@ -1497,6 +1532,8 @@ void nts_destroy(nts_ctx* ctx)
   hipStreamSynchronize(ctx->stream);
   ws_release(ctx);
   for (auto& p : ctx->mx_pool) hipFree(p.first);
+  io_release(ctx->io_up);
+  io_release(ctx->io_down);
   for (auto& kv : ctx->init_tabs) hipFree(kv.second);
   if (ctx->mail) hipHostFree(ctx->mail);
   if (ctx->stage) hipHostFree(ctx->stage);
@@ -2161,56 +2198,53 @@ int nts_bf_save(nts_ctx* ctx, const nts_bf* bf, const char* path, const void* he
   bool ok = header_bytes == 0 || write_at(header, header_bytes, 0);
   std::atomic<uint64_t> next(0);
   std::atomic<bool> failed(false);
-  const uint64_t CHUNK = (uint64_t)16 << 20;
+  const uint64_t CHUNK = IO_CHUNK;
   const uint64_t n_chunks = (bf->bytes + CHUNK - 1) / CHUNK;
   const uint8_t* src = (const uint8_t*)bf->d_words;
   const int device = ctx->device;
-  auto worker = [&]() {
+  // a small filter does not pay for six threads: one per 64 MiB, at most n_threads (default 6)
+  const unsigned T = ok ? io_lanes(ctx, ctx->io_down, (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_threads ? n_threads : 6, (n_chunks + 7) / 8))) : 0;
+  if (ok && T == 0) ok = false;
+  auto worker = [&](unsigned lane) {
     if (hipSetDevice(device) != hipSuccess) {
       failed.store(true);
       return;
     }
-    hipStream_t st = nullptr;
-    uint8_t* stage[2] = { nullptr, nullptr };
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipHostMalloc((void**)&stage[0], CHUNK) != hipSuccess ||
-        hipHostMalloc((void**)&stage[1], CHUNK) != hipSuccess || hipStreamWaitEvent(st, ready, 0) != hipSuccess) {
+    nts_ctx::IoLane& io = ctx->io_down[lane];
+    hipStream_t st = io.stream;
+    uint8_t* const* stage = io.stage;
+    if (hipStreamWaitEvent(st, ready, 0) != hipSuccess) {
       failed.store(true);
-    } else {
-      // two chunks in flight per thread: while chunk c is copied into the mapping, chunk c' is on its way from HBM
-      uint64_t cur = next.fetch_add(1), cur_len = 0;
-      int slot = 0;
-      if (cur < n_chunks) {
-        cur_len = std::min(CHUNK, bf->bytes - cur * CHUNK);
-        if (hipMemcpyAsync(stage[slot], src + cur * CHUNK, cur_len, hipMemcpyDeviceToHost, st) != hipSuccess) failed.store(true);
-      }
-      while (cur < n_chunks && !failed.load()) {
-        if (hipStreamSynchronize(st) != hipSuccess) {
-          failed.store(true);
-          break;
-        }
-        const uint64_t nxt = next.fetch_add(1);
-        uint64_t nxt_len = 0;
-        if (nxt < n_chunks) {
-          nxt_len = std::min(CHUNK, bf->bytes - nxt * CHUNK);
-          if (hipMemcpyAsync(stage[slot ^ 1], src + nxt * CHUNK, nxt_len, hipMemcpyDeviceToHost, st) != hipSuccess) failed.store(true);
-        }
-        if (!write_at(stage[slot], cur_len, header_bytes + cur * CHUNK)) failed.store(true);
-        cur = nxt;
-        cur_len = nxt_len;
-        slot ^= 1;
-      }
+      return;
     }
-    if (st) {
-      hipStreamSynchronize(st);
-      hipStreamDestroy(st);
+    // two chunks in flight per thread: while chunk c is written to the file, chunk c' is on its way from HBM
+    uint64_t cur = next.fetch_add(1), cur_len = 0;
+    int slot = 0;
+    if (cur < n_chunks) {
+      cur_len = std::min(CHUNK, bf->bytes - cur * CHUNK);
+      if (hipMemcpyAsync(stage[slot], src + cur * CHUNK, cur_len, hipMemcpyDeviceToHost, st) != hipSuccess) failed.store(true);
     }
-    if (stage[0]) hipHostFree(stage[0]);
-    if (stage[1]) hipHostFree(stage[1]);
+    while (cur < n_chunks && !failed.load()) {
+      if (hipStreamSynchronize(st) != hipSuccess) {
+        failed.store(true);
+        break;
+      }
+      const uint64_t nxt = next.fetch_add(1);
+      uint64_t nxt_len = 0;
+      if (nxt < n_chunks) {
+        nxt_len = std::min(CHUNK, bf->bytes - nxt * CHUNK);
+        if (hipMemcpyAsync(stage[slot ^ 1], src + nxt * CHUNK, nxt_len, hipMemcpyDeviceToHost, st) != hipSuccess) failed.store(true);
+      }
+      if (!write_at(stage[slot], cur_len, header_bytes + cur * CHUNK)) failed.store(true);
+      cur = nxt;
+      cur_len = nxt_len;
+      slot ^= 1;
+    }
+    hipStreamSynchronize(st);
   };
   if (ok) {
-    const unsigned T = std::max(1u, std::min<unsigned>(n_threads ? n_threads : 6, (unsigned)std::max<uint64_t>(n_chunks, 1)));
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t < T; ++t) pool.emplace_back(worker);
+    for (unsigned t = 0; t < T; ++t) pool.emplace_back(worker, t);
     for (auto& th : pool) th.join();
   }
   close(fd);
