@@ -478,3 +478,76 @@ def test_dev_overlap_check_matches_the_oracle(capsys):
         assert got == want
         total += want.count("WARNING")
     assert total > 50
+
+
+class _ShiftedOracle(SO.SyntenyOracle):
+    """The oracle on genomes whose every record carries `shift` leading N: minimizer positions, block coordinates and
+    hard-mask intervals all move by `shift`, nothing else changes (no k-mer spans an N)."""
+    shift = 0
+
+    def sketch_masked(self, asm, ctg_masks, new_w):
+        back = {c: [(s - self.shift, e - self.shift) for s, e in ivs] for c, ivs in ctg_masks.items()}
+        info, lists = super().sketch_masked(asm, back, new_w)
+        return {h: (c, p + self.shift) for h, (c, p) in info.items()}, lists
+
+
+def shifted_oracle_run(paths, shift, k, w, w_rounds, indel, merge, block_size):
+    "oracle outputs for the family with `shift` N prepended to every record + what an engine under test needs"
+    genomes = {p: O.read_fasta(p) for p in paths}
+    bf = O.common_bf(genomes, k, 0.025, 1)
+    tables, by_tsv, initial = {}, {}, {}
+    for p in paths:
+        tsv = f"{os.path.basename(p)}.k{k}.w{w}.tsv"
+        mins = O.minimize(genomes[p], k, w, bf)
+        info, lists = SO.mx_tables_from_tokens(SO.mx_records_from_arrays(genomes[p].names, mins))
+        tables[tsv] = ({h: (c, pos + shift) for h, (c, pos) in info.items()}, lists)
+        by_tsv[tsv] = genomes[p]
+        h1, rec, pos = oracle_flat(mins)
+        initial[tsv] = (h1, rec, pos.astype(np.uint64) + np.uint64(shift))
+    ora = _ShiftedOracle(list(tables), by_tsv, k, w, w_rounds, indel, merge, block_size, "p", bf=bf)
+    ora.shift = shift
+    ora.load(tables)
+    ora.main()
+    return ora, genomes, bf, initial
+
+
+@pytest.mark.parametrize("shift", [5_000_000_000, (1 << 40) - 1_500_000])
+def test_positions_beyond_32_bits(tmp_path, shift):
+    """Records longer than 2^32 bp (and up to the engine's 2^40 limit): every position-carrying step -- composite sort
+    keys, gap arithmetic of the indel rule, mask intervals, span lookups of the refinement filter, erosion distances,
+    the merge rule, the TSV text -- on 64-bit coordinates, against the oracle."""
+    k, w, rounds, indel, merge, block = 24, 400, [100, 10], 500, 3000, 300
+    paths = synth.make_family(str(tmp_path), 3, 900_000, 3, 0.01, seed=17, micro=6)
+    cwd = os.getcwd()
+    try:
+        os.makedirs(tmp_path / "ora")
+        os.chdir(tmp_path / "ora")
+        ora, genomes, bf, initial = shifted_oracle_run(paths, shift, k, w, rounds, indel, merge, block)
+        os.makedirs(tmp_path / "eng")
+        os.chdir(tmp_path / "eng")
+        tsvs = [f"{os.path.basename(p)}.k{k}.w{w}.tsv" for p in paths]
+        glist = [genomes[p] for p in paths]
+
+        def sketch_fn(i, masks, new_w):
+            g = glist[i]
+            seqs = []
+            for r in range(len(g.names)):
+                buf = bytearray(g.record(r))
+                for mr, s, e in masks:
+                    if mr == r:
+                        s, e = max(0, int(s) - shift), min(len(buf), int(e) - shift)
+                        if e > s:
+                            buf[s:e] = b"N" * (e - s)
+                seqs.append(bytes(buf))
+            h1, rec, pos = oracle_flat(O.minimize(O.Genome(g.names, seqs), k, new_w, bf))
+            return h1, rec, pos.astype(np.uint64) + np.uint64(shift)
+
+        eng = SyntenyEngine(tsvs, [g.names for g in glist], k, w, rounds, indel, merge, block, "p", build_graph_numpy, sketch_fn,
+                            walk_paths, degree_fn=edge_degrees)
+        out = eng.run([initial[t] for t in tsvs])
+    finally:
+        os.chdir(cwd)
+    for name, text in ora.outputs.items():
+        assert out[name] == text, name
+    rows = ora.outputs["p.synteny_blocks.tsv"].splitlines()
+    assert len(rows) > 20 and all(int(r.split("\t")[3]) >= shift for r in rows)

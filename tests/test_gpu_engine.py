@@ -215,3 +215,63 @@ def test_mx_split_matches_host_split(ctx):
     batch.free()
     for g in parts:
         g.free()
+
+
+@pytest.mark.parametrize("shift", [5_000_000_000, (1 << 40) - 1_500_000])
+def test_device_engine_on_positions_beyond_32_bits(ctx, tmp_path, shift):
+    """Every record as if it began with `shift` N (records beyond 2^32 bp, up to the 2^40 limit): the device engine's 64-bit
+    positions through graph build, list ranking, indel cuts, refinement filter, erosion, merge and text vs the oracle."""
+    from ntsynt_amd.device import Genome, Minimizers, sketch, wrap_bloom  # noqa: F401
+    from ntsynt_amd.device import BloomFilter
+    from ntsynt_amd.synteny_device import DeviceSyntenyEngine
+    from tests.test_engine_cpu import shifted_oracle_run
+    k, w, rounds, indel, merge, block = 24, 400, [100, 10], 500, 3000, 300
+    paths = synth.make_family(str(tmp_path), 3, 900_000, 3, 0.01, seed=17, micro=6)
+    cwd = os.getcwd()
+    genomes = []
+    try:
+        os.makedirs(tmp_path / "ora")
+        os.chdir(tmp_path / "ora")
+        ora, og, bits, initial = shifted_oracle_run(paths, shift, k, w, rounds, indel, merge, block)
+        os.makedirs(tmp_path / "dev")
+        os.chdir(tmp_path / "dev")
+        tsvs = [f"{os.path.basename(p)}.k{k}.w{w}.tsv" for p in paths]
+        for p in paths:
+            g = og[p]
+            seq = b"".join(g.record(r) for r in range(len(g.names)))
+            lens = np.array([len(g.record(r)) for r in range(len(g.names))], np.uint64)
+            off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+            genomes.append(Genome(ctx, g.names, np.frombuffer(seq, np.uint8), off, lens))
+        bf = BloomFilter(ctx, bits.size, k)
+        bf.from_numpy(bits)
+
+        def moved(mx):
+            h1, rec, pos = mx.to_numpy()
+            mx.free()
+            return Minimizers.from_numpy(ctx, h1, rec, pos + np.uint64(shift))
+
+        def sketch_dev(masks_by_asm, new_w):
+            out = {}
+            for i, m in masks_by_asm.items():
+                m = m.copy()
+                m["start"] -= np.uint64(shift)
+                m["end"] -= np.uint64(shift)
+                out[i] = moved(sketch(ctx, genomes[i], k, new_w, bf, m))
+            return out
+
+        # the device's own initial sketch, moved, must be the oracle's moved list
+        handles = []
+        for i, t in enumerate(tsvs):
+            mx = moved(sketch(ctx, genomes[i], k, w, bf))
+            for a, b in zip(mx.to_numpy(), initial[t]):
+                assert np.array_equal(a, b)
+            handles.append(mx)
+        dev = DeviceSyntenyEngine(ctx, tsvs, [og[p].names for p in paths], k, w, rounds, indel, merge, block, "p", sketch_dev)
+        out = dev.run(handles)
+    finally:
+        os.chdir(cwd)
+        for g in genomes:
+            g.free()
+    for name, text in ora.outputs.items():
+        assert out[name] == text, name
+    assert all(int(r.split("\t")[3]) >= shift for r in ora.outputs["p.synteny_blocks.tsv"].splitlines())

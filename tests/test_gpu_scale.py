@@ -79,3 +79,44 @@ def test_three_gbp_genome_sketch_properties_and_slice_parity(ctx):
     for g in (g0, g1):
         g.free()
     common.free()
+
+
+def test_records_longer_than_2_to_32(ctx):
+    """Two 4.6 Gbp records (lungfish-scale chromosomes; 46 GB filter): pruned == dense, positions beyond 2^32 come back, and the
+    oracle agrees on slices either side of the 2^32 boundary of both records."""
+    from ntsynt_amd.device import BloomFilter, Genome, bf_size_bytes, sketch
+    k, w, contigs, total = 24, 1000, 2, 9_200_000_000
+    g0 = Genome.synth(ctx, total, contigs, 77, 1, 0.005)
+    g1 = Genome.synth(ctx, total, contigs, 77, 2, 0.005)
+    assert g0.total_bp == total and g0.valid_kmers(k) == total - contigs * (k - 1)
+    _, nbytes = bf_size_bytes(total, 0.025)
+    common = BloomFilter(ctx, nbytes, k)
+    common.insert(g0)
+    assert abs(common.get_fpr() - 0.025) < 0.001
+    other = BloomFilter(ctx, nbytes, k)
+    other.insert(g1)
+    common.and_(other)
+    other.free()
+    res = {}
+    for mode in ("pruned", "dense"):
+        ctx.sketch_mode(mode)
+        res[mode] = sketch(ctx, g1, k, w, common).to_numpy()
+    ctx.sketch_mode("auto")
+    for a, b in zip(res["pruned"], res["dense"]):
+        assert np.array_equal(a, b)
+    h1, rec, pos = res["pruned"]
+    per = total // contigs
+    assert int(pos.max()) > (1 << 32) and int(pos.max()) <= per - k
+    bits = common.to_numpy()
+    n_slice = 1_000_000
+    for r in (0, 1):
+        for start in (0, (1 << 32) - 500_000, per - n_slice):
+            seq = g1.download(int(g1.rec_off[r]) + start, n_slice).tobytes()
+            exp = O.minimize(O.Genome(["s"], [seq]), k, w, bits)[0]
+            m = (rec == r) & (pos >= start + w + k) & (pos < start + n_slice - k - w)   # windows wholly inside the slice
+            e = (exp[1] >= w + k) & (exp[1] < n_slice - k - w)
+            assert int(m.sum()) > 500
+            assert np.array_equal(pos[m] - np.uint64(start), exp[1][e].astype(np.uint64)) and np.array_equal(h1[m], exp[0][e])
+    for g in (g0, g1):
+        g.free()
+    common.free()
