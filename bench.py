@@ -455,7 +455,7 @@ def main():
     valu = None
     if world == 1:
         # VALU roof of the issue-bound kernel: measured issue rate of its instruction mix's slowest member (nts_bench_valu)
-        rows = {kind: ctx.bench_valu(kind, 8, 20000) for kind in ("v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64")}
+        rows = {kind: ctx.bench_valu(kind, 8, 20000) for kind in ("v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64", "roll31 step (9 instructions)")}
         valu = {"wave_instr_per_s_per_cu": {n: round(r["wave_instr_per_s_per_cu"] / 1e9, 3) for n, r in rows.items()},
                 "unit": "G wave-instructions/s/CU", "how": "nts_bench_valu: 8 waves per SIMD, eight independent chains per lane, wall clock"}
 
@@ -499,7 +499,11 @@ def main():
         value = bases_total(n_fam, genomes) * args.steps / dt / 1e9
         pruned_run = tm["hash_select"][1] > 0
         if pruned_run:
-            kern, a_ms = "k_hash_select (hash every k-mer, probe candidates only)", avg("hash_select")
+            # (the library's rule: upper-halves kernel for k <= 32 while a 4096-index tile lists at most ~180 k-mers)
+            hi_kernel = k <= 32 and 4096.0 * c_used / w * 1.4 <= 256.0
+            kern = ("k_hash_select_hi (upper halves of both strand hashes rolled for every k-mer; the ~c/w listed k-mers hashed in full and probed, "
+                    "probes overlapped with the next tile)") if hi_kernel else "k_hash_select (hash every k-mer, probe candidates only)"
+            a_ms = avg("hash_select")
             probe_frac = min(1.0, c_used / w)
             # bytes the pruned kernel has to move per base: the base (2 bits, from the packed image of the genome),
             # one sector per probed candidate, 16 B per accepted candidate written
@@ -507,25 +511,35 @@ def main():
         else:
             kern, a_ms = "k_hash<MODE_KEYS> (every k-mer probed)", avg("hash_probe")
             bpb = dense_bpb
+            hi_kernel = False
         achieved = bpb * per_launch_bases / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
         if valu is not None and pruned_run and a_ms > 0:
-            # VALU wave-instructions per 64 k-mers from the PMC pass (profiles/r02_sq_counters.json); the roof: the issue rate the
-            # microbenchmark measures for the slowest class of the kernel's instruction mix (3-operand / 64-bit integer ops)
-            per_64 = 29.8
+            # VALU wave-instructions per 64 k-mers from the PMC pass (profiles/r02_sq_counters.json); the roof: the issue rates
+            # the microbenchmark measures for the classes of the kernel's instruction mix
+            key = "k_hash_select_hi" if hi_kernel else "k_hash_select"
+            per_64 = 17.2 if hi_kernel else 29.8
             try:
                 sq = json.load(open(os.path.join(ROOT, "profiles", "r02_sq_counters.json")))
-                per_64 = float(sq["kernels"]["k_hash_select"]["valu_wave_instructions_per_64_kmers"])
+                per_64 = float(sq["kernels"][key]["valu_wave_instructions_per_64_kmers"])
             except (OSError, KeyError, ValueError):
                 pass
             n_cu = 256
             ach_v = per_64 * per_launch_bases / 64.0 / (a_ms * 1e-3) / n_cu / 1e9
-            # the rolling step is ~12 two-operand 32-bit operations (xor / and / shift class) and ~17 three-operand or 64-bit ones
-            # (alignbit, bfi, lshl_add_u64 class): the roof of that mix
-            fast, slow = valu["wave_instr_per_s_per_cu"]["v_xor_b32"], min(valu["wave_instr_per_s_per_cu"]["v_alignbit_b32"],
-                                                                           valu["wave_instr_per_s_per_cu"]["v_lshl_add_u64"])
-            peak_v = 29.0 / (12.0 / fast + 17.0 / slow)
-            valu.update({"kernel": "k_hash_select", "valu_wave_instr_per_64_kmers": per_64, "achieved": round(ach_v, 3),
-                         "peak": round(peak_v, 3), "frac": round(ach_v / peak_v, 3),
+            rate = valu["wave_instr_per_s_per_cu"]
+            fast, slow = rate["v_xor_b32"], min(rate["v_alignbit_b32"], rate["v_lshl_add_u64"])
+            if hi_kernel:
+                # per k-mer: the 9-instruction rolling step (measured as a unit) + 2 two-operand instructions for the table offset;
+                # the rest (listing, full hashes of the listed k-mers, probes, output: per_64 - 11 per k-mer) priced half and half
+                rest = max(per_64 - 11.0, 0.0)
+                peak_v = per_64 / (9.0 / rate["roll31 step (9 instructions)"] + 2.0 / fast + rest * 0.5 / fast + rest * 0.5 / slow)
+                mix = "9 (rolling step, measured as a unit) + 2 two-operand + the rest half two-operand, half three-operand"
+            else:
+                # the rolling step is ~12 two-operand 32-bit operations (xor / and / shift class) and ~17 three-operand or 64-bit ones
+                # (alignbit, bfi, lshl_add_u64 class): the roof of that mix
+                peak_v = 29.0 / (12.0 / fast + 17.0 / slow)
+                mix = "12 two-operand + 17 three-operand or 64-bit per k-mer"
+            valu.update({"kernel": key, "valu_wave_instr_per_64_kmers": per_64, "achieved": round(ach_v, 3),
+                         "peak": round(peak_v, 3), "frac": round(ach_v / peak_v, 3), "mix": mix,
                          "peak_if_all_slow_class": slow, "peak_if_all_fast_class": fast})
         out = {
             "metric": "minimizer-sketch Gbases/s (sketch with common Bloom filter, inputs resident in HBM)",
@@ -613,7 +627,8 @@ def pmc_traffic(name, pruned_run):
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if name != "c3" or not os.path.exists(path):
         return None
-    k = json.load(open(path))["kernels"].get("k_hash_select" if pruned_run else "k_hash<0>")
+    kernels = json.load(open(path))["kernels"]
+    k = (kernels.get("k_hash_select_hi") or kernels.get("k_hash_select")) if pruned_run else kernels.get("k_hash<0>")
     if not k:
         return None
     raw = (k["fetch_MB_per_launch_max"] + k["write_MB_per_launch_max"]) * 1024 * 1024

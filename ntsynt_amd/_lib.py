@@ -105,6 +105,7 @@ SYMBOLS = [
                                   ctypes.POINTER(c_vp)]),
     ("nts_sketch_mode", ctypes.c_int, [c_vp, ctypes.c_int, u32]),
     ("nts_sketch_summary", ctypes.c_int, [c_vp, ctypes.c_int, c_u32p]),
+    ("nts_sketch_select", ctypes.c_int, [c_vp, ctypes.c_int]),
     ("nts_sketch_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u64p, c_u32p]),
     ("nts_mx_count", u64, [c_vp]),
     ("nts_mx_free", None, [c_vp, c_vp]),

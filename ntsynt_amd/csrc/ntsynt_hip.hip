@@ -104,6 +104,7 @@ struct nts_ctx
     uint8_t* stage[2] = { nullptr, nullptr };
   };
   std::vector<IoLane> io_up, io_down;
+  int select_impl = 0;  // candidate selection of the pruned sketch: 0 auto (upper-halves kernel where it applies), 1 full-width kernel
   int summary_mode = 0; // 0 auto, 1 never (tests)
   uint32_t last_summary = 0;
 };
@@ -2127,7 +2128,7 @@ int nts_bench_valu(nts_ctx* ctx, int kind, uint32_t waves_per_simd, uint32_t ite
   hipEventDestroy(a);
   hipEventDestroy(b);
   if (e != hipSuccess) return fail(ctx, NTS_EHIP, std::string("nts_bench_valu: ") + hipGetErrorString(e));
-  const double per_iter = (double)VB_CHAINS * VB_UNROLL * (kind == VK_ADD_CO_PAIR ? 2 : 1);
+  const double per_iter = (double)VB_CHAINS * VB_UNROLL * (kind == VK_ADD_CO_PAIR || kind == VK_CMP_ADDC ? 2 : kind == VK_ROLL31_STEP ? 9 : 1);
   const double n_instr = per_iter * iters;
   std::sort(cyc.begin(), cyc.end());
   const double median = (double)cyc[n_waves / 2];
@@ -2356,9 +2357,9 @@ constexpr uint32_t GAP_PEEK = 1024; // uncovered ranges fetched together with th
 // small device results -> the context's pinned mailbox (up to 6 ranges of 64-bit words)
 struct MailParams
 {
-  const uint64_t* src[6];
-  uint32_t n[6];
-  uint32_t off[6];
+  const uint64_t* src[8];
+  uint32_t n[8];
+  uint32_t off[8];
   uint32_t count;
   uint64_t seq; // arrival flag value, written to the last word of the mailbox
   uint64_t* mail;
@@ -2592,7 +2593,8 @@ int ensure_pack(nts_ctx* ctx, const nts_genome* g)
   if (g->d_pack) return NTS_OK;
   const uint64_t n_words = (g->n + PAD) / 16; // the trailing pad is readable: look-ahead past the last base stays in bounds
   uint32_t* p = nullptr;
-  HIP_TRY(ctx, hipMalloc((void**)&p, std::max<uint64_t>(n_words, 1) * 4));
+  // (320 more words that nothing looks at: k_hash_select_hi stages 272 words from the word of a tile's first base on)
+  HIP_TRY(ctx, hipMalloc((void**)&p, (n_words + 320) * 4));
   if (n_words) hipLaunchKernelGGL(k_pack2, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, g->d_code + PAD, n_words, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -2638,7 +2640,11 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
 {
   const RunTable& rt = T.rt;
   const uint64_t V = rt.n_valid;
-  const uint64_t sel_tile = accept_all ? (uint64_t)KEY_TILE : (uint64_t)SEL_TILE;
+  // the upper-halves select kernel (k <= 32, threshold below half the hash range) works on wave tiles
+  // (and a listing that fits one round of 4 per lane with room to spare: ~4096 c/w k-mers per tile; beyond that k_hash_select)
+  const bool sel_hi = !accept_all && ctx->select_impl != 1 && k <= HI_K_MAX && 4096.0 * prune_c / w * 1.4 <= 256.0;
+  const uint32_t hi_per = 4096.0 * prune_c / w * 1.5 <= 128.0 ? 2u : 4u; // listed k-mers per lane and round
+  const uint64_t sel_tile = accept_all ? (uint64_t)KEY_TILE : sel_hi ? (uint64_t)HIW_TILE : (uint64_t)SEL_TILE;
   const uint64_t n_kt = (V + sel_tile - 1) / sel_tile; // tiles of the select kernel (16384 indices each; 8192 for k_hash_accept)
   if (n_kt > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
   // threshold: a fraction c/w of all hashes
@@ -2652,7 +2658,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   type ptr = (type)ws_get(ctx, name, bytes);                                                        \
   if (!ptr) return NTS_ENOMEM
   PR_WS(d_toff, uint64_t*, "sel_tile_off", n_kt * 8);
-  PR_WS(d_tcnt, uint32_t*, "sel_tile_cnt", n_kt * 4);
+  PR_WS(d_tcnt, uint32_t*, "sel_tile_cnt", n_kt * 4 + 8);
   PR_WS(d_tord, uint8_t*, "sel_tile_ord", n_kt);
   PR_WS(d_tscan, uint64_t*, "sel_tile_scan", n_kt * 8);
   // control block: [0..63] candidate segment counters, [64] uncovered-range counter, [65] "a tile list did not fit"
@@ -2669,8 +2675,10 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   for (int attempt = 0; attempt < 2; ++attempt) {
     const uint64_t m_max = cseg_cap * N_SEG;
     const uint64_t n_blk = (m_max + SPARSE_THREADS - 1) / SPARSE_THREADS;
-    d_sj = (uint64_t*)ws_get(ctx, "sel_seg_j", m_max * 8);
-    d_sk = (uint64_t*)ws_get(ctx, "sel_seg_key", m_max * 8);
+    // (upper-halves select kernel: one slot of 64 * hi_per entries per tile in front of the segments)
+    const uint64_t slot_words = sel_hi ? n_kt * 64ull * hi_per : 0ull;
+    d_sj = (uint64_t*)ws_get(ctx, "sel_seg_j", (slot_words + m_max) * 8);
+    d_sk = (uint64_t*)ws_get(ctx, "sel_seg_key", (slot_words + m_max) * 8);
     PR_WS(d_pj, uint64_t*, "cand_j", m_max * 8);
     PR_WS(d_pk, uint64_t*, "cand_key", m_max * 8);
     PR_WS(d_stj, uint64_t*, "stage_j", n_blk * SPARSE_THREADS * 8);
@@ -2742,7 +2750,24 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
         const uint32_t need = (uint32_t)std::min(16.0, std::ceil(48.0 * frac + 4.0));
         S.flush_at = slots == 8 ? 8u : slots - need;
       }
-      if (64.0 * frac > 2.5)
+      const uint32_t nch = (k + 3) / 4;
+      if (sel_hi) {
+        // tiles per wave: enough to amortise the table load and to overlap probes with rolling, not so many that a small genome leaves CUs idle
+        const uint64_t waves_wanted = 256ull * 32ull * 2ull;
+        uint32_t tpw = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, n_kt / waves_wanted));
+        if (getenv("NTS_HI_TPW")) tpw = (uint32_t)atoi(getenv("NTS_HI_TPW")); // DEBUG
+        const uint64_t per_wg = (uint64_t)HIW_WAVES * tpw;
+        const dim3 grid((uint32_t)((n_kt + per_wg - 1) / per_wg));
+        if (filter && hi_per == 2)
+          hipLaunchKernelGGL((k_hash_select_hi<true, 2>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
+        else if (filter)
+          hipLaunchKernelGGL((k_hash_select_hi<true, 4>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
+        else if (hi_per == 2)
+          hipLaunchKernelGGL((k_hash_select_hi<false, 2>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
+        else
+          hipLaunchKernelGGL((k_hash_select_hi<false, 4>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
+      }
+      else if (64.0 * frac > 2.5)
         hipLaunchKernelGGL(k_hash_select<16>, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
       else
         hipLaunchKernelGGL(k_hash_select<8>, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
@@ -2750,8 +2775,12 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     {
       ScopedTimer t(ctx, "cand_compact");
       if (int rc_s = scan_counts<uint32_t>(ctx, d_tcnt, n_kt, d_tscan)) return rc_s;
-      hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)((n_kt + CC_TILES - 1) / CC_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tord, d_tscan, n_kt,
-                         d_pj, d_pk, m_max, d_ctl + N_SEG + 1);
+      if (sel_hi)
+        hipLaunchKernelGGL(k_cand_compact_slots, dim3((uint32_t)((n_kt + CCS_TILES - 1) / CCS_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, d_toff, d_tcnt, d_tscan, n_kt,
+                           d_pj, d_pk, m_max, d_ctl + N_SEG + 1);
+      else
+        hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)((n_kt + CC_TILES - 1) / CC_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tord, d_tscan, n_kt,
+                           d_pj, d_pk, m_max, d_ctl + N_SEG + 1, false);
     }
     SparseParams Q;
     Q.pj = d_pj;
@@ -2780,14 +2809,16 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     }
     HIP_TRY(ctx, hipGetLastError());
     // one synchronisation: candidate counters, uncovered-range count + a first batch of ranges, winner count
-    uint64_t last_scan = 0, last_cnt = 0;
+    uint64_t last_scan = 0, last_cnt = 0, listed = 0;
     {
-      static_assert(N_SEG + 3 + 2 * GAP_PEEK < MAIL_WORDS, "mailbox too small (the last word is the arrival flag)");
+      static_assert(N_SEG + 5 + 2 * GAP_PEEK < MAIL_WORDS, "mailbox too small (the last word is the arrival flag)");
       const uint32_t peek = (uint32_t)std::min<uint64_t>(GAP_PEEK, gap_cap);
       Mail mb(ctx);
       const uint32_t a_ctl = mb.add(d_ctl, N_SEG + 1);
       const uint32_t a_scan = mb.add(d_bscan + (n_blk - 1), 1);
       const uint32_t a_cnt = mb.add(d_bcnt + (n_blk - 1), 1);
+      const uint32_t a_tscan = mb.add(d_tscan + (n_kt - 1), 1);
+      const uint32_t a_tcnt = mb.add((const uint64_t*)(d_tcnt + ((n_kt - 1) & ~1ull)), 1); // (32-bit counts: the pair holding the last one)
       const uint32_t a_lo = mb.add(d_glo, peek);
       const uint32_t a_hi = mb.add(d_ghi, peek);
       // the gather runs behind the mail kernel: the counters are on their way to the host while it works
@@ -2802,6 +2833,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       for (uint32_t i = 0; i <= N_SEG; ++i) ctl[i] = ctx->mail[a_ctl + i];
       last_scan = ctx->mail[a_scan];
       last_cnt = ctx->mail[a_cnt];
+      listed = ctx->mail[a_tscan] + (uint32_t)(ctx->mail[a_tcnt] >> (32 * ((n_kt - 1) & 1ull)));
       memcpy(glo.data(), ctx->mail + a_lo, (size_t)peek * 8);
       memcpy(ghi.data(), ctx->mail + a_hi, (size_t)peek * 8);
     }
@@ -2813,6 +2845,10 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     }
     n_gap = ctl[N_SEG];
     n_sparse = last_scan + last_cnt;
+    if (sel_hi) { // the tiles' own slots are not counted by the segment counters: the directory's total is
+      m = listed;
+      if (listed > m_max) worst = std::max<uint64_t>(worst, listed / N_SEG + 1); // the compacted array was cut short
+    }
     if (worst <= cseg_cap) break;
     if (attempt == 1) return fail(ctx, NTS_EHIP, "candidate segments overflowed twice");
     cseg_cap = worst + 1024; // candidate lists were truncated: everything downstream of them is void; run again
@@ -2918,6 +2954,13 @@ extern "C" int nts_sketch_summary(nts_ctx* ctx, int mode, uint32_t* last_shift)
   return NTS_OK;
 }
 
+extern "C" int nts_sketch_select(nts_ctx* ctx, int impl)
+{
+  if (!ctx || impl < 0 || impl > 1) return fail(ctx, NTS_EINVAL, "nts_sketch_select: impl is 0 (auto) or 1 (full-width rolling)");
+  ctx->select_impl = impl;
+  return NTS_OK;
+}
+
 extern "C" int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers, uint32_t* prune_c_used)
 {
   if (!ctx) return NTS_EINVAL;
@@ -3001,9 +3044,11 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
         p = share((double)rt.n_valid);
       }
     }
-    // c*p = 12 accepted candidates per window on average.  (More would not empty the list of uncovered ranges:
-    // beyond the ~V*(cp/w)*exp(-cp) chance ones there are the stretches the other genomes do not share at all.)
-    const double cp = 12.0;
+    // c*p = 11 accepted candidates per window on average.  (More would not empty the list of uncovered ranges:
+    // beyond the ~V*(cp/w)*exp(-cp) chance ones there are the stretches the other genomes do not share at all.
+    // Measured at 3 x 3 Gbp, w = 1000, p = 0.66, with k_hash_select_hi: c = 14 / 16 / 18 / 22 -> 966 / 1065 / 1024 / 832
+    // Gbases/s; with k_hash_select, whose rolling cost twice as much per k-mer, the optimum was c = 18, cp = 12.)
+    const double cp = 11.0;
     const double want = std::max(8.0, std::ceil(cp / std::max(p, 1e-4)));
     // (measured: at a quarter of the k-mers as candidates the pruned pass is still twice as fast as the dense one;
     // at 40 % single lanes run out of slots in most tiles and it is half as fast)

@@ -62,6 +62,10 @@ class Context:
         self.check(self.lib.nts_sketch_summary(self.h, code, ctypes.byref(last)), "nts_sketch_summary")
         return last.value
 
+    def sketch_select(self, impl="auto"):
+        "candidate selection kernel of the pruned sketch (nts_sketch_select): 'auto' or 'full' (full-width rolling); same result"
+        self.check(self.lib.nts_sketch_select(self.h, {"auto": 0, "full": 1}[impl]), "nts_sketch_select")
+
     def bf_build_mode(self, mode="auto"):
         """How BloomFilter.insert sets the bits: 'auto' (partitioned streaming build for large genomes), 'atomic'
         (one atomic OR per k-mer) or 'binned' (partitioned whenever the filter layout allows); same filter."""
@@ -76,7 +80,8 @@ class Context:
         return a.value, b.value, c.value
 
     VALU_KINDS = ["v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64", "v_lshlrev_b64", "v_mul_lo_u32", "v_mad_u64_u32",
-                  "v_add_co_u32+v_addc_co_u32", "v_xor_b32 (dependent chain)"]
+                  "v_add_co_u32+v_addc_co_u32", "v_xor_b32 (dependent chain)", "v_add3_u32", "v_cmp_ge_u32+v_addc_co_u32",
+                  "roll31 step (9 instructions)"]
 
     def bench_valu(self, kind, waves_per_simd=4, iters=20000):
         """Issue-rate microbenchmark of one integer VALU instruction (nts_bench_valu): dict with the shader cycles a SIMD

@@ -16,7 +16,7 @@ import json
 import re
 import sys
 
-KEEP = ["k_hash_select", "k_sparse_win", "k_cand_compact", "k_bin1", "k_bin2", "k_bin3", "k_hash<0>", "k_window_min"]
+KEEP = ["k_hash_select", "k_hash_select_hi", "k_sparse_win", "k_cand_compact", "k_bin1", "k_bin2", "k_bin3", "k_hash<0>", "k_window_min"]
 import os
 
 # k-mers per launch: NTS_PROF_KMERS for the bench command's genomes (round 2: 3 Gbp genomes, one launch sequence each);
@@ -30,7 +30,7 @@ def short(n):
     m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", n)
     if not m or "rocprim" in n:
         return None
-    return m.group(1) if m.group(1) == "k_hash_select" else m.group(0)   # (slot-count template: one row)
+    return m.group(1) if m.group(1) in ("k_hash_select", "k_hash_select_hi") else m.group(0)   # (slot-count template: one row)
 
 
 def main():

@@ -429,3 +429,55 @@ def test_long_and_degenerate_k_end_to_end(ctx, k):
                     assert np.array_equal(a, b.astype(a.dtype)), (mode, k, w)
     finally:
         ctx.sketch_mode("auto", 0)
+
+
+@pytest.mark.parametrize("tpw", ["1", "3"])
+@pytest.mark.parametrize("k,w,c", [(24, 1000, 16), (20, 700, 12), (32, 400, 6), (24, 250, 9), (31, 1000, 40), (33, 1000, 16)])
+def test_select_kernels_agree(ctx, monkeypatch, k, w, c, tpw):
+    """The two candidate-selection kernels of the pruned sketch (k_hash_select_hi: upper halves rolled, listed k-mers hashed in
+    full, probes overlapped with the next tile; k_hash_select: full-width rolling) and the dense path give the oracle's list:
+    fragmented records with N runs (tiles that span runs), a satellite repeat (tiles that list more k-mers than a round
+    holds), records shorter than k, with and without a filter, one and several tiles per wave (NTS_HI_TPW), both list
+    widths (c/w below and above 1/42), k on either side of the kernel's limit (k = 33: full-width kernel in both settings)."""
+    from ntsynt_amd.device import BloomFilter, sketch
+    monkeypatch.setenv("NTS_HI_TPW", tpw)
+    rng = np.random.default_rng(1234 + k)
+    _, clean = _family(177 + k, lengths=[260000, 100000])        # whole tiles inside one run: the pipelined path
+    _, ragged = _family(77 + k, lengths=[900, 20, 0, 130000, 41000, 5000, 3000, 2999, 70000], n_frac=0.003)   # an N every ~300 bases
+    seqs = list(clean) + list(ragged)
+    names = [f"r{i}" for i in range(len(seqs))]
+    big = bytearray(seqs[0])
+    big[60000:90000] = (b"ACGTTGCA" * 4000)[:30000]          # period-8 satellite: a handful of distinct k-mers, thousands of copies
+    big[150000:150300] = b"A" * 300
+    seqs[0] = bytes(big)
+    other = []
+    for s in seqs:
+        a = np.frombuffer(s, dtype=np.uint8).copy()
+        hit = (rng.random(a.size) < 0.01) & (a != ord("N"))
+        a[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+        other.append(a.tobytes())
+    og = [to_oracle(names, seqs), to_oracle(names, other)]
+    dg = [to_device(ctx, names, seqs), to_device(ctx, names, other)]
+    nbytes = O.bf_ctor_bytes(O.bf_approx_bytes(og[0].total_bp, 0.025))
+    obf = O.bf_build(og[1], k, nbytes, prev=O.bf_build(og[0], k, nbytes))
+    dbf = BloomFilter(ctx, nbytes, k)
+    dbf.from_numpy(obf)
+    try:
+        for o, d in zip(og, dg):
+            for bf_o, bf_d in ((obf, dbf), (None, None)):
+                exp = oracle_flat(O.minimize(o, k, w, bf_o))
+                assert exp[0].size > 100
+                for impl in ("auto", "full"):
+                    ctx.sketch_select(impl)
+                    ctx.sketch_mode("pruned", c)
+                    got = sketch(ctx, d, k, w, bf_d).to_numpy()
+                    for a, b in zip(got, exp):
+                        assert np.array_equal(a, b.astype(a.dtype)), (impl, k, w, c, bf_o is not None)
+                    cand, _, _ = ctx.sketch_stats()
+                    assert cand > 0
+    finally:
+        ctx.sketch_select("auto")
+        ctx.sketch_mode("auto", 0)
+        dbf.free()
+        for d in dg:
+            d.free()
