@@ -219,8 +219,9 @@ int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c);
  * nts_sketch call used (0: it did not use a summary). */
 int nts_sketch_summary(nts_ctx* ctx, int mode, uint32_t* last_shift);
 /* Candidate selection of the pruned sketch (k_hash_select_hi / k_hash_select): 0 = automatic (the kernel that rolls only the
-   upper halves of the strand hashes where it applies: k <= 32, threshold below half the hash range), 1 = always the
-   full-width kernel.  Results are identical; tests and measurements switch it. */
+   upper halves of the strand hashes where it applies -- k <= 32, at most ~180 candidates per 4096 k-mers -- and pays -- fewer
+   than one run of valid bases per two tiles), 1 = always the full-width kernel, 2 = the upper-halves kernel wherever it
+   applies, fragmented assemblies included.  Results are identical; tests and measurements switch it. */
 int nts_sketch_select(nts_ctx* ctx, int impl);
 /* of the last nts_sketch call: accepted candidates, uncovered ranges handed to the dense kernels, the number of
  * k-mers in them, and the c that was used (all 0 for a dense-mode call) */

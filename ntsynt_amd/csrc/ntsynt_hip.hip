@@ -104,7 +104,7 @@ struct nts_ctx
     uint8_t* stage[2] = { nullptr, nullptr };
   };
   std::vector<IoLane> io_up, io_down;
-  int select_impl = 0;  // candidate selection of the pruned sketch: 0 auto (upper-halves kernel where it applies), 1 full-width kernel
+  int select_impl = 0;  // candidate selection of the pruned sketch: 0 auto, 1 full-width kernel, 2 upper-halves kernel also for assemblies in pieces
   int summary_mode = 0; // 0 auto, 1 never (tests)
   uint32_t last_summary = 0;
 };
@@ -2642,7 +2642,11 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   const uint64_t V = rt.n_valid;
   // the upper-halves select kernel (k <= 32, threshold below half the hash range) works on wave tiles
   // (and a listing that fits one round of 4 per lane with room to spare: ~4096 c/w k-mers per tile; beyond that k_hash_select)
-  const bool sel_hi = !accept_all && ctx->select_impl != 1 && k <= HI_K_MAX && 4096.0 * prune_c / w * 1.4 <= 256.0;
+  // (and an assembly that is not in pieces: a tile that spans runs lists 64 k-mers per boundary and looks positions up
+  // per k-mer.  3 Gbp in 24 / 5,000 / 100,000 / 1,000,000 contigs: 1.43 / 1.56 / 2.12 / 7.29 ms against k_hash_select's
+  // 2.19 / 2.26 / 2.82 / 4.39 -- it keeps the assemblies with more than one run per two tiles)
+  const bool sel_hi = !accept_all && ctx->select_impl != 1 && k <= HI_K_MAX && 4096.0 * prune_c / w * 1.4 <= 256.0 &&
+                      (ctx->select_impl == 2 || 2ull * T.n_runs <= (V + HIW_TILE - 1) / HIW_TILE + 64);
   const uint32_t hi_per = 4096.0 * prune_c / w * 1.5 <= 128.0 ? 2u : 4u; // listed k-mers per lane and round
   const uint64_t sel_tile = accept_all ? (uint64_t)KEY_TILE : sel_hi ? (uint64_t)HIW_TILE : (uint64_t)SEL_TILE;
   const uint64_t n_kt = (V + sel_tile - 1) / sel_tile; // tiles of the select kernel (16384 indices each; 8192 for k_hash_accept)
@@ -2956,7 +2960,8 @@ extern "C" int nts_sketch_summary(nts_ctx* ctx, int mode, uint32_t* last_shift)
 
 extern "C" int nts_sketch_select(nts_ctx* ctx, int impl)
 {
-  if (!ctx || impl < 0 || impl > 1) return fail(ctx, NTS_EINVAL, "nts_sketch_select: impl is 0 (auto) or 1 (full-width rolling)");
+  if (!ctx || impl < 0 || impl > 2)
+    return fail(ctx, NTS_EINVAL, "nts_sketch_select: impl is 0 (auto), 1 (full-width rolling) or 2 (upper halves wherever the kernel applies)");
   ctx->select_impl = impl;
   return NTS_OK;
 }

@@ -63,8 +63,9 @@ class Context:
         return last.value
 
     def sketch_select(self, impl="auto"):
-        "candidate selection kernel of the pruned sketch (nts_sketch_select): 'auto' or 'full' (full-width rolling); same result"
-        self.check(self.lib.nts_sketch_select(self.h, {"auto": 0, "full": 1}[impl]), "nts_sketch_select")
+        """candidate selection kernel of the pruned sketch (nts_sketch_select): 'auto', 'full' (full-width rolling) or 'hi' (upper
+        halves rolled, also for assemblies in many pieces); same result"""
+        self.check(self.lib.nts_sketch_select(self.h, {"auto": 0, "full": 1, "hi": 2}[impl]), "nts_sketch_select")
 
     def bf_build_mode(self, mode="auto"):
         """How BloomFilter.insert sets the bits: 'auto' (partitioned streaming build for large genomes), 'atomic'

@@ -467,7 +467,7 @@ def test_select_kernels_agree(ctx, monkeypatch, k, w, c, tpw):
             for bf_o, bf_d in ((obf, dbf), (None, None)):
                 exp = oracle_flat(O.minimize(o, k, w, bf_o))
                 assert exp[0].size > 100
-                for impl in ("auto", "full"):
+                for impl in ("hi", "auto", "full"):
                     ctx.sketch_select(impl)
                     ctx.sketch_mode("pruned", c)
                     got = sketch(ctx, d, k, w, bf_d).to_numpy()
