@@ -429,8 +429,12 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
                                                        uint32_t* __restrict__ bf_out,
                                                        FastMod fm,
                                                        uint64_t* __restrict__ keys,
-                                                       const uint32_t* __restrict__ tile_ids)
+                                                       const uint32_t* __restrict__ tile_ids,
+                                                       const uint2* __restrict__ tile_span)
 {
+  // tile_span (with tile_ids): per listed tile the first and last in-tile index whose key anybody reads (the uncovered ranges
+  // inside it); only those are probed, the rest are written as rejected -- a listed tile holds one or two ranges of ~w..3w
+  // k-mers, and probing all 8192 was nine tenths of this pass
   __shared__ uint64_t s_tab[36];
   __shared__ uint32_t s_seq[SEQ_LDS_DWORDS];
   const uint32_t tid = threadIdx.x;
@@ -445,6 +449,7 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
   // with a tile list, the keys of the i-th listed tile go to slot i of a compact key buffer
   const uint64_t KB = (uint64_t)blockIdx.x * KEY_TILE;
   const uint32_t tile_len = (uint32_t)min((uint64_t)KEY_TILE, n_valid - J0);
+  const uint2 span = (tile_ids && tile_span) ? tile_span[blockIdx.x] : make_uint2(0u, KEY_TILE - 1u);
   // run holding J0 (same for every lane: broadcast loads)
   uint32_t lo = 0, hi = n_runs;
   while (hi - lo > 1) {
@@ -497,12 +502,14 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             const uint64_t idx = fm(h[u]);
-            wd[u] = bf_in[idx >> 5];
-            bit[u] = (uint32_t)idx & 31u;
+            const uint32_t e = first + b0 + (uint32_t)u;
+            const bool wanted = e >= span.x && e <= span.y;
+            wd[u] = bf_in[wanted ? idx >> 5 : 0ULL]; // (word 0 is cached; the result is not used)
+            bit[u] = wanted ? (uint32_t)idx & 31u : 32u;
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            if (!((wd[u] >> bit[u]) & 1u)) h[u] = KEY_MAX;
+            if (bit[u] == 32u || !((wd[u] >> bit[u]) & 1u)) h[u] = KEY_MAX;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -539,7 +546,11 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
       r = srol1(r) ^ s_tab[32 + 3 - code[p + k - 1 - i]];
     }
     for (;;) {
-      hash_emit<MODE>(f + r, true, KB + (key_phys(j) - J0), bf_in, bf_out, fm, keys);
+      const uint32_t e = (uint32_t)(j - J0);
+      if (MODE == MODE_KEYS && (e < span.x || e > span.y))
+        keys[KB + (key_phys(j) - J0)] = KEY_MAX;
+      else
+        hash_emit<MODE>(f + r, true, KB + (key_phys(j) - J0), bf_in, bf_out, fm, keys);
       ++j;
       if (j >= seg_end) break;
       const uint32_t cout = code[p], cin = code[p + k];
@@ -1452,7 +1463,8 @@ int get_tables(nts_ctx* ctx, const nts_genome* g, uint32_t k, const nts_interval
 
 template <int MODE>
 int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const GenomeTables& T, uint32_t k,
-                const nts_bf* bf_in, nts_bf* bf_out, uint64_t* keys, const uint32_t* d_tile_ids = nullptr, uint64_t n_tile_ids = 0)
+                const nts_bf* bf_in, nts_bf* bf_out, uint64_t* keys, const uint32_t* d_tile_ids = nullptr, uint64_t n_tile_ids = 0,
+                const uint2* d_tile_span = nullptr)
 {
   const RunTable& rt = T.rt;
   if (rt.n_valid == 0) return NTS_OK;
@@ -1477,7 +1489,7 @@ int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const Genom
   }
   hipLaunchKernelGGL(k_hash<MODE>, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, T.d_run_pos,
                      T.d_run_vstart, T.n_runs, rt.n_valid, hp, bf_in ? bf_in->d_words : nullptr, bf_out ? bf_out->d_words : nullptr,
-                     fm, keys, d_tile_ids);
+                     fm, keys, d_tile_ids, d_tile_span);
   HIP_TRY(ctx, hipGetLastError());
   return NTS_OK;
 }
@@ -2460,8 +2472,10 @@ struct SortedOut
 // and res.count is an upper bound, and no synchronisation happens here.
 int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter,
                      const std::vector<uint64_t>* pseudo_vstart, const std::vector<uint64_t>* pseudo_nv, const std::vector<uint32_t>* tiles,
-                     uint64_t est_kmers, const char* slot_prefix, SortedOut& res, const SortedOut* sparse = nullptr)
+                     uint64_t est_kmers, const char* slot_prefix, SortedOut& res, const SortedOut* sparse = nullptr,
+                     const std::vector<uint32_t>* tile_spans = nullptr)
 {
+  // tile_spans (with tiles): 2 words per listed tile, the first and last in-tile index inside an uncovered range
   const RunTable& rt = T.rt;
 #define DN_WS(ptr, type, name, bytes)                                                               \
   type ptr = (type)ws_get(ctx, name, bytes);                                                        \
@@ -2470,6 +2484,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
   DN_WS(d_seg, unsigned long long*, "seg_count", N_SEG * sizeof(unsigned long long));
   int rc;
   uint32_t* d_tiles = nullptr;
+  const uint2* d_spans = nullptr;
   uint64_t n_tile_ids = 0;
   uint64_t n_tiles;
   const uint64_t *d_vs, *d_nv, *d_ts;
@@ -2480,14 +2495,17 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     n_tiles = tiles_of(*pseudo_nv, w, tile_start);
     if (pseudo_nv->size() > 0xFFFFFFF0ULL) return fail(ctx, NTS_ERANGE, "too many uncovered ranges");
     const bool use_tiles = tiles && tiles->size() * 2 <= (rt.n_valid + KEY_TILE - 1) / KEY_TILE;
-    void* dev[4];
+    const bool use_spans = use_tiles && tile_spans && tile_spans->size() == 2 * tiles->size();
+    void* dev[5];
     if ((rc = upload_packed(ctx, "gap_tables",
                             { { pseudo_vstart->data(), pseudo_vstart->size() * 8 },
                               { pseudo_nv->data(), pseudo_nv->size() * 8 },
                               { tile_start.data(), tile_start.size() * 8 },
-                              { use_tiles ? (const void*)tiles->data() : nullptr, use_tiles ? tiles->size() * 4 : 0 } },
+                              { use_tiles ? (const void*)tiles->data() : nullptr, use_tiles ? tiles->size() * 4 : 0 },
+                              { use_spans ? (const void*)tile_spans->data() : nullptr, use_spans ? tile_spans->size() * 4 : 0 } },
                             dev)))
       return rc;
+    if (use_spans) d_spans = (const uint2*)dev[4];
     d_vs = (const uint64_t*)dev[0];
     d_nv = (const uint64_t*)dev[1];
     d_ts = (const uint64_t*)dev[2];
@@ -2505,7 +2523,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
   }
   // keys: one slot per key tile of the genome, or only the listed tiles (uncovered ranges) in a compact buffer
   DN_WS(d_keys, uint64_t*, d_tiles ? "gap_keys" : "keys", (d_tiles ? n_tile_ids * KEY_TILE : key_buffer_elems(rt.n_valid)) * 8);
-  if ((rc = launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, T, k, filter, nullptr, d_keys, d_tiles, n_tile_ids))) return rc;
+  if ((rc = launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, T, k, filter, nullptr, d_keys, d_tiles, n_tile_ids, d_spans))) return rc;
   OutSegs segs;
   segs.d_count = d_seg;
   segs.seg_cap = std::max<uint64_t>(256, (3 * est_kmers / w + 2 * n_tiles) / N_SEG + 64);
@@ -2877,14 +2895,24 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   for (size_t i = 0; i < n_gap; ++i) ord[i] = i;
   std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return glo[a] < glo[b]; });
   std::vector<uint64_t> pv(n_gap), pn(n_gap);
-  std::vector<uint32_t> tiles;
+  std::vector<uint32_t> tiles, spans; // spans: per listed tile, first and last in-tile index inside a range
   uint64_t covered = 0;
   for (size_t i = 0; i < n_gap; ++i) {
-    pv[i] = glo[ord[i]];
-    pn[i] = ghi[ord[i]] - glo[ord[i]] + 1;
+    const uint64_t a = glo[ord[i]], b = ghi[ord[i]];
+    pv[i] = a;
+    pn[i] = b - a + 1;
     covered += pn[i];
-    for (uint64_t t = pv[i] / KEY_TILE; t <= ghi[ord[i]] / KEY_TILE; ++t)
-      if (tiles.empty() || tiles.back() != (uint32_t)t) tiles.push_back((uint32_t)t);
+    for (uint64_t t = a / KEY_TILE; t <= b / KEY_TILE; ++t) {
+      const uint32_t lo_in = (uint32_t)(std::max(a, t * KEY_TILE) - t * KEY_TILE);
+      const uint32_t hi_in = (uint32_t)(std::min(b, t * KEY_TILE + KEY_TILE - 1) - t * KEY_TILE);
+      if (tiles.empty() || tiles.back() != (uint32_t)t) {
+        tiles.push_back((uint32_t)t);
+        spans.push_back(lo_in);
+        spans.push_back(hi_in);
+      } else { // (ranges ascend: the tile's first index stays, its last grows)
+        spans[spans.size() - 1] = std::max(spans.back(), hi_in);
+      }
+    }
   }
   ctx->last_gap_kmers = covered;
   SortedOut dense;
@@ -2892,7 +2920,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   sparse_list.d_j = d_sj;
   sparse_list.d_key = d_sk;
   sparse_list.count = n_sparse;
-  int rc = run_dense_sorted(ctx, g, T, k, w, filter, &pv, &pn, &tiles, covered, "gap_", dense, &sparse_list);
+  int rc = run_dense_sorted(ctx, g, T, k, w, filter, &pv, &pn, &tiles, covered, "gap_", dense, &sparse_list, &spans);
   if (rc) return rc;
   if (dense.d_ctl) { // merged on the device: the caller reads the count after its own synchronisation
     res = dense;
@@ -3049,11 +3077,12 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
         p = share((double)rt.n_valid);
       }
     }
-    // c*p = 11 accepted candidates per window on average.  (More would not empty the list of uncovered ranges:
+    // c*p = 10.5 accepted candidates per window on average.  (More would not empty the list of uncovered ranges:
     // beyond the ~V*(cp/w)*exp(-cp) chance ones there are the stretches the other genomes do not share at all.
-    // Measured at 3 x 3 Gbp, w = 1000, p = 0.66, with k_hash_select_hi: c = 14 / 16 / 18 / 22 -> 966 / 1065 / 1024 / 832
-    // Gbases/s; with k_hash_select, whose rolling cost twice as much per k-mer, the optimum was c = 18, cp = 12.)
-    const double cp = 11.0;
+    // Measured at 3 x 3 Gbp, w = 1000, p = 0.70, with k_hash_select_hi and the uncovered ranges probed only where a window
+    // reads them: c = 12 / 13 / 14 / 15 / 16 -> 1021 / 1085 / 1124 / 1134 / 1124 Gbases/s; with k_hash_select, whose rolling
+    // cost twice as much per k-mer, and whole key tiles probed around every range, the optimum was c = 18, cp = 12.)
+    const double cp = 10.5;
     const double want = std::max(8.0, std::ceil(cp / std::max(p, 1e-4)));
     // (measured: at a quarter of the k-mers as candidates the pruned pass is still twice as fast as the dense one;
     // at 40 % single lanes run out of slots in most tiles and it is half as fast)
