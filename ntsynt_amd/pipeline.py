@@ -324,7 +324,7 @@ def _exchange_lists(backend, local, n_total):
 
 def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000, merge=10000,
         block_size=500, common=True, simplify=True, device=0, write_mx_tsv=True, mx_with_seq=True,
-        benchmark=False, log=print, ctx=None, backend=None, bf_rounding="up", bf_signature=BF_SIGNATURE, dev=False):
+        benchmark=False, log=print, ctx=None, backend=None, bf_rounding="up", bf_signature=BF_SIGNATURE, dev=False, interarrivals=False):
     """FASTA paths -> engine (outputs in .outputs and in the CWD).  Mirrors oracle.synteny_oracle.run_pipeline's
     signature so the parity tests read alike.  Under torch.distributed (WORLD_SIZE > 1, process group already
     initialised by the caller) genomes are sharded over the ranks."""
@@ -465,7 +465,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         st.mark("sketches_done")
         st.start("ntsynt_synteny")
         eng = DeviceSyntenyEngine(backend.ctx, tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size,
-                                  out_prefix, sketch_dev_round, simplify=simplify, log=log, dev=dev)
+                                  out_prefix, sketch_dev_round, simplify=simplify, log=log, dev=dev, interarrivals=interarrivals)
         first = [initial_dev[i] for i in range(len(fastas))]
     else:
         st.start("indexlr")
@@ -510,7 +510,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         sketch_fn.all_at_once = sketch_round
 
         eng = SyntenyEngine(tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size, out_prefix,
-                            backend.graph, sketch_fn, backend.walk, simplify=simplify, log=log, degree_fn=edge_degrees, dev=dev)
+                            backend.graph, sketch_fn, backend.walk, simplify=simplify, log=log, degree_fn=edge_degrees, dev=dev, interarrivals=interarrivals)
         first = initial
     try:
         eng.run(first)

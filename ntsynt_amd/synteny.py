@@ -68,7 +68,7 @@ class SyntenyEngine:
     walk_fn / scan_fn: chain walk and per-path scan (native host helpers nts_walk_chains / nts_path_scan)."""
 
     def __init__(self, files, contig_names, k, w, w_rounds, bp, collinear_merge, z, prefix, graph_fn, sketch_fn,
-                 walk_fn, simplify=True, m=90, n=0, log=None, scan_fn=None, degree_fn=None, dev=False):
+                 walk_fn, simplify=True, m=90, n=0, log=None, scan_fn=None, degree_fn=None, dev=False, interarrivals=False):
         order = sorted(range(len(files)), key=lambda i: files[i], reverse=True)
         self.input_order = order                       # engine index a -> caller's assembly index
         self.files = [files[i] for i in order]
@@ -78,6 +78,7 @@ class SyntenyEngine:
         self.bp, self.z, self.prefix, self.m = bp, z, prefix, m
         self.simplify = simplify
         self.dev = dev                                 # --dev: overlap self-check of the final blocks (S:513-514)
+        self.interarrivals = interarrivals             # --interarrivals: distances between neighbouring minimizers of the initial blocks (S:557-564)
         self.n = n or self.G
         cm = str(collinear_merge)
         if mt := re.search(r"^(\d+)w$", cm):
@@ -643,6 +644,23 @@ class SyntenyEngine:
     def _round_blocks(self):
         return self._drop_small(self._blocks_of_paths(self._paths()), 4)
 
+    def _write_interarrivals(self, vid_lists, v_pos=None):
+        """<prefix>.interarrivals.tsv (S:557-564): per block, per assembly (in the reference's assembly order), the distance between
+        every two neighbouring minimizers, one per line.  The blocks come in this engine's path order, which is not the
+        reference's (ntJoin's component order is not pinned): the file holds the same lines in a different block order."""
+        v_pos = self.v_pos if v_pos is None else v_pos
+        parts = []
+        for vids in vid_lists:
+            vids = np.asarray(vids, dtype=np.int64)
+            for a in range(self.G):
+                parts.append(np.abs(np.diff(v_pos[a][vids].astype(np.int64))))
+        flat = np.concatenate(parts) if parts else np.zeros(0, np.int64)
+        text = "".join(f"{int(x)}\n" for x in flat)
+        name = f"{self.prefix}.interarrivals.tsv"
+        self.outputs[name] = text
+        with open(name, "w", encoding="utf-8") as fout:
+            fout.write(text)
+
     def run(self, initial_lists):
         """initial_lists[i] = (h1, rec, pos) of assembly i in the caller's order."""
         if len(self.w_rounds) != len(set(self.w_rounds)):
@@ -656,6 +674,8 @@ class SyntenyEngine:
         if self.n > 1:
             self.e_alive &= self.e_w >= self.n
         blocks = self._round_blocks()
+        if self.interarrivals:
+            self._write_interarrivals([b.vids for b in blocks])
         ordered = self._sorted(blocks)
         if not ordered:
             print("Error - no paths found. Try adjusting the specified k/w parameters.")

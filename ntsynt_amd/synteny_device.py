@@ -126,9 +126,9 @@ class DeviceSyntenyEngine(SyntenyEngine):
     for the caller's assembly indices a (device-resident lists; the engine frees them)."""
 
     def __init__(self, ctx, files, contig_names, k, w, w_rounds, bp, collinear_merge, z, prefix, sketch_dev_fn, simplify=True,
-                 m=90, n=0, log=None, dev=False):
+                 m=90, n=0, log=None, dev=False, interarrivals=False):
         super().__init__(files, contig_names, k, w, w_rounds, bp, collinear_merge, z, prefix, None, None, None, simplify=simplify,
-                         m=m, n=n, log=log, scan_fn=False, dev=dev)
+                         m=m, n=n, log=log, scan_fn=False, dev=dev, interarrivals=interarrivals)
         self.ctx = ctx
         self.sketch_dev_fn = sketch_dev_fn
         self.graph = DeviceGraph(ctx, self.G, self.ref)
@@ -187,8 +187,23 @@ class DeviceSyntenyEngine(SyntenyEngine):
         self.stats["indel_cuts"] += tb["indel_cuts"]
         self.stats["small_blocks"] += tb["small"]
         n = tb["n"]
+        self._last_vids = (tb["first_vid"], tb["last_vid"])        # (--interarrivals reads the blocks' vertices back)
         return {"n": n, "rec": tb["rec"], "first_pos": tb["first_pos"], "last_pos": tb["last_pos"], "ori": tb["ori"],
                 "n_mx": tb["n_mx"].astype(np.int64), "reason": np.zeros(n, np.uint8)}
+
+    def _interarrivals_dev(self):
+        "a block is a stretch of its path: its vertices are path_verts between the positions of its first and last vertex"
+        pv = self.graph.read("path_verts").astype(np.int64)
+        v_pos = self.graph.read("v_pos").astype(np.int64)
+        where = np.full(v_pos.shape[1], -1, np.int64)
+        where[pv] = np.arange(pv.size)
+        first, last = self._last_vids
+        lists = []
+        for a, b in zip(where[first.astype(np.int64)], where[last.astype(np.int64)]):
+            lo, hi = (a, b) if a <= b else (b, a)
+            seg = pv[lo:hi + 1]
+            lists.append(seg if a <= b else seg[::-1])
+        self._write_interarrivals(lists, v_pos)
 
     @staticmethod
     def _take(tb, idx):
@@ -313,6 +328,8 @@ class DeviceSyntenyEngine(SyntenyEngine):
         if self.n > 1:
             self._filter(flag=False)
         blocks = self._blocks()
+        if self.interarrivals:
+            self._interarrivals_dev()
         ordered = self._sorted(blocks)
         if ordered["n"] == 0:
             print("Error - no paths found. Try adjusting the specified k/w parameters.")

@@ -305,7 +305,8 @@ class SyntenyOracle:
     bf: common Bloom filter (uint8 array) or None."""
 
     def __init__(self, files, genomes, k, w, w_rounds, bp, collinear_merge, z, prefix, bf=None,
-                 simplify=True, m=90, n=0, threads=1, log=None):
+                 simplify=True, m=90, n=0, threads=1, log=None, interarrivals=False):
+        self.interarrivals = interarrivals                        # --interarrivals (S:557-564, S:626-627)
         self.files = sorted(files, reverse=True)                  # S:34
         self.genomes = genomes
         self.k, self.w, self.w_rounds = k, w, list(w_rounds)
@@ -661,6 +662,14 @@ class SyntenyOracle:
         blocks = self.blocks_of_paths(paths)
         blocks = self.split_indels(blocks)
         blocks = self.drop_small(blocks, 4)
+        if self.interarrivals:                                              # S:557-564: one distance per line, blocks in path order
+            lines = []
+            for blk in blocks:
+                for ab in blk.asm.values():
+                    lines.extend(str(abs(b[1] - a[1])) for a, b in zip(ab.minimizers, ab.minimizers[1:]))
+            self.outputs[f"{self.prefix}.interarrivals.tsv"] = "".join(x + "\n" for x in lines)
+            with open(f"{self.prefix}.interarrivals.tsv", "w", encoding="utf-8") as fout:
+                fout.write(self.outputs[f"{self.prefix}.interarrivals.tsv"])
         ordered = sorted(blocks, key=SynBlock.sort_key)
         self.initial_blocks = ordered
         if not ordered:
@@ -704,7 +713,7 @@ def divergence_defaults(d):
 
 def run_pipeline(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000,
                  merge=10000, block_size=500, common=True, simplify=True, threads=1,
-                 write_mx_tsv=True, log=None, bf_rounding="up"):
+                 write_mx_tsv=True, log=None, bf_rounding="up", interarrivals=False):
     """FASTA paths -> {output file name: text}; files are written into the CWD like the reference.
     Stage order: make_common_bf (smk:55-62) -> indexlr per genome (smk:74-85) -> ntsynt_run.py
     (smk:87-103)."""
@@ -723,7 +732,7 @@ def run_pipeline(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10
             tables[tsv] = mx_tables_from_tokens(mx_records_from_arrays(genomes[p].names, mins))
         by_tsv[tsv] = genomes[p]
     eng = SyntenyOracle(list(tables), by_tsv, k, w, w_rounds, indel, merge, block_size, prefix,
-                        bf=bf, simplify=simplify, threads=threads, log=log)
+                        bf=bf, simplify=simplify, threads=threads, log=log, interarrivals=interarrivals)
     eng.load(tables)
     eng.main()
     eng.bf = bf

@@ -551,3 +551,47 @@ def test_positions_beyond_32_bits(tmp_path, shift):
         assert out[name] == text, name
     rows = ora.outputs["p.synteny_blocks.tsv"].splitlines()
     assert len(rows) > 20 and all(int(r.split("\t")[3]) >= shift for r in rows)
+
+
+def test_interarrivals_file_matches_the_oracle(tmp_path):
+    """--interarrivals (ntsynt_run.py, S:557-564, S:626-627): the distances between neighbouring minimizers of the initial
+    blocks.  Same lines as the oracle's; the order of the blocks is the engine's path order (the reference's is ntJoin's
+    component order, unpinned), so the comparison is on the sorted lines, and on per-block runs being intact."""
+    k, w, rounds, indel, merge, block = 24, 500, [100, 10], 500, 3000, 300
+    paths = synth.make_family(str(tmp_path), 3, 900_000, 3, 0.01, seed=23, micro=6)
+    cwd = os.getcwd()
+    try:
+        os.makedirs(tmp_path / "ora")
+        os.chdir(tmp_path / "ora")
+        ora = SO.run_pipeline(paths, k=k, w=w, w_rounds=rounds, indel=indel, merge=merge, block_size=block, prefix="p",
+                              interarrivals=True)
+        os.makedirs(tmp_path / "eng")
+        os.chdir(tmp_path / "eng")
+        genomes = [O.read_fasta(p) for p in paths]
+        tsvs = [f"{os.path.basename(p)}.k{k}.w{w}.tsv" for p in paths]
+        initial = [oracle_flat(O.minimize(g, k, w, ora.bf)) for g in genomes]
+
+        def sketch_fn(i, masks, new_w):
+            g = genomes[i]
+            seqs = []
+            for r in range(len(g.names)):
+                buf = bytearray(g.record(r))
+                for mr, s, e in masks:
+                    if mr == r:
+                        s, e = max(0, s), min(len(buf), e)
+                        if e > s:
+                            buf[s:e] = b"N" * (e - s)
+                seqs.append(bytes(buf))
+            return oracle_flat(O.minimize(O.Genome(g.names, seqs), k, new_w, ora.bf))
+
+        eng = SyntenyEngine(tsvs, [g.names for g in genomes], k, w, rounds, indel, merge, block, "p", build_graph_numpy, sketch_fn,
+                            walk_paths, degree_fn=edge_degrees, interarrivals=True)
+        out = eng.run(initial)
+        on_disk = open("p.interarrivals.tsv").read()
+    finally:
+        os.chdir(cwd)
+    want = ora.outputs["p.interarrivals.tsv"]
+    assert out["p.interarrivals.tsv"] == on_disk
+    assert len(want.splitlines()) > 1000
+    assert sorted(out["p.interarrivals.tsv"].splitlines()) == sorted(want.splitlines())
+    assert out["p.synteny_blocks.tsv"] == ora.outputs["p.synteny_blocks.tsv"]

@@ -275,3 +275,26 @@ def test_device_engine_on_positions_beyond_32_bits(ctx, tmp_path, shift):
     for name, text in ora.outputs.items():
         assert out[name] == text, name
     assert all(int(r.split("\t")[3]) >= shift for r in ora.outputs["p.synteny_blocks.tsv"].splitlines())
+
+
+def test_interarrivals_from_the_device_engine(tmp_path):
+    "--interarrivals through the product pipeline (device engine): the oracle's lines (block order aside)"
+    from ntsynt_amd import pipeline
+    paths = synth.make_family(str(tmp_path), 3, 1_500_000, 5, 0.01, seed=31, micro=8)
+    kw = dict(k=24, w=400, w_rounds=[100, 20], indel=500, merge="10w", block_size=300)
+    cwd = os.getcwd()
+    try:
+        os.makedirs(tmp_path / "hip")
+        os.makedirs(tmp_path / "ora")
+        os.chdir(tmp_path / "hip")
+        eng = pipeline.run(paths, prefix="p", log=lambda *a: None, interarrivals=True, **kw)
+        got = open("p.interarrivals.tsv").read()
+        os.chdir(tmp_path / "ora")
+        ora = SO.run_pipeline(paths, prefix="p", interarrivals=True, **kw)
+    finally:
+        os.chdir(cwd)
+    assert type(eng).__name__ == "DeviceSyntenyEngine"
+    want = ora.outputs["p.interarrivals.tsv"]
+    assert len(want.splitlines()) > 1000
+    assert sorted(got.splitlines()) == sorted(want.splitlines())
+    assert eng.outputs["p.synteny_blocks.tsv"] == ora.outputs["p.synteny_blocks.tsv"]
