@@ -204,6 +204,12 @@ int nts_sketch(nts_ctx* ctx,
                const nts_interval* mask,
                uint64_t n_mask,
                nts_mx** out);
+
+/* The same with a filter-out Bloom filter as well (`indexlr -r <bf>`, the reference's experimental repeat filter: rule indexlr,
+   bin/ntsynt_run_pipeline.smk:74-85, and ntsynt_synteny.py:172-180): a k-mer present in `filter_out` is rejected like one
+   absent from `filter`; either may be NULL.  With a filter-out filter the call takes the every-k-mer-probed kernels. */
+int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const nts_bf* filter, const nts_bf* filter_out,
+                  const nts_interval* mask, uint64_t n_mask, nts_mx** out);
 /* Sketch policy.  mode 0 = auto (pruned when w >= 200 and c = 12 / accepted share stays below w/4, below 0.15 w for w < 512),
  * 1 = dense (probe the filter for every k-mer), 2 = pruned: only k-mers whose hash is <= (c / w) * 2^64 are probed;
  * windows holding no accepted candidate are re-evaluated densely, so the result is identical

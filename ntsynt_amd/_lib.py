@@ -103,6 +103,8 @@ SYMBOLS = [
     ("nts_mx_export_async", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("nts_sketch", ctypes.c_int, [c_vp, c_vp, u32, u32, c_vp, ctypes.POINTER(Interval), u64,
                                   ctypes.POINTER(c_vp)]),
+    ("nts_sketch_ex", ctypes.c_int, [c_vp, c_vp, u32, u32, c_vp, c_vp, ctypes.POINTER(Interval), u64,
+                                     ctypes.POINTER(c_vp)]),
     ("nts_sketch_mode", ctypes.c_int, [c_vp, ctypes.c_int, u32]),
     ("nts_sketch_summary", ctypes.c_int, [c_vp, ctypes.c_int, c_u32p]),
     ("nts_sketch_select", ctypes.c_int, [c_vp, ctypes.c_int]),

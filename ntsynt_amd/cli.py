@@ -50,6 +50,7 @@ def build_parser():
     p.add_argument("--benchmark", help="write the wall-clock time of every stage to <prefix>.stage_times.tsv", action="store_true")
     p.add_argument("-f", "--force", help="accepted for compatibility (every run recomputes everything)", action="store_true")
     p.add_argument("--dev", help="developer mode: verbose log, overlap self-check of the final blocks", action="store_true")
+    p.add_argument("--repeat", help=argparse.SUPPRESS, action="store_true")   # the Snakefile's experimental config "repeat": <prefix>.repeat.bf + indexlr -r
     p.add_argument("--interarrivals", help=argparse.SUPPRESS, action="store_true")   # ntsynt_run.py --interarrivals: <prefix>.interarrivals.tsv
     p.add_argument("--device", help="GPU index [0]", type=int, default=0)
     # switches for the two btllib details this implementation recalls rather than reads
@@ -148,7 +149,7 @@ def main(argv=None):
     pipeline.run(fastas, k=args.k, w=args.w, fpr=args.fpr, prefix=args.prefix, w_rounds=args.w_rounds,
                  indel=args.indel, merge=args.merge, block_size=args.block_size, common=not args.no_common,
                  simplify=not args.no_simplify_graph, device=device, benchmark=args.benchmark,
-                 dev=args.dev, interarrivals=args.interarrivals, bf_rounding=args.bf_rounding, bf_signature=args.bf_signature or pipeline.BF_SIGNATURE,
+                 dev=args.dev, interarrivals=args.interarrivals, repeat=args.repeat, bf_rounding=args.bf_rounding, bf_signature=args.bf_signature or pipeline.BF_SIGNATURE,
                  log=print if (args.dev and int(os.environ.get("RANK", "0")) == 0) else quiet)
     if world > 1:
         dist.barrier()

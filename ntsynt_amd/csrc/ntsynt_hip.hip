@@ -104,6 +104,7 @@ struct nts_ctx
     uint8_t* stage[2] = { nullptr, nullptr };
   };
   std::vector<IoLane> io_up, io_down;
+  const nts_bf* cur_rep = nullptr; // filter-out filter of the running nts_sketch_ex call (indexlr -r), or null
   int select_impl = 0;  // candidate selection of the pruned sketch: 0 auto, 1 full-width kernel, 2 upper-halves kernel also for assemblies in pieces
   int summary_mode = 0; // 0 auto, 1 never (tests)
   uint32_t last_summary = 0;
@@ -397,11 +398,13 @@ __host__ __device__ __forceinline__ uint64_t key_phys(uint64_t j)
 
 template <int MODE>
 __device__ __forceinline__ void hash_emit(uint64_t h0, bool live, uint64_t phys, const uint32_t* __restrict__ bf_in,
-                                          uint32_t* __restrict__ bf_out, const FastMod& fm, uint64_t* __restrict__ keys)
+                                          uint32_t* __restrict__ bf_out, const FastMod& fm, uint64_t* __restrict__ keys,
+                                          const uint32_t* __restrict__ bf_rep = nullptr, const FastMod* fm_rep = nullptr)
 {
   if (MODE == MODE_KEYS) {
     uint64_t key = h0;
     if (bf_in != nullptr && !bf_test(bf_in, fm(h0))) key = KEY_MAX;
+    if (bf_rep != nullptr && key != KEY_MAX && bf_test(bf_rep, (*fm_rep)(h0))) key = KEY_MAX; // filter-out (indexlr -r)
     if (live) keys[phys] = key;
   } else if (MODE == MODE_INSERT) {
     if (live) bf_set(bf_out, fm(h0));
@@ -430,8 +433,11 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
                                                        FastMod fm,
                                                        uint64_t* __restrict__ keys,
                                                        const uint32_t* __restrict__ tile_ids,
-                                                       const uint2* __restrict__ tile_span)
+                                                       const uint2* __restrict__ tile_span,
+                                                       const uint32_t* __restrict__ bf_rep,
+                                                       FastMod fm_rep)
 {
+  // bf_rep (MODE_KEYS): filter-out Bloom filter, indexlr -r -- a k-mer present in it is rejected like one absent from bf_in
   // tile_span (with tile_ids): per listed tile the first and last in-tile index whose key anybody reads (the uncovered ranges
   // inside it); only those are probed, the rest are written as rejected -- a listed tile holds one or two ranges of ~w..3w
   // k-mers, and probing all 8192 was nine tenths of this pass
@@ -511,6 +517,19 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
           for (int u = 0; u < 8; ++u)
             if (bit[u] == 32u || !((wd[u] >> bit[u]) & 1u)) h[u] = KEY_MAX;
         }
+        if (bf_rep != nullptr) {
+          uint32_t wd[8], bit[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const uint64_t idx = fm_rep(h[u]);
+            const bool wanted = h[u] != KEY_MAX; // (a k-mer rejected already reads word 0)
+            wd[u] = bf_rep[wanted ? idx >> 5 : 0ULL];
+            bit[u] = wanted ? (uint32_t)idx & 31u : 32u;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (bit[u] != 32u && ((wd[u] >> bit[u]) & 1u)) h[u] = KEY_MAX;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (b0 + u < n_mine) keys[out_base + (uint64_t)(b0 + u) * 256u] = h[u];
@@ -550,7 +569,7 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
       if (MODE == MODE_KEYS && (e < span.x || e > span.y))
         keys[KB + (key_phys(j) - J0)] = KEY_MAX;
       else
-        hash_emit<MODE>(f + r, true, KB + (key_phys(j) - J0), bf_in, bf_out, fm, keys);
+        hash_emit<MODE>(f + r, true, KB + (key_phys(j) - J0), bf_in, bf_out, fm, keys, bf_rep, &fm_rep);
       ++j;
       if (j >= seg_end) break;
       const uint32_t cout = code[p], cin = code[p + k];
@@ -1489,7 +1508,8 @@ int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const Genom
   }
   hipLaunchKernelGGL(k_hash<MODE>, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, T.d_run_pos,
                      T.d_run_vstart, T.n_runs, rt.n_valid, hp, bf_in ? bf_in->d_words : nullptr, bf_out ? bf_out->d_words : nullptr,
-                     fm, keys, d_tile_ids, d_tile_span);
+                     fm, keys, d_tile_ids, d_tile_span, (MODE == MODE_KEYS && ctx->cur_rep) ? ctx->cur_rep->d_words : nullptr,
+                     make_fastmod((MODE == MODE_KEYS && ctx->cur_rep) ? ctx->cur_rep->bytes * 8 : 64));
   HIP_TRY(ctx, hipGetLastError());
   return NTS_OK;
 }
@@ -3007,7 +3027,19 @@ extern "C" int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* un
 extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const nts_bf* filter, const nts_interval* mask,
                           uint64_t n_mask, nts_mx** out)
 {
+  return nts_sketch_ex(ctx, g, k, w, filter, nullptr, mask, n_mask, out);
+}
+
+extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const nts_bf* filter, const nts_bf* filter_out,
+                             const nts_interval* mask, uint64_t n_mask, nts_mx** out)
+{
   if (!ctx || !g || !out || k == 0 || w == 0 || (n_mask && !mask)) return fail(ctx, NTS_EINVAL, "nts_sketch: bad arguments");
+  ctx->cur_rep = filter_out; // (read by the key kernel's launch; cleared on every way out)
+  struct RepGuard
+  {
+    nts_ctx* c;
+    ~RepGuard() { c->cur_rep = nullptr; }
+  } rep_guard{ ctx };
   if (w > WIN_MAX_W) return fail(ctx, NTS_ERANGE, "nts_sketch: w exceeds the LDS-resident window limit (12000)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   GenomeTables scratch;
@@ -3053,6 +3085,8 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   // only the accepted ones, so c may grow until a quarter of the k-mers are candidates (p down to 48/w); below that
   // the dense kernels take over.
   bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= 200);
+  // a filter-out filter (indexlr -r: experimental in the reference) is served by the every-k-mer-probed kernels only
+  if (filter_out) pruned = false;
   uint32_t prune_c = ctx->prune_c;
   double p = 1.0; // accepted share of the candidates (1 when unknown: sizes the candidate arrays)
   if (pruned && prune_c == 0) {
@@ -3100,7 +3134,7 @@ extern "C" int nts_sketch(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_
   ctx->cur_tile_any = nullptr;
   ctx->last_summary = 0;
   bool accept_all = false;
-  if (!pruned && filter && filter->owned && ctx->summary_mode == 0) {
+  if (!pruned && filter && filter->owned && ctx->summary_mode == 0 && !filter_out) {
     uint64_t pc = 0;
     SK_TRY(nts_bf_popcount(ctx, filter, &pc));
     const double bits = (double)filter->bytes * 8.0;

@@ -421,9 +421,10 @@ class Minimizers:
             pass
 
 
-def sketch(ctx, genome, k, w, bf=None, masks=None):
-    """`indexlr -k k -w w --long --pos [-s bf]` on the resident genome.  masks: iterable of
-    (record index, start, end) hard-mask intervals applied on the fly (refinement rounds)."""
+def sketch(ctx, genome, k, w, bf=None, masks=None, repeat=None):
+    """`indexlr -k k -w w --long --pos [-s bf] [-r repeat]` on the resident genome.  masks: iterable of
+    (record index, start, end) hard-mask intervals applied on the fly (refinement rounds).  repeat: filter-out
+    Bloom filter (the reference's experimental repeat filter; served by the every-k-mer-probed kernels)."""
     n_mask, arr = 0, None
     if masks is not None and len(masks):
         n_mask = len(masks)
@@ -435,8 +436,12 @@ def sketch(ctx, genome, k, w, bf=None, masks=None):
             for i, (r, s, e) in enumerate(masks):
                 arr[i].rec, arr[i].start, arr[i].end = int(r), int(s), int(e)
     h = c_vp()
-    ctx.check(ctx.lib.nts_sketch(ctx.h, genome.h, int(k), int(w), bf.h if bf is not None else None,
-                                 arr, n_mask, ctypes.byref(h)), "nts_sketch")
+    if repeat is not None:
+        ctx.check(ctx.lib.nts_sketch_ex(ctx.h, genome.h, int(k), int(w), bf.h if bf is not None else None, repeat.h,
+                                        arr, n_mask, ctypes.byref(h)), "nts_sketch_ex")
+    else:
+        ctx.check(ctx.lib.nts_sketch(ctx.h, genome.h, int(k), int(w), bf.h if bf is not None else None,
+                                     arr, n_mask, ctypes.byref(h)), "nts_sketch")
     return Minimizers(ctx, h)
 
 

@@ -354,16 +354,21 @@ typedef struct
  *   - emit when pos > last emitted pos and min_hash != UINT64_MAX
  * Output: out_h1[] (the printed hash, hashes()[1]), out_pos[]; returns the count.
  */
+/*   - with a filter-out Bloom filter as well (indexlr -r, the experimental repeat filter: ntsynt_run_pipeline.smk:83),
+ *     a k-mer present in it is rejected too; with only a filter-out filter, presence alone rejects
+ *     (btllib Indexlr::filter_hashed_kmer, recalled: unpinned) */
 uint64_t
-nts_o_minimize(const char* seq,
-               uint64_t len,
-               unsigned k,
-               unsigned w,
-               const uint8_t* bf,
-               uint64_t bf_bytes,
-               uint64_t* out_h1,
-               uint64_t* out_pos,
-               uint64_t cap)
+nts_o_minimize2(const char* seq,
+                uint64_t len,
+                unsigned k,
+                unsigned w,
+                const uint8_t* bf,
+                uint64_t bf_bytes,
+                const uint8_t* bf_out,
+                uint64_t bf_out_bytes,
+                uint64_t* out_h1,
+                uint64_t* out_pos,
+                uint64_t cap)
 {
   if ((uint64_t)k > len || (uint64_t)w > len - k + 1) return 0;
   const uint64_t ring = (uint64_t)w + 1;
@@ -382,6 +387,7 @@ nts_o_minimize(const char* seq,
     hk->out_hash = extend_h1(h0, k);
     hk->pos = R.pos;
     if (bf && !bf_get(bf, bits, h0)) hk->min_hash = UINT64_MAX;
+    if (bf_out && bf_get(bf_out, bf_out_bytes * 8, h0)) hk->min_hash = UINT64_MAX;
     if (idx + 1 >= w) {
       const uint64_t left = idx + 1 - w, right = idx + 1;
       const hashed_kmer* min_left = &buf[left % ring];
@@ -409,10 +415,61 @@ nts_o_minimize(const char* seq,
   return n_out;
 }
 
+uint64_t
+nts_o_minimize(const char* seq,
+               uint64_t len,
+               unsigned k,
+               unsigned w,
+               const uint8_t* bf,
+               uint64_t bf_bytes,
+               uint64_t* out_h1,
+               uint64_t* out_pos,
+               uint64_t cap)
+{
+  return nts_o_minimize2(seq, len, k, w, bf, bf_bytes, NULL, 0, out_h1, out_pos, cap);
+}
+
 /*
  * All records of a genome, `threads` records in flight (indexlr -t N).  Outputs are written
  * per record into [rec_cap_off[r], rec_cap_off[r+1]) of out_h1/out_pos; counts into rec_cnt[r].
  */
+void
+nts_o_minimize_records2(const char* seq,
+                        const uint64_t* rec_off,
+                        const uint64_t* rec_len,
+                        uint32_t n_rec,
+                        unsigned k,
+                        unsigned w,
+                        const uint8_t* bf,
+                        uint64_t bf_bytes,
+                        const uint8_t* bf_out,
+                        uint64_t bf_out_bytes,
+                        uint64_t* out_h1,
+                       uint64_t* out_pos,
+                       const uint64_t* rec_cap_off,
+                       uint64_t* rec_cnt,
+                       int threads)
+{
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (uint32_t r = 0; r < n_rec; ++r) {
+    const uint64_t cap = rec_cap_off[r + 1] - rec_cap_off[r];
+    rec_cnt[r] = nts_o_minimize2(seq + rec_off[r],
+                                 rec_len[r],
+                                 k,
+                                 w,
+                                 bf,
+                                 bf_bytes,
+                                 bf_out,
+                                 bf_out_bytes,
+                                 out_h1 + rec_cap_off[r],
+                                 out_pos + rec_cap_off[r],
+                                 cap);
+  }
+}
+
 void
 nts_o_minimize_records(const char* seq,
                        const uint64_t* rec_off,
@@ -428,20 +485,5 @@ nts_o_minimize_records(const char* seq,
                        uint64_t* rec_cnt,
                        int threads)
 {
-#ifdef _OPENMP
-  if (threads > 0) omp_set_num_threads(threads);
-#pragma omp parallel for schedule(dynamic, 1)
-#endif
-  for (uint32_t r = 0; r < n_rec; ++r) {
-    const uint64_t cap = rec_cap_off[r + 1] - rec_cap_off[r];
-    rec_cnt[r] = nts_o_minimize(seq + rec_off[r],
-                                rec_len[r],
-                                k,
-                                w,
-                                bf,
-                                bf_bytes,
-                                out_h1 + rec_cap_off[r],
-                                out_pos + rec_cap_off[r],
-                                cap);
-  }
+  nts_o_minimize_records2(seq, rec_off, rec_len, n_rec, k, w, bf, bf_bytes, NULL, 0, out_h1, out_pos, rec_cap_off, rec_cnt, threads);
 }

@@ -56,6 +56,13 @@ def _load(native=False):
                                            ctypes.c_uint, ctypes.c_uint, _u8p, _u64,
                                            _u64p, _u64p, _u64p, _u64p, ctypes.c_int]
     lib.nts_o_minimize_records.restype = None
+    lib.nts_o_minimize2.argtypes = [ctypes.c_char_p, _u64, ctypes.c_uint, ctypes.c_uint, _u8p, _u64, _u8p, _u64,
+                                    _u64p, _u64p, _u64]
+    lib.nts_o_minimize2.restype = _u64
+    lib.nts_o_minimize_records2.argtypes = [ctypes.c_char_p, _u64p, _u64p, ctypes.c_uint32,
+                                            ctypes.c_uint, ctypes.c_uint, _u8p, _u64, _u8p, _u64,
+                                            _u64p, _u64p, _u64p, _u64p, ctypes.c_int]
+    lib.nts_o_minimize_records2.restype = None
     return lib
 
 
@@ -200,8 +207,8 @@ def common_bf(genomes_by_path, k, fpr, threads=1, bf_bytes=None, native=False, r
     return bf
 
 
-def minimize(genome, k, w, bf=None, threads=1, native=False):
-    """indexlr over every record: list (per record) of (h1 uint64[], pos uint64[])."""
+def minimize(genome, k, w, bf=None, threads=1, native=False, repeat=None):
+    """indexlr over every record: list (per record) of (h1 uint64[], pos uint64[]).  bf: filter-in (-s); repeat: filter-out (-r)."""
     n_rec = len(genome.names)
     caps = np.zeros(n_rec + 1, dtype=np.uint64)
     # an upper bound on minimizers per record: every valid k-mer could in principle be one
@@ -212,9 +219,9 @@ def minimize(genome, k, w, bf=None, threads=1, native=False):
     out_h = np.empty(max(tot, 1), dtype=np.uint64)
     out_p = np.empty(max(tot, 1), dtype=np.uint64)
     cnt = np.zeros(max(n_rec, 1), dtype=np.uint64)
-    lib(native).nts_o_minimize_records(genome.blob, _p64(genome.rec_off), _p64(genome.rec_len), n_rec,
-                                       k, w, _p8(bf), 0 if bf is None else bf.size,
-                                       _p64(out_h), _p64(out_p), _p64(caps), _p64(cnt), threads)
+    lib(native).nts_o_minimize_records2(genome.blob, _p64(genome.rec_off), _p64(genome.rec_len), n_rec,
+                                        k, w, _p8(bf), 0 if bf is None else bf.size, _p8(repeat), 0 if repeat is None else repeat.size,
+                                        _p64(out_h), _p64(out_p), _p64(caps), _p64(cnt), threads)
     res = []
     for r in range(n_rec):
         c, o = int(cnt[r]), int(caps[r])
@@ -222,8 +229,8 @@ def minimize(genome, k, w, bf=None, threads=1, native=False):
             hh = np.empty(c, dtype=np.uint64)
             pp = np.empty(c, dtype=np.uint64)
             rec = genome.record(r)
-            lib(native).nts_o_minimize(rec, len(rec), k, w, _p8(bf), 0 if bf is None else bf.size,
-                                       _p64(hh), _p64(pp), c)
+            lib(native).nts_o_minimize2(rec, len(rec), k, w, _p8(bf), 0 if bf is None else bf.size,
+                                        _p8(repeat), 0 if repeat is None else repeat.size, _p64(hh), _p64(pp), c)
             res.append((hh, pp))
         else:
             res.append((out_h[o:o + c].copy(), out_p[o:o + c].copy()))

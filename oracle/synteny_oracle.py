@@ -713,7 +713,7 @@ def divergence_defaults(d):
 
 def run_pipeline(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000,
                  merge=10000, block_size=500, common=True, simplify=True, threads=1,
-                 write_mx_tsv=True, log=None, bf_rounding="up", interarrivals=False):
+                 write_mx_tsv=True, log=None, bf_rounding="up", interarrivals=False, repeat=False):
     """FASTA paths -> {output file name: text}; files are written into the CWD like the reference.
     Stage order: make_common_bf (smk:55-62) -> indexlr per genome (smk:74-85) -> ntsynt_run.py
     (smk:87-103)."""
@@ -721,10 +721,15 @@ def run_pipeline(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10
     prefix = prefix or f"ntSynt.k{k}.w{w}"
     genomes = {p: O.read_fasta(p) for p in fastas}
     bf = O.common_bf(genomes, k, fpr, threads, rounding=bf_rounding) if common else None
+    rep = None
+    if repeat:      # smk:65-85 (experimental): repeat filter over all genomes, sized from the first; used by the whole-genome indexlr only
+        import math
+        size_bits = math.ceil((-1 * genomes[fastas[0]].total_bp) / (math.log(1 - fpr)))     # ntsynt_make_repeat_bfs.py:25-34
+        rep = O.repeat_bf([genomes[p] for p in fastas], k, (int(size_bits / 8) + 7) // 8 * 8)
     tables, by_tsv = {}, {}
     for p in fastas:
         tsv = f"{os.path.basename(p)}.k{k}.w{w}.tsv"
-        mins = O.minimize(genomes[p], k, w, bf, threads)
+        mins = O.minimize(genomes[p], k, w, bf, threads, repeat=rep)
         if write_mx_tsv:
             O.write_indexlr_tsv(tsv, genomes[p], mins, k)
             tables[tsv] = read_minimizers_tsv(tsv)

@@ -73,6 +73,8 @@ def main(argv=None):
             mode, c = [("auto", 0), ("pruned", int(rng.choice([1, 4, 12, 40, 300]))), ("dense", 0)][int(rng.integers(0, 3))]
             use_bf = bool(rng.integers(0, 2))
             ctx.sketch_mode(mode, c)
+            ctx.sketch_select(str(rng.choice(["auto", "hi", "hi", "full"])))      # both candidate-selection kernels
+            os.environ["NTS_HI_TPW"] = str(int(rng.choice([1, 2, 5])))            # one and several tiles per wave
             exp = [oracle_flat(O.minimize(o, k, w, want if use_bf else None)) for o in (og, og2)]
             got = [sketch(ctx, d, k, w, bf if use_bf else None).to_numpy() for d in (dg, dg2)]
             bmx = sketch(ctx, batch, k, w, bf if use_bf else None)
@@ -92,6 +94,7 @@ def main(argv=None):
                                                       n_frac=n_frac, seed=args.seed, case=n_cases))
                         sys.exit(1)
         ctx.sketch_mode("auto", 0)
+        ctx.sketch_select("auto")
         batch.free()
         bf.free()
         dg.free()

@@ -481,3 +481,64 @@ def test_select_kernels_agree(ctx, monkeypatch, k, w, c, tpw):
         dbf.free()
         for d in dg:
             d.free()
+
+
+@pytest.mark.parametrize("k,w,with_common", [(24, 1000, True), (24, 100, True), (20, 33, False), (32, 400, True)])
+def test_sketch_with_filter_out_repeat_filter(ctx, k, w, with_common):
+    """indexlr -r: k-mers present in the repeat filter (k-mers seen twice within a genome: nts_bf_insert_repeats, checked
+    against the oracle's bits here as well) are rejected next to the ones absent from the common filter; with and without
+    the common filter, with hard masks, on records with N runs and a satellite array that fills the repeat filter."""
+    from ntsynt_amd.device import BloomFilter, sketch
+    rng = np.random.default_rng(k * 1000 + w)
+    names, seqs = _family(4000 + w, lengths=[120000, 900, 0, 50000, 2500, 40000], n_frac=0.002)
+    seqs = list(seqs)
+    big = bytearray(seqs[0])
+    unit = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=700))
+    big[30000:30000 + 7000] = unit * 10                          # a tandem repeat: its k-mers enter the repeat filter
+    big[90000:97000] = big[10000:17000]                          # a dispersed duplicate
+    seqs[0] = bytes(big)
+    other = []
+    for s in seqs:
+        a = np.frombuffer(s, dtype=np.uint8).copy()
+        hit = (rng.random(a.size) < 0.01) & (a != ord("N"))
+        a[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+        other.append(a.tobytes())
+    og = [to_oracle(names, seqs), to_oracle(names, other)]
+    dg = [to_device(ctx, names, seqs), to_device(ctx, names, other)]
+    nbytes = O.bf_ctor_bytes(O.bf_approx_bytes(og[0].total_bp, 0.025))
+    obf = O.bf_build(og[1], k, nbytes, prev=O.bf_build(og[0], k, nbytes))
+    dbf = BloomFilter(ctx, nbytes, k)
+    dbf.from_numpy(obf)
+    rep_bytes = 40000
+    orep = O.repeat_bf(og, k, rep_bytes)
+    drep = BloomFilter(ctx, rep_bytes, k)
+    own = BloomFilter(ctx, rep_bytes, k)
+    for d in dg:
+        own.clear()
+        drep.insert_repeats_of(d, own)
+    assert np.array_equal(drep.to_numpy(), orep) and O.bf_popcount(orep) > 5000
+    try:
+        for o, d in zip(og, dg):
+            exp = oracle_flat(O.minimize(o, k, w, obf if with_common else None, repeat=orep))
+            plain = oracle_flat(O.minimize(o, k, w, obf if with_common else None))
+            assert exp[0].size > 50 and not (exp[1].size == plain[1].size and np.array_equal(exp[1], plain[1]))   # the filter bites
+            got = sketch(ctx, d, k, w, dbf if with_common else None, repeat=drep).to_numpy()
+            for a, b in zip(got, exp):
+                assert np.array_equal(a, b.astype(a.dtype))
+        masks = [(0, 5000, 60000), (3, 100, 30000)]
+        masked = []
+        for i, s in enumerate(seqs):
+            b = bytearray(s)
+            for r, st, en in masks:
+                if r == i:
+                    b[st:min(en, len(b))] = b"N" * (min(en, len(b)) - st)
+            masked.append(bytes(b))
+        exp = oracle_flat(O.minimize(to_oracle(names, masked), k, w, obf if with_common else None, repeat=orep))
+        got = sketch(ctx, dg[0], k, w, dbf if with_common else None, masks, repeat=drep).to_numpy()
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b.astype(a.dtype))
+    finally:
+        for x in (dbf, drep, own):
+            x.free()
+        for d in dg:
+            d.free()

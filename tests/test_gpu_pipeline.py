@@ -110,3 +110,52 @@ def test_cli_runs_like_the_reference_tests(tmp_path):
     assert a == ora.outputs["cli.synteny_blocks.tsv"]
     for p in paths:
         assert os.path.exists(tmp_path / f"{os.path.basename(p)}.fai")
+
+
+def test_pipeline_with_the_experimental_repeat_filter(tmp_path):
+    """config "repeat" of the reference's Snakefile (rules make_repeat_bf, indexlr -r; ntsynt_run.py gets --repeat without --filter,
+    so the refinement rounds do not use it): <prefix>.repeat.bf holds the oracle's bits, minimizer TSVs and synteny blocks are
+    the oracle pipeline's."""
+    from ntsynt_amd import pipeline, synth
+    from oracle import nts_oracle as O
+    from oracle import synteny_oracle as SO
+    paths = synth.make_family(str(tmp_path), 3, 1_200_000, 4, 0.01, seed=44, micro=10)
+    # give every genome something repeated: a copy of an earlier stretch further down the first record
+    import re
+    for p in paths:
+        txt = open(p).read()
+        recs = re.split(r"(?m)^>", txt)[1:]
+        head, *lines = recs[0].split("\n")
+        seq = "".join(lines)
+        seq = seq[:200000] + seq[20000:60000] + seq[240000:]
+        recs[0] = head + "\n" + "\n".join(seq[i:i + 80] for i in range(0, len(seq), 80)) + "\n"
+        open(p, "w").write("".join(">" + r for r in recs))
+    kw = dict(k=24, w=300, w_rounds=[100, 20], indel=400, merge="10w", block_size=300)
+    cwd = os.getcwd()
+    try:
+        os.makedirs(tmp_path / "hip")
+        os.makedirs(tmp_path / "ora")
+        os.chdir(tmp_path / "hip")
+        eng = pipeline.run(paths, prefix="p", log=lambda *a: None, repeat=True, **kw)
+        os.chdir(tmp_path / "ora")
+        ora = SO.run_pipeline(paths, prefix="p", repeat=True, **kw)
+        os.makedirs(tmp_path / "plain")
+        os.chdir(tmp_path / "plain")
+        SO.run_pipeline(paths, prefix="p", **kw)
+    finally:
+        os.chdir(cwd)
+    for name in ("p.synteny_blocks.tsv", "p.pre-collinear-merge.synteny_blocks.tsv"):
+        assert eng.outputs[name] == ora.outputs[name], name
+    differs = False
+    for p in paths:
+        tsv = f"{os.path.basename(p)}.k24.w300.tsv"
+        assert open(tmp_path / "hip" / tsv).read() == open(tmp_path / "ora" / tsv).read()
+        differs |= open(tmp_path / "ora" / tsv).read() != open(tmp_path / "plain" / tsv).read()
+    assert differs                                       # the filter changes the sketches
+    assert ora.outputs["p.synteny_blocks.tsv"] != "" and os.path.getsize(tmp_path / "hip" / "p.repeat.bf") > 1000
+    genomes = [O.read_fasta(p) for p in paths]
+    import math
+    nb = (int(math.ceil(-genomes[0].total_bp / math.log(1 - 0.025)) / 8) + 7) // 8 * 8
+    want = O.repeat_bf(genomes, 24, nb)
+    raw = open(tmp_path / "hip" / "p.repeat.bf", "rb").read()
+    assert raw[-nb:] == want.tobytes() and O.bf_popcount(want) > 10000
