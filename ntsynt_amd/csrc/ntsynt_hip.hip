@@ -2716,15 +2716,15 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   uint64_t *d_sj = nullptr, *d_sk = nullptr;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const uint64_t m_max = cseg_cap * N_SEG;
-    const uint64_t n_blk = (m_max + SPARSE_THREADS - 1) / SPARSE_THREADS;
+    const uint64_t n_blk = (m_max + SPARSE_BLOCK - 1) / SPARSE_BLOCK;
     // (upper-halves select kernel: one slot of 64 * hi_per entries per tile in front of the segments)
     const uint64_t slot_words = sel_hi ? n_kt * 64ull * hi_per : 0ull;
     d_sj = (uint64_t*)ws_get(ctx, "sel_seg_j", (slot_words + m_max) * 8);
     d_sk = (uint64_t*)ws_get(ctx, "sel_seg_key", (slot_words + m_max) * 8);
     PR_WS(d_pj, uint64_t*, "cand_j", m_max * 8);
     PR_WS(d_pk, uint64_t*, "cand_key", m_max * 8);
-    PR_WS(d_stj, uint64_t*, "stage_j", n_blk * SPARSE_THREADS * 8);
-    PR_WS(d_stk, uint64_t*, "stage_k", n_blk * SPARSE_THREADS * 8);
+    PR_WS(d_stj, uint64_t*, "stage_j", n_blk * SPARSE_BLOCK * 8);
+    PR_WS(d_stk, uint64_t*, "stage_k", n_blk * SPARSE_BLOCK * 8);
     PR_WS(d_bcnt, uint64_t*, "blk_cnt", n_blk * 8);
     PR_WS(d_bscan, uint64_t*, "blk_scan", n_blk * 8);
     if (!d_sj || !d_sk) return NTS_ENOMEM;
