@@ -308,6 +308,35 @@ def load_genomes(backend, paths, max_threads=8):
         return {p: backend.upload_host(f.result()) for p, f in zip(paths, pending)}
 
 
+class _Arriving(dict):
+    """{path: genome} whose values arrive from a loader thread: a lookup waits for that file.  On one GPU the common
+    filter is built while the later files are still on their way up (the inserts run on the compute stream, the uploads on
+    the loader's context: copy engines and host threads) -- the filter file, which is what the run waits for in the end,
+    gets started that much earlier."""
+
+    def __init__(self, paths, load, on_arrival):
+        super().__init__()
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=1)
+        self._order = list(paths)
+
+        def task(p):
+            g = load(p)
+            on_arrival(p, g)
+            return g
+        self._fut = {p: self._pool.submit(task, p) for p in paths}
+
+    def __getitem__(self, p):
+        if not dict.__contains__(self, p):
+            dict.__setitem__(self, p, self._fut[p].result())
+        return dict.__getitem__(self, p)
+
+    def wait_all(self):
+        for p in self._order:
+            self[p]
+        self._pool.shutdown(wait=True)
+
+
 def _exchange_lists(backend, local, n_total):
     """Exchange 2: every rank contributes the minimizer lists of its own genomes ({genome index: (h1,
     rec, pos)}) and receives those of all genomes, in one all-gather -- on the GPUs through the backend
@@ -351,20 +380,31 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         if not 1 <= int(ww) <= MAX_W:
             raise ValueError(f"window size {ww} outside 1..{MAX_W} (limit of the window kernels)")
     st.start("read_fasta+upload")
-    genomes = load_genomes(backend, mine)
-    st.mark("genomes_resident")
-    for p in mine:
-        g = genomes[p]
+
+    def arrived(p, g):
         if len(g.names) == 0 or g.total_bp == 0:
             raise ValueError(f"{p}: no sequence records")
         rl = getattr(g, "rec_len", None)
         if len(g.names) >= MAX_RECORDS or (rl is not None and len(rl) and int(np.max(rl)) >= MAX_RECORD_BP):
             raise ValueError(f"{p}: more than 2^22 records or a record of 2^40 bases or more "
                              "(limits of the refinement rounds' composite interval keys)")
-    for p in mine:
-        fa.write_fai(f"{fa.basename(p)}.fai", genomes[p].recs)
+        fa.write_fai(f"{fa.basename(p)}.fai", g.recs)
+
+    overlap_load = (world == 1 and common and len(mine) > 1 and isinstance(backend, GpuBackend)
+                    and os.environ.get("NTS_FASTA", "device") != "host" and os.environ.get("NTS_LOAD_OVERLAP", "1") != "0")
+    if overlap_load:
+        # files in the order the filter takes them (sorted: src/ntsynt_make_common_bf.cpp:105-107), on a context of their own
+        from .device import Context
+        load_ctx = Context(backend.device)
+        genomes = _Arriving(sorted(mine), lambda p: fa.read_fasta_device(load_ctx, p)[0], arrived)
+        genomes[sorted(mine)[0]]                               # the first one sizes the filter
+    else:
+        genomes = load_genomes(backend, mine)
+        for p in mine:
+            arrived(p, genomes[p])
+    st.mark("first_genome_resident" if overlap_load else "genomes_resident")
     # record names and sizes are needed everywhere (output text, filter sizing)
-    meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine}
+    meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine} if not overlap_load else None
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, meta)
@@ -380,8 +420,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         st.start("make_common_bf")
         ordered = sorted(fastas)                               # src/ntsynt_make_common_bf.cpp:105-107
         from .device import bf_size_bytes
-        approx, nbytes = bf_size_bytes(meta[ordered[0]][1], fpr, bf_rounding)
-        log(f"Genome size (bp): {meta[ordered[0]][1]}")
+        first_bp = meta[ordered[0]][1] if meta is not None else genomes[ordered[0]].total_bp
+        approx, nbytes = bf_size_bytes(first_bp, fpr, bf_rounding)
+        log(f"Genome size (bp): {first_bp}")
         log(f"BF size (bytes): {approx}")
         my_sorted = [p for p in ordered if owner[p] == rank]
         bf = backend.bf_new(nbytes, k, world, ones=(world > 1 and not my_sorted))
@@ -411,6 +452,10 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
         st.stop()
         st.mark("common_filter_done")
+    if overlap_load:
+        genomes.wait_all()
+        meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine}
+        st.mark("genomes_resident")
 
     # The reference's experimental repeat filter (config "repeat": rules make_repeat_bf and indexlr -r, smk:65-85): k-mers seen
     # twice within a genome, excluded from the whole-genome sketches; the refinement rounds do not use it (ntsynt_run.py gets
