@@ -314,17 +314,18 @@ class _Arriving(dict):
     the loader's context: copy engines and host threads) -- the filter file, which is what the run waits for in the end,
     gets started that much earlier."""
 
-    def __init__(self, paths, load, on_arrival):
+    def __init__(self, paths, loaders, on_arrival):
+        "loaders: one callable per loader thread (each with a context of its own); file i goes to loader i mod len(loaders)"
         super().__init__()
         from concurrent.futures import ThreadPoolExecutor
-        self._pool = ThreadPoolExecutor(max_workers=1)
+        self._pools = [ThreadPoolExecutor(max_workers=1) for _ in loaders]
         self._order = list(paths)
 
-        def task(p):
+        def task(load, p):
             g = load(p)
             on_arrival(p, g)
             return g
-        self._fut = {p: self._pool.submit(task, p) for p in paths}
+        self._fut = {p: self._pools[i % len(loaders)].submit(task, loaders[i % len(loaders)], p) for i, p in enumerate(paths)}
 
     def __getitem__(self, p):
         if not dict.__contains__(self, p):
@@ -334,7 +335,8 @@ class _Arriving(dict):
     def wait_all(self):
         for p in self._order:
             self[p]
-        self._pool.shutdown(wait=True)
+        for pool in self._pools:
+            pool.shutdown(wait=True)
 
 
 def _exchange_lists(backend, local, n_total):
@@ -395,8 +397,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     if overlap_load:
         # files in the order the filter takes them (sorted: src/ntsynt_make_common_bf.cpp:105-107), on a context of their own
         from .device import Context
-        load_ctx = Context(backend.device)
-        genomes = _Arriving(sorted(mine), lambda p: fa.read_fasta_device(load_ctx, p)[0], arrived)
+        n_loaders = max(1, min(int(os.environ.get("NTS_LOADERS", "1")), len(mine)))
+        load_ctxs = [Context(backend.device) for _ in range(n_loaders)]
+        genomes = _Arriving(sorted(mine), [(lambda p, c=c: fa.read_fasta_device(c, p)[0]) for c in load_ctxs], arrived)
         genomes[sorted(mine)[0]]                               # the first one sizes the filter
     else:
         genomes = load_genomes(backend, mine)
