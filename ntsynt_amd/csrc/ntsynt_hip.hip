@@ -94,6 +94,7 @@ struct nts_ctx
   const uint32_t* cur_fold = nullptr; // folded copy of the filter for the LDS first look (k_hash_accept4), or null
   int fold_mode = 0;                  // 0 auto, 1 never (tests)
   bool acc4_lds_set = false;
+  bool acc4r_lds_set = false;
   uint32_t cur_summary_shift = 0;
   uint32_t* cur_tile_any = nullptr;
   // pinned staging buffers + streams of the bulk transfers done by host threads (FASTA bytes up: nts_genome_from_fasta; filter
@@ -2771,7 +2772,17 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       A.tile_cnt = d_tcnt;
       A.tile_ordered = d_tord;
       ScopedTimer t(ctx, "hash_accept", true);
-      if (ctx->cur_fold) {
+      if (ctx->cur_fold && k <= 32 && !(getenv("NTS_ACCEPT_REG") && atoi(getenv("NTS_ACCEPT_REG")) == 0)) {
+        // bases from the 2-bit image in registers (k_hash_accept4r); NTS_ACCEPT_REG=0: the LDS-staged kernel (tests)
+        if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
+        if (!ctx->acc4r_lds_set) {
+          HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4r), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(Accept4rLds)));
+          ctx->acc4r_lds_set = true;
+        }
+        hipLaunchKernelGGL(k_hash_accept4r, dim3((uint32_t)((n_kt + 3) / 4)), dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A, g->d_pack,
+                           ctx->cur_fold, n_kt);
+      } else if (ctx->cur_fold) {
         if (!ctx->acc4_lds_set) {
           HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(Accept4Lds)));

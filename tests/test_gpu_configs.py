@@ -240,7 +240,7 @@ def test_c4_one_gpu_share_of_eight_divergent_3gbp_genomes(ctx):
     common.free()
 
 
-def test_sparse_filter_summary_path_matches_oracle(ctx):
+def test_sparse_filter_summary_path_matches_oracle(ctx, monkeypatch):
     "the summary-first dense pass (csrc: k_hash_keys_sparse) on ragged records with N runs, against the plain pass and the oracle"
     from ntsynt_amd import synth
     from ntsynt_amd.device import BloomFilter, bf_size_bytes, sketch
@@ -274,7 +274,9 @@ def test_sparse_filter_summary_path_matches_oracle(ctx):
             b = sketch(ctx, d, k, w, common).to_numpy()                # every k-mer probed in HBM
             # "dense": keys + window kernel behind the summary; "auto": the accepted k-mers as the candidate list, with the folded
             # copy of the filter in LDS first (k_hash_accept4) or without it (k_hash_accept)
-            for smode, mode in (("auto", "dense"), ("auto", "auto"), ("no-lds", "auto")):
+            # copy of the filter in LDS first (k_hash_accept4r: bases in registers; k_hash_accept4: bases staged in LDS) or without it
+            for smode, mode, reg in (("auto", "dense", "1"), ("auto", "auto", "1"), ("auto", "auto", "0"), ("no-lds", "auto", "1")):
+                monkeypatch.setenv("NTS_ACCEPT_REG", reg)
                 ctx.sketch_summary(smode)
                 ctx.sketch_mode(mode)
                 a = sketch(ctx, d, k, w, common).to_numpy()
