@@ -499,8 +499,8 @@ def main():
         value = bases_total(n_fam, genomes) * args.steps / dt / 1e9
         pruned_run = tm["hash_select"][1] > 0
         if pruned_run:
-            # (the library's rule: upper-halves kernel for k <= 32 while a 4096-index tile lists at most ~180 k-mers)
-            hi_kernel = k <= 32 and 4096.0 * c_used / w * 1.4 <= 256.0
+            # (the library's rule: upper-halves kernel for k <= 32 while a 4096-index tile lists at most ~220 k-mers)
+            hi_kernel = k <= 32 and 4096.0 * c_used / w * 1.15 <= 256.0
             kern = ("k_hash_select_hi (upper halves of both strand hashes rolled for every k-mer; the ~c/w listed k-mers hashed in full and probed, "
                     "probes overlapped with the next tile)") if hi_kernel else "k_hash_select (hash every k-mer, probe candidates only)"
             a_ms = avg("hash_select")

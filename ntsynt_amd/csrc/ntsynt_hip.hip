@@ -2684,9 +2684,13 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   // (and an assembly that is not in pieces: a tile that spans runs lists 64 k-mers per boundary and looks positions up
   // per k-mer.  3 Gbp in 24 / 5,000 / 100,000 / 1,000,000 contigs: 1.43 / 1.56 / 2.12 / 7.29 ms against k_hash_select's
   // 2.19 / 2.26 / 2.82 / 4.39 -- it keeps the assemblies with more than one run per two tiles)
-  const bool sel_hi = !accept_all && ctx->select_impl != 1 && k <= HI_K_MAX && 4096.0 * prune_c / w * 1.4 <= 256.0 &&
+  // (listed k-mers per tile: mean 4096 c/w, spread ~ its square root; a tile with more than a round holds takes the slow path.
+  // Margins measured at 3 Gbp, pairs at 2-8 % divergence: two per lane up to a mean of 107 (c = 22: select 1.79 ms against 2.00
+  // with four per lane), four per lane up to 223 (c = 53: 4.32 ms against 4.79 for k_hash_select); NTS_HI_M2 / NTS_HI_M4 override)
+  const double hi_m4 = getenv("NTS_HI_M4") ? atof(getenv("NTS_HI_M4")) : 1.15, hi_m2 = getenv("NTS_HI_M2") ? atof(getenv("NTS_HI_M2")) : 1.2;
+  const bool sel_hi = !accept_all && ctx->select_impl != 1 && k <= HI_K_MAX && 4096.0 * prune_c / w * hi_m4 <= 256.0 &&
                       (ctx->select_impl == 2 || 2ull * T.n_runs <= (V + HIW_TILE - 1) / HIW_TILE + 64);
-  const uint32_t hi_per = 4096.0 * prune_c / w * 1.5 <= 128.0 ? 2u : 4u; // listed k-mers per lane and round
+  const uint32_t hi_per = 4096.0 * prune_c / w * hi_m2 <= 128.0 ? 2u : 4u; // listed k-mers per lane and round
   const uint64_t sel_tile = accept_all ? (uint64_t)KEY_TILE : sel_hi ? (uint64_t)HIW_TILE : (uint64_t)SEL_TILE;
   const uint64_t n_kt = (V + sel_tile - 1) / sel_tile; // tiles of the select kernel (16384 indices each; 8192 for k_hash_accept)
   if (n_kt > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
