@@ -261,16 +261,17 @@ def main():
     import torch
     import torch.distributed as dist
     from ntsynt_amd.device import BloomFilter, Comm, Context, Genome, allgather_minimizers, bf_size_bytes, sketch
-    # NTS_BENCH_BACKEND=gloo is a verification mode for boxes with fewer GPUs than ranks (tests/test_gpu_multirank.py):
-    # ranks share the visible GPUs and the two exchanges run on host copies; the measured configuration is RCCL.
+    # The process group carries the communicator id, the barriers and the max-over-ranks of the clock; the two exchanges run
+    # inside libntsynt_hip.so.  NTS_BENCH_BACKEND=gloo + NTS_RCCL_LIB=<tests/rccl_standin>: ranks sharing the visible GPUs (boxes
+    # with fewer GPUs than ranks, tests/test_gpu_multirank.py) -- same code path, not a measurement; the measured one is nccl.
     backend = os.environ.get("NTS_BENCH_BACKEND", "nccl")
-    host_comm = backend != "nccl"
-    if host_comm and torch.cuda.is_available():
+    shared_gpus = backend != "nccl"
+    if shared_gpus and torch.cuda.is_available():
         local_rank = local_rank % torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        if host_comm:
+        if shared_gpus:
             dist.init_process_group(backend)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -280,23 +281,25 @@ def main():
     # communicator not come up on this node (it has only ever been brought up with one rank), the bench still measures the
     # sketch: the exchanges then go through torch.distributed on device tensors, and the line says so (config.exchanges).
     comm, exchanges = None, "none (one GPU)"
-    if world > 1 and not host_comm:
+    pg_dev = "cpu" if shared_gpus else f"cuda:{local_rank}"
+    if world > 1:
         try:
             comm = Comm.from_torch(ctx)
-            exchanges = "libntsynt_hip.so over RCCL (nts_bf_allreduce_and, nts_mx_allgather)"
+            served_by = ctx.lib.nts_comm_library().decode()
+            exchanges = f"libntsynt_hip.so (nts_bf_allreduce_and, nts_mx_allgather) over {'RCCL' if served_by == 'librccl' else served_by}"
         except Exception as exc:                              # noqa: BLE001 -- any failure of the communicator set-up
+            if shared_gpus:
+                raise
             exchanges = f"torch.distributed (library communicator failed: {exc})"
             print(f"[bench] rank {rank}: {exchanges}", file=sys.stderr, flush=True)
         # every rank must take the same path
-        ok = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}")
+        ok = torch.tensor([1 if comm is not None else 0], device=pg_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0 and comm is not None:
             comm.close()
             comm = None
             exchanges = "torch.distributed (library communicator failed on another rank)"
-    elif world > 1:
-        exchanges = "host copies over gloo (verification mode)"
-    torch_comm = world > 1 and comm is None and not host_comm
+    torch_comm = world > 1 and comm is None
     k, w = args.k, args.w
     total_bp = int(mbp * 1e6)
 
@@ -343,13 +346,6 @@ def main():
                 ctx.sync()
             ndist.allreduce_and(buf, and_into)
             torch.cuda.synchronize()
-        else:                                               # verification mode: the same reduction on host copies
-            bits = torch.from_numpy(common.to_numpy())
-            gathered = [torch.empty_like(bits) for _ in range(world)]
-            dist.all_gather(gathered, bits)
-            for other in gathered:
-                bits &= other
-            common.from_numpy(bits.numpy())
         ctx.sync()
         t_allreduce = time.time() - t1
     ins_ms, ins_n = ctx.timing("bf_insert")
@@ -412,7 +408,7 @@ def main():
         fence()
         el = time.time() - t_start
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device="cpu" if host_comm else f"cuda:{local_rank}")
+            t = torch.tensor([el], dtype=torch.float64, device=pg_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, n_mx

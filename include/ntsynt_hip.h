@@ -168,6 +168,9 @@ int nts_and_raw(nts_ctx* ctx, void* acc_dev, const void* other_dev, uint64_t byt
  *                      (torch.distributed store, MPI, a file)
  * nts_comm_init      : ncclCommInitRank on the context's GPU
  * nts_comm_wrap      : adopt an existing ncclComm_t (not destroyed by nts_comm_destroy)
+ * nts_comm_library   : which library serves the collectives: "librccl" (the process's copy or the system's), the path
+ *                      given in NTS_RCCL_LIB (a site's own build; the test suite's stand-in for ranks that share one
+ *                      GPU), or "" when none could be loaded
  * nts_bf_create_sharded : a filter whose allocation is `world` chunks of a multiple of 16 bytes -- the layout the
  *                      all-reduce exchanges; otherwise identical to nts_bf_create
  * nts_bf_fill_ones   : identity of AND, for a rank that owns no genome
@@ -185,6 +188,7 @@ void nts_comm_destroy(nts_comm* comm);
 int nts_comm_world(const nts_comm* comm);
 int nts_comm_rank(const nts_comm* comm);
 void* nts_comm_handle(const nts_comm* comm);
+const char* nts_comm_library(void);
 int nts_bf_create_sharded(nts_ctx* ctx, uint64_t bytes, int world, nts_bf** out);
 int nts_bf_fill_ones(nts_ctx* ctx, nts_bf* bf);
 int nts_bf_allreduce_and(nts_ctx* ctx, nts_bf* bf, nts_comm* comm);

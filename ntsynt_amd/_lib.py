@@ -95,6 +95,7 @@ SYMBOLS = [
     ("nts_comm_world", ctypes.c_int, [c_vp]),
     ("nts_comm_rank", ctypes.c_int, [c_vp]),
     ("nts_comm_handle", c_vp, [c_vp]),
+    ("nts_comm_library", ctypes.c_char_p, []),
     ("nts_bf_create_sharded", ctypes.c_int, [c_vp, u64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     ("nts_bf_fill_ones", ctypes.c_int, [c_vp, c_vp]),
     ("nts_bf_allreduce_and", ctypes.c_int, [c_vp, c_vp, c_vp]),

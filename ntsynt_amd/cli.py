@@ -135,8 +135,9 @@ def main(argv=None):
         import torch.distributed as dist
         device = int(os.environ.get("LOCAL_RANK", "0"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # NTS_DIST_BACKEND=gloo: verification mode for boxes with fewer GPUs than ranks (ranks share the GPUs, the
-        # collectives run on host copies: ntsynt_amd/pipeline.py GpuBackend.host_comm); production is nccl (= RCCL)
+        # The process group only hands the communicator id round and synchronises the ranks; the two exchanges run inside
+        # libntsynt_hip.so (nts_bf_allreduce_and, nts_mx_allgather).  NTS_DIST_BACKEND=gloo + NTS_RCCL_LIB=<stand-in>: ranks that
+        # share GPUs (a box with fewer GPUs than ranks; tests/test_gpu_multirank.py); production is nccl (= RCCL) throughout
         backend = os.environ.get("NTS_DIST_BACKEND", "nccl")
         if backend != "nccl":
             device %= max(torch.cuda.device_count(), 1)

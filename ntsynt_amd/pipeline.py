@@ -97,8 +97,6 @@ class GpuBackend:
         self.own_ctx = ctx is None
         self.ctx = ctx or Context(device)
         self.device = self.ctx.device
-        # collectives on host copies (gloo) instead of device buffers (RCCL): verification mode, see cli.py
-        self.host_comm = os.environ.get("NTS_DIST_BACKEND", "nccl") != "nccl"
         self.comm = None
         self._batch = None                 # (key, Genome): the run's assemblies as one resident batch genome
 
@@ -122,25 +120,15 @@ class GpuBackend:
         return g
 
     # multi-GPU: the two exchanges run in the library over RCCL (nts_bf_allreduce_and, nts_mx_allgather); the id of the
-    # communicator travels through torch.distributed's default group.  host_comm: verification mode (see __init__).
+    # communicator travels through torch.distributed's default group (any backend: it carries 128 bytes and barriers).
     def init_comm(self):
-        if not self.host_comm and self.comm is None:
+        if self.comm is None:
             from .device import Comm
             self.comm = Comm.from_torch(self.ctx)
 
     def bf_new(self, nbytes, k, world=1, ones=False):
-        from .device import BloomFilter, wrap_bloom
-        if world == 1 or not self.host_comm:
-            return BloomFilter(self.ctx, nbytes, k, world=world, ones=ones)
-        import torch
-        from .dist import padded_len
-        buf = torch.zeros(padded_len(nbytes, world), dtype=torch.uint8, device=f"cuda:{self.device}")
-        if ones:                      # identity of AND, for a rank that owns no genome
-            buf[:nbytes] = 0xFF
-        torch.cuda.synchronize(buf.device)
-        bf = wrap_bloom(self.ctx, buf, nbytes, k)
-        bf.tensor = buf
-        return bf
+        from .device import BloomFilter
+        return BloomFilter(self.ctx, nbytes, k, world=world, ones=ones)
 
     def bf_insert(self, bf, genome):
         bf.insert(genome)
@@ -228,15 +216,8 @@ class GpuBackend:
 
     def exchange_dev(self, local, n_total):
         "exchange 2 on device handles: {genome index: Minimizers} of this rank -> [Minimizers of every genome], all in HBM"
-        from .device import Minimizers
         ids = sorted(local)
-        if not self.host_comm:
-            return self.comm.allgather_minimizers([local[i] for i in ids], ids, n_total)
-        import torch.distributed as dist               # verification mode: through host objects
-        box = [None] * dist.get_world_size()
-        dist.all_gather_object(box, {i: local[i].to_numpy() for i in ids})
-        merged = {i: v for part in box for i, v in part.items()}
-        return [Minimizers.from_numpy(self.ctx, *merged[i]) for i in range(n_total)]
+        return self.comm.allgather_minimizers([local[i] for i in ids], ids, n_total)
 
     def graph(self, lists, keeps, list_ids):
         from .graph import build_graph_device
@@ -247,34 +228,14 @@ class GpuBackend:
         return walk_paths(nv, eu, ev, e_alive, key)
     walk.oriented = True
 
-    def to_comm(self, arr, dtype):
-        "numpy -> tensor on the device the collectives use"
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(arr).view(dtype))
-        return t if self.host_comm else t.to(f"cuda:{self.device}")
-
-    def comm_empty(self, n, dtype):
-        import torch
-        return torch.empty(n, dtype=dtype, device="cpu" if self.host_comm else f"cuda:{self.device}")
-
     def allreduce_and(self, bf):
         "exchange 1: common filter = AND over the ranks' filters, in place"
         self.ctx.sync()
-        if not self.host_comm:
-            self.comm.allreduce_and(bf)
-            return
-        import torch
-        from .dist import allreduce_and
-        staged = bf.tensor.cpu()
-        allreduce_and(staged, lambda a, b: a.bitwise_and_(b))
-        bf.tensor.copy_(staged)
-        torch.cuda.synchronize(bf.tensor.device)
+        self.comm.allreduce_and(bf)
 
     def exchange_lists(self, local, n_total):
         """exchange 2: {genome index: (h1, rec, pos)} of this rank -> the lists of all genomes on every rank, as ONE
-        device all-gather (nts_mx_allgather).  Verification mode: None (the caller gathers host objects)."""
-        if self.host_comm:
-            return None
+        device all-gather (nts_mx_allgather)."""
         from .device import Minimizers
         ids = sorted(local)
         mine = [Minimizers.from_numpy(self.ctx, *local[i]) for i in ids]

@@ -1,6 +1,11 @@
-"""Two ranks on one box: bench.py's and the pipeline's multi-rank code paths, end to end on the GPU, with gloo and host
-copies standing in for RCCL (a 1-GPU box cannot host two RCCL ranks).  What RCCL itself adds -- the collectives on
-device buffers -- is the part exercised by the driver's multi-GPU run; the schedules are covered on CPU by
+"""More than one rank on a box with ONE GPU: the product's exchange code (csrc/nts_comm.inc: nts_bf_allreduce_and,
+nts_mx_allgather -- the reduce-scatter by grouped send/recv, the AND of the received pieces, the in-place all-gather, the
+packed list payload) executed with world 2 and 3, plus bench.py's and the pipeline's multi-rank paths end to end.
+
+Real RCCL refuses two ranks on one device, so the ranks (processes sharing GPU 0) reach each other through the test-only
+librccl stand-in (tests/rccl_standin/, selected with NTS_RCCL_LIB): same C entry points, same call sequence, device
+buffers on both ends.  What this does NOT show is speed or RCCL's own behaviour on xGMI -- that is the driver's
+multi-GPU run.  The schedules of the torch.distributed fallback (ntsynt_amd/dist.py) are covered on CPU by
 tests/test_dist_gloo.py."""
 import json
 import os
@@ -12,6 +17,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STANDIN = os.path.join(ROOT, "tests", "rccl_standin", "librccl_standin.so")
+WORKER = os.path.join(ROOT, "tests", "multirank_worker.py")
 
 
 def _free_port():
@@ -20,11 +27,55 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _env(**extra):
+    assert os.path.exists(STANDIN), "tests/rccl_standin/librccl_standin.so is not built (__graft_entry__.build())"
+    return dict(os.environ, PYTHONPATH=ROOT, NTS_RCCL_LIB=STANDIN, **extra)
+
+
+def _ranks(world, case, tmp_path, **extra):
+    "`world` worker processes on GPU 0; returns their JSON lines"
+    id_file = str(tmp_path / f"id_{case}_{world}")
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), id_file, case], env=_env(**extra), cwd=tmp_path,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    for r, p in enumerate(procs):
+        try:
+            so, se = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, f"rank {r}: {se[-3000:]}"
+        outs.append(json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]))
+    return outs
+
+
 def _torchrun(n, script_args, env_extra, cwd):
-    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
-    return subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    return subprocess.run(cmd, cwd=cwd, env=_env(MASTER_ADDR="127.0.0.1", **env_extra), capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bf_allreduce_and_between_ranks(world, tmp_path):
+    """exchange 1 == bitwise AND of the ranks' filters: sizes that do not divide by 16 x world, pieces forced small so the
+    reduce-scatter loop iterates (3,000,008 bytes / world in 64 KiB pieces), a rank contributing the identity"""
+    outs = _ranks(world, "allreduce", tmp_path, NTS_COMM_PIECE="65536")
+    assert all(o["library"] == STANDIN and o["sizes"][-1] == 3_000_008 for o in outs)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bf_allreduce_and_one_piece(world, tmp_path):
+    "same, with the product's piece size (every chunk is one piece)"
+    outs = _ranks(world, "allreduce", tmp_path)
+    assert len(outs) == world
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_mx_allgather_between_ranks(world, tmp_path):
+    "exchange 2: uneven list counts per rank, an empty list, lists of very different lengths; repeated genome numbers rejected"
+    outs = _ranks(world, "allgather", tmp_path)
+    assert all(o["rejects_repeats"] for o in outs)
 
 
 def test_bench_two_ranks(tmp_path):
@@ -36,24 +87,29 @@ def test_bench_two_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and out["steps"] == 2
     assert out["config"]["genomes_on_rank0"] == 2 and "c4: 4 synthetic" in out["config"]["workload"]
+    assert out["config"]["exchanges"].startswith("libntsynt_hip.so (nts_bf_allreduce_and, nts_mx_allgather)")
     assert out["bloom"]["allreduce_and_s"] > 0
     assert "e2e" not in out and "cpu_baseline" not in out          # single-GPU legs only
 
 
-def test_pipeline_two_ranks_matches_single_rank(tmp_path):
-    "bin/ntSynt under torchrun with two ranks (genomes sharded, AND all-reduce, list broadcasts) == one rank, byte for byte"
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipeline_ranks_match_single_rank(world, tmp_path):
+    """bin/ntSynt under torchrun with `world` ranks (genomes sharded, nts_bf_allreduce_and, nts_mx_allgather in every round,
+    replicated graph stage) == one rank, byte for byte -- the filter file included"""
     from ntsynt_amd import synth
-    paths = synth.make_family(str(tmp_path), 3, 1_500_000, 2, 0.01, seed=44, micro=6)
+    paths = synth.make_family(str(tmp_path), 4, 1_200_000, 2, 0.01, seed=44, micro=6)
     one = tmp_path / "one"
-    two = tmp_path / "two"
+    many = tmp_path / "many"
     os.makedirs(one)
-    os.makedirs(two)
+    os.makedirs(many)
     args = ["-k", "24", "-w", "500", "-d", "1", "--prefix", "p", "--indel", "5000", "--merge", "20000", "--force"] + paths
     env = dict(os.environ, PYTHONPATH=ROOT)
     subprocess.run([sys.executable, os.path.join(ROOT, "bin", "ntSynt")] + args, cwd=one, env=env, check=True,
                    stdout=subprocess.DEVNULL, timeout=600)
-    r = _torchrun(2, [os.path.join(ROOT, "bin", "ntSynt")] + args, {"NTS_DIST_BACKEND": "gloo"}, two)
+    r = _torchrun(world, [os.path.join(ROOT, "bin", "ntSynt")] + args, {"NTS_DIST_BACKEND": "gloo", "NTS_COMM_PIECE": "262144"}, many)
     assert r.returncode == 0, r.stderr[-3000:]
-    for name in ("p.synteny_blocks.tsv", "p.pre-collinear-merge.synteny_blocks.tsv", "p.common.bf"):
-        assert (one / name).read_bytes() == (two / name).read_bytes(), name
-    assert len((one / "p.synteny_blocks.tsv").read_text().splitlines()) >= 6
+    names = ["p.synteny_blocks.tsv", "p.pre-collinear-merge.synteny_blocks.tsv", "p.common.bf"]
+    names += [os.path.basename(p) + ".k24.w500.tsv" for p in paths]
+    for name in names:
+        assert (one / name).read_bytes() == (many / name).read_bytes(), name
+    assert len((one / "p.synteny_blocks.tsv").read_text().splitlines()) >= 8
