@@ -357,6 +357,34 @@ typedef struct
 /*   - with a filter-out Bloom filter as well (indexlr -r, the experimental repeat filter: ntsynt_run_pipeline.smk:83),
  *     a k-mer present in it is rejected too; with only a filter-out filter, presence alone rejects
  *     (btllib Indexlr::filter_hashed_kmer, recalled: unpinned) */
+/* The window decision of Indexlr::minimize for the k-mer just written to buf[idx % ring] (idx-th VALID k-mer of the
+ * record): returns the k-mer to emit, or NULL.  `strict` is 0 in the restatement (`<=`: the rightmost of equal hashes
+ * wins); 1 (`<`) exists only so that a test can show the reference's own output rules it out. */
+static const hashed_kmer*
+window_decide(const hashed_kmer* buf, uint64_t ring, uint64_t idx, unsigned w, const hashed_kmer** cur_io, int64_t* min_pos_prev, int strict)
+{
+  if (idx + 1 < w) return NULL;
+  const hashed_kmer* cur = *cur_io;
+  const uint64_t left = idx + 1 - w, right = idx + 1;
+  const hashed_kmer* min_left = &buf[left % ring];
+  const hashed_kmer* min_right = &buf[(right - 1) % ring];
+  if (cur == NULL || cur->pos < min_left->pos) {
+    cur = min_left;
+    for (uint64_t i = left; i < right; ++i) {
+      const hashed_kmer* mi = &buf[i % ring];
+      if (strict ? mi->min_hash < cur->min_hash : mi->min_hash <= cur->min_hash) cur = mi;
+    }
+  } else if (strict ? min_right->min_hash < cur->min_hash : min_right->min_hash <= cur->min_hash) {
+    cur = min_right;
+  }
+  *cur_io = cur;
+  if ((int64_t)cur->pos > *min_pos_prev && cur->min_hash != UINT64_MAX) {
+    *min_pos_prev = (int64_t)cur->pos;
+    return cur;
+  }
+  return NULL;
+}
+
 uint64_t
 nts_o_minimize2(const char* seq,
                 uint64_t len,
@@ -388,27 +416,41 @@ nts_o_minimize2(const char* seq,
     hk->pos = R.pos;
     if (bf && !bf_get(bf, bits, h0)) hk->min_hash = UINT64_MAX;
     if (bf_out && bf_get(bf_out, bf_out_bytes * 8, h0)) hk->min_hash = UINT64_MAX;
-    if (idx + 1 >= w) {
-      const uint64_t left = idx + 1 - w, right = idx + 1;
-      const hashed_kmer* min_left = &buf[left % ring];
-      const hashed_kmer* min_right = &buf[(right - 1) % ring];
-      if (cur == NULL || cur->pos < min_left->pos) {
-        cur = min_left;
-        for (uint64_t i = left; i < right; ++i) {
-          const hashed_kmer* mi = &buf[i % ring];
-          if (mi->min_hash <= cur->min_hash) cur = mi;
-        }
-      } else if (min_right->min_hash <= cur->min_hash) {
-        cur = min_right;
+    const hashed_kmer* emit = window_decide(buf, ring, idx, w, &cur, &min_pos_prev, 0);
+    if (emit) {
+      if (n_out < cap) {
+        out_h1[n_out] = emit->out_hash;
+        out_pos[n_out] = emit->pos;
       }
-      if ((int64_t)cur->pos > min_pos_prev && cur->min_hash != UINT64_MAX) {
-        min_pos_prev = (int64_t)cur->pos;
-        if (n_out < cap) {
-          out_h1[n_out] = cur->out_hash;
-          out_pos[n_out] = cur->pos;
-        }
-        ++n_out;
-      }
+      ++n_out;
+    }
+  }
+  free(buf);
+  return n_out;
+}
+
+/* The same decision logic over a stream of comparison keys instead of a sequence: keys[i] is the key of the k-mer at
+ * position i (UINT64_MAX = no accepted k-mer there), every position counts as a valid k-mer.  Used to pin the window rule
+ * to the reference's own output (tests/test_oracle_golden.py): fed only the minimizers a reference TSV lists -- h0 recovered
+ * from the printed hash -- it must emit exactly those again.  Returns the count, positions into out_pos. */
+uint64_t
+nts_o_minimize_keys(const uint64_t* keys, uint64_t n, unsigned w, int strict, uint64_t* out_pos, uint64_t cap)
+{
+  if ((uint64_t)w > n || w == 0) return 0;
+  const uint64_t ring = (uint64_t)w + 1;
+  hashed_kmer* buf = (hashed_kmer*)malloc(sizeof(hashed_kmer) * ring);
+  const hashed_kmer* cur = NULL;
+  int64_t min_pos_prev = -1;
+  uint64_t n_out = 0;
+  for (uint64_t idx = 0; idx < n; ++idx) {
+    hashed_kmer* hk = &buf[idx % ring];
+    hk->min_hash = keys[idx];
+    hk->out_hash = keys[idx];
+    hk->pos = idx;
+    const hashed_kmer* emit = window_decide(buf, ring, idx, w, &cur, &min_pos_prev, strict);
+    if (emit) {
+      if (n_out < cap) out_pos[n_out] = emit->pos;
+      ++n_out;
     }
   }
   free(buf);

@@ -63,6 +63,8 @@ def _load(native=False):
                                             ctypes.c_uint, ctypes.c_uint, _u8p, _u64, _u8p, _u64,
                                             _u64p, _u64p, _u64p, _u64p, ctypes.c_int]
     lib.nts_o_minimize_records2.restype = None
+    lib.nts_o_minimize_keys.argtypes = [_u64p, _u64, ctypes.c_uint, ctypes.c_int, _u64p, _u64]
+    lib.nts_o_minimize_keys.restype = _u64
     return lib
 
 
@@ -251,3 +253,12 @@ def write_indexlr_tsv(path, genome, mins, k, with_seq=True):
                 else:
                     toks.append(f"{hv}:{pv}")
             out.write(f"{name}\t{' '.join(toks)}\n")
+
+
+def minimize_keys(keys, w, strict=False):
+    """Positions the window rule of `minimize` emits for a stream of comparison keys (uint64 per position, 2^64-1 = no
+    accepted k-mer there).  strict=True swaps the tie rule to `<` (a negative control for the tests, not the restatement)."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    out = np.empty(max(keys.size, 1), dtype=np.uint64)
+    n = lib().nts_o_minimize_keys(_p64(keys), keys.size, int(w), int(bool(strict)), _p64(out), out.size)
+    return out[:n].copy()

@@ -1,0 +1,83 @@
+"""Build-time guard for the hand-scheduled kernel (csrc/nts_pruned.inc k_hash_select_hi).
+
+Its software pipeline issues its loads with explicit instructions and waits with hand-counted `s_waitcnt vmcnt(N)`
+(N = the LDS-DMA loads of the next tile + the Bloom probes of the previous one).  That arithmetic holds only while the
+compiler puts no vector-memory operation of its own between them -- a spilled register or a struct copied through
+scratch has done that before (nts_pruned.inc, comments at the geometry variables).  This test reads the gfx950 code object
+out of the built library and checks the four instantiations, so that a toolchain or source change that breaks the
+assumption fails the CPU suite here instead of a stress run on a GPU box."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "ntsynt_amd", "libntsynt_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+VMEM = re.compile(r"^\s*(global_|flat_|buffer_|scratch_|tbuffer_)\w+")
+
+
+@pytest.fixture(scope="module")
+def code_object(tmp_path_factory):
+    assert os.path.exists(LIB), "libntsynt_hip.so is not built (__graft_entry__.build())"
+    for tool in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump", "llvm-readelf"):
+        if not os.path.exists(os.path.join(LLVM, tool)):
+            pytest.skip(f"{tool} not in {LLVM}")
+    d = tmp_path_factory.mktemp("co")
+    fat, co = str(d / "fat.bin"), str(d / "dev.co")
+    subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", LIB, str(d / "unused.so")], check=True)
+    subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+    notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+    return co, notes
+
+
+def _kernel_meta(notes, symbol):
+    "the metadata block of one kernel in the code object's note record"
+    at = notes.index(f".name:           {symbol}\n")
+    start = notes.rfind("  - .agpr_count", 0, at)
+    if start < 0:
+        start = notes.rfind("  - .args", 0, at)
+    end = notes.find("\n  - ", at)
+    block = notes[start:end if end > 0 else None]
+    return {m.group(1): m.group(2) for m in re.finditer(r"\.(\w+):\s+(\S+)", block)}
+
+
+def _disassemble(co, symbol):
+    out = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", f"--disassemble-symbols={symbol}", co], check=True,
+                         capture_output=True, text=True).stdout
+    return [ln.split("//")[0].strip() for ln in out.splitlines() if ln.startswith("\t")]
+
+
+@pytest.mark.parametrize("has_bf,per", [(True, 2), (True, 4), (False, 2), (False, 4)])
+def test_select_hi_pipeline_has_only_its_own_vector_memory_operations(code_object, has_bf, per):
+    co, notes = code_object
+    symbol = f"_ZN12_GLOBAL__N_116k_hash_select_hiILb{int(has_bf)}ELj{per}EEEvNS_9SelParamsEjjm"
+    assert symbol in notes, "k_hash_select_hi instantiation not found (renamed? update this guard with it)"
+    meta = _kernel_meta(notes, symbol)
+    # nothing of the kernel lives in scratch memory: a spill would travel through the queue the waits count
+    assert meta["private_segment_fixed_size"] == "0", meta
+    assert meta.get("vgpr_spill_count", "0") == "0", meta          # (scalar spills go to lanes of a vector register, not to memory)
+    ins = _disassemble(co, symbol)
+    assert len(ins) > 1000
+    assert not [i for i in ins if i.startswith(("scratch_", "buffer_", "tbuffer_"))]
+    # the explicit loads: the stage (two 16-byte LDS-DMA loads, in the prologue and in the loop) and `per` probes in the loop
+    assert sum(i.startswith("global_load_lds_dwordx4") for i in ins) == 4
+    assert sum(i.startswith("global_load_lds_dword ") for i in ins) == (2 * per if has_bf else 0)     # loop + the last tile behind it
+    # the wait that lets the rolling start: everything but the loads issued in this turn has landed.  Walk back from it: the
+    # vector-memory operations since the loop's first stage load are exactly [stage, stage, probe x per]
+    n_wait = per + 2 if has_bf else 2
+    stage = [n for n, i in enumerate(ins) if i.startswith("global_load_lds_dwordx4")]
+    loop_first_stage = stage[2]
+    waits = [n for n, i in enumerate(ins) if i == f"s_waitcnt vmcnt({n_wait})" and n > loop_first_stage]
+    assert waits, f"no s_waitcnt vmcnt({n_wait}) behind the loop's stage loads"
+    wait_at = waits[0]
+    between = [i.split()[0] for i in ins[loop_first_stage:wait_at] if VMEM.match(i)]
+    assert between == ["global_load_lds_dwordx4"] * 2 + ["global_load_lds_dword"] * (per if has_bf else 0), between
+    # and the compiler did not slip a wait of its own for vector memory in between (it would show a load it tracks there)
+    assert not [i for i in ins[loop_first_stage:wait_at] if i.startswith("s_waitcnt") and "vmcnt" in i]
+    if has_bf:
+        # the probes are read from LDS only behind a full wait
+        after = ins[wait_at + 1:]
+        assert any(i == "s_waitcnt vmcnt(0)" for i in after)

@@ -81,6 +81,62 @@ def test_minimizer_tsv_counts(golden_dir):
         assert (np.diff(pos) > 0).all() and np.diff(pos).max() <= 1000
 
 
+def _h0_from_h1(h1, k):
+    "inverse of ntHash's extension step (t = h0 * (1 ^ k * MULTISEED); t ^= t >> 27): SURVEY.md P1"
+    seed, mask = 0x90b45d39fb6da1fa, (1 << 64) - 1
+    x = h1.copy()
+    for _ in range(3):                                   # undoes t ^= t >> 27 (27 * 3 >= 64)
+        x = h1 ^ (x >> np.uint64(27))
+    inv = pow((1 ^ (k * seed)) & mask, -1, 1 << 64)      # the multiplier is odd
+    with np.errstate(over="ignore"):
+        h0 = x * np.uint64(inv)
+        back = h0 * np.uint64((1 ^ (k * seed)) & mask)
+    assert np.array_equal(back ^ (back >> np.uint64(27)), h1)
+    return h0
+
+
+@pytest.mark.parametrize("key", sorted(MX_FILES))
+def test_window_rule_pinned_to_reference_minimizers(golden_dir, key):
+    """u5 against the reference's own indexlr output (295,028 minimizers over the five fixture TSVs): the window is w k-mers,
+    the comparison key is hashes()[0] (not the printed hash), and of equal keys the rightmost wins.
+
+    h0 of every listed minimizer is recovered from the printed h1.  A k-mer that was never a window's minimum can be
+    deleted without changing any window's minimum, so the oracle's decision logic run over ONLY the listed minimizers
+    (every other position empty) must emit exactly the list again.  Negative controls show the data discriminates:
+    the same with the printed hash as key, with `<` as tie rule, or with a window of w + 1 does not reproduce it.  A window
+    shorter than w cannot be told apart this way; that bound comes from the gaps: none exceeds w, and dozens per file equal w."""
+    z = np.load(os.path.join(golden_dir, MX_FILES[key]))
+    k, w = key[1], 1000
+    h1, pos, ci = z["h1"], z["pos"].astype(np.int64), z["contig_idx"]
+    h0 = _h0_from_h1(h1, k)
+    n_w = n_ties = 0
+    for c in np.unique(ci):
+        m = ci == c
+        p, a, b = pos[m], h0[m], h1[m]
+        assert (np.diff(p) > 0).all()
+        gaps = np.diff(p)
+        assert gaps.max() <= w
+        n_w += int((gaps == w).sum())
+        n_ties += int(((a[1:] == a[:-1]) & (gaps < w)).sum())     # equal keys, the later one listed while the earlier is in its window
+        n = int(p[-1]) + w
+        dense = np.full(n, np.iinfo(np.uint64).max, dtype=np.uint64)
+        dense[p] = a
+        assert np.array_equal(O.minimize_keys(dense, w).astype(np.int64), p), "oracle window rule != reference list"
+        assert not np.array_equal(O.minimize_keys(dense, w + 1).astype(np.int64), p), "a window of w + 1 k-mers fits as well"
+        assert not np.array_equal(O.minimize_keys(dense, w, strict=True).astype(np.int64), p), "`<` fits as well"
+        dense[p] = b
+        assert not np.array_equal(O.minimize_keys(dense, w).astype(np.int64), p), "the printed hash as key fits as well"
+        # the condition the verdict names, spelled out: for neighbours a < b with key[b] > key[a] (b took over when a left the
+        # window), every later minimizer c within a's reach has key[c] > key[b]
+        up = np.nonzero(a[1:] > a[:-1])[0]
+        for i in up[:4000]:
+            j = i + 2
+            while j < len(p) and p[j] <= p[i] + w:
+                assert a[j] > a[i + 1]
+                j += 1
+    assert n_w >= 20 and n_ties >= 500
+
+
 def test_bf_size_arithmetic():
     "row A1 numbers (src/ntsynt_make_common_bf.cpp:38-39)"
     assert O.bf_approx_bytes(29058289, 0.025) == 143467638
