@@ -5,7 +5,12 @@
 
 A "step" is one pass of the sketch (canonical ntHash + common-Bloom probe + window-of-w argmin, rows B1-B3) over the
 rank's synthetic genomes, which are resident in HBM together with the common Bloom filter before the timed region
-starts (generated there: nts_genome_synth).  `value` = bases sketched by all ranks per second.
+starts (generated there: nts_genome_synth_plan).  `value` = bases sketched by all ranks per second.
+
+The families are SURVEY.md 8(d)'s: an i.i.d. ancestor in contigs, genome j = the ancestor with substitutions at p/2 plus a fixed
+set of structural events of its own (5 inversions of 1-5 Mbp, 2 inter-contig translocations, 20 indels of 1-60 kbp, 60 small
+rearrangements, 200 indels of 1-50 bp: ntsynt_amd/synth.py structural_plan), so that the graph stage of the end-to-end leg has indel cuts, erosions and merges to make
+(--substitutions-only gives round 2's family).  `nruns` is the sketch on the variant with 0.5 % of the bases in N runs.
 
 Workloads (--workload; default c3 at N=1, c4 at N>1):
   c3   BASELINE configs[2], the configuration the metric is quoted on: 3 synthetic 3 Gbp genomes (24 contigs) at 1 %
@@ -70,6 +75,8 @@ def parse():
     ap.add_argument("--no-c4-leg", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="c2: one launch sequence per genome instead of one per step")
+    ap.add_argument("--no-nruns-leg", action="store_true")
+    ap.add_argument("--substitutions-only", action="store_true", help="genomes differ by substitutions only (round 2's family)")
     ap.add_argument("--e2e-dir", default=None, help="where the e2e leg writes its FASTA files [a temp dir]")
     return ap.parse_args()
 
@@ -190,38 +197,87 @@ def cpu_baseline(k, w, fpr, sample, bf_np, budget_s=24.0, graph_lists=None):
                       f"`value` = sketch on all {cores} cores the cgroup grants"}
 
 
-def write_fasta_from_device(g, path, chunk=1 << 28):
-    "resident genome -> single-line FASTA file (inputs of the e2e leg; not timed)"
+def family_genome(ctx, args, total_bp, contigs, j, rate, n_runs=False):
+    "genome j of the bench family, generated in HBM"
+    from ntsynt_amd import synth
+    from ntsynt_amd.device import Genome
+    if args.substitutions_only and not n_runs:
+        return Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + j, rate)
+    plan = synth.structural_plan(contigs, int(total_bp) // contigs, j, ANCESTOR_SEED, n_runs=n_runs,
+                                 **({"inversions": 0, "translocations": 0, "indels": 0, "micro": 0, "small_indels": 0}
+                                    if args.substitutions_only else {}))
+    return Genome.synth_plan(ctx, plan, ANCESTOR_SEED, 1000 + j, rate)
+
+
+def family_bases(args, n_fam, total_bp, contigs):
+    "bases of every genome of the family (the plans are cheap: no device work)"
+    from ntsynt_amd import synth
+    if args.substitutions_only:
+        return [int(total_bp) // contigs * contigs] * n_fam
+    return [int(synth.structural_plan(contigs, int(total_bp) // contigs, j, ANCESTOR_SEED)[0].sum()) for j in range(n_fam)]
+
+
+def write_fasta_from_device(g, path, chunk=1 << 28, soft_mask_seed=None):
+    """resident genome -> single-line FASTA file (inputs of the e2e leg; not timed).  soft_mask_seed: lower-case stretches
+    (10-20,000 bases, about one per 250 kbp) as in SURVEY.md 8(d)'s soft-masked variant -- the parse has to fold them"""
+    rng = np.random.default_rng(soft_mask_seed) if soft_mask_seed is not None else None
     with open(path, "wb") as fh:
         for r, name in enumerate(g.names):
             fh.write(b">" + name.encode() + b"\n")
             off, ln = int(g.rec_off[r]), int(g.rec_len[r])
             for s in range(0, ln, chunk):
-                fh.write(g.download(off + s, min(chunk, ln - s)).tobytes())
+                part = g.download(off + s, min(chunk, ln - s))
+                if rng is not None and part.size > 40000:
+                    for st in rng.integers(0, part.size - 20000, size=max(1, part.size // 250000)):
+                        part[st:st + int(rng.integers(10, 20000))] |= 0x20      # ('N' would become 'n': still invalid)
+                fh.write(part.tobytes())
             fh.write(b"\n")
 
 
-def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir):
-    """FASTA files on disk -> {prefix}.synteny_blocks.tsv through ntsynt_amd.pipeline.run with ntSynt's defaults for the
-    divergence (the second half of BASELINE's metric).  The files are written from genomes generated in HBM first (same
-    family as the sketch legs; not timed)."""
-    from ntsynt_amd import cli, pipeline
-    from ntsynt_amd.device import Context, Genome
-    divergence_pct = max(div * 100, 0.01)
-    t = time.time()
+ORACLE_RECORD = os.path.join(ROOT, "profiles", "r03_e2e_oracle.json")       # written by scripts/e2e_oracle_check.py
+
+
+def e2e_key(args, n_fam, total_bp, contigs, div):
+    "identity of an e2e family + parameter set (the oracle's recorded md5 applies to exactly this)"
+    return (f"{n_fam}x{total_bp}bp/{contigs}contigs/div{div:g}/k{args.k}/w{args.w}/fpr{args.fpr}/seed{ANCESTOR_SEED}/"
+            f"{'substitutions-only' if args.substitutions_only else 'structural+softmask'}")
+
+
+def e2e_inputs(args, device, n_fam, total_bp, contigs, div, workdir):
+    "the e2e leg's FASTA files, written from genomes generated in HBM (same family as the sketch legs)"
+    from ntsynt_amd.device import Context
     paths = []
     ctx = Context(device)
     for j in range(n_fam):
-        g = Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + j, div / 2.0)
+        g = family_genome(ctx, args, total_bp, contigs, j, div / 2.0)
         p = os.path.join(workdir, f"syn{j}.fa")
-        write_fasta_from_device(g, p)
+        write_fasta_from_device(g, p, soft_mask_seed=None if args.substitutions_only else 4000 + j)
         g.free()
         paths.append(p)
     ctx.close()
-    t_write = time.time() - t
+    return paths
+
+
+def e2e_params(args, paths, div):
+    "ntSynt's own defaults for the divergence (bin/ntSynt:89-99), resolved by the product's CLI code"
+    from ntsynt_amd import cli
+    divergence_pct = max(div * 100, 0.01)
     parser = cli.build_parser()
     a = parser.parse_args(paths + ["-d", f"{divergence_pct:g}", "-p", "e2e", "-k", str(args.k), "-w", str(args.w), "--fpr", str(args.fpr)])
     cli.resolve(parser, a)
+    return a, divergence_pct
+
+
+def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
+    """FASTA files on disk -> {prefix}.synteny_blocks.tsv through ntsynt_amd.pipeline.run with ntSynt's defaults for the
+    divergence (the second half of BASELINE's metric).  The files are written from genomes generated in HBM first (same
+    family as the sketch legs; not timed)."""
+    from ntsynt_amd import pipeline
+    t = time.time()
+    if paths is None:
+        paths = e2e_inputs(args, device, n_fam, total_bp, contigs, div, workdir)
+    t_write = time.time() - t
+    a, divergence_pct = e2e_params(args, paths, div)
     cwd = os.getcwd()
     os.chdir(workdir)
     try:
@@ -237,11 +293,25 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir):
         extra["engine_times_s"] = {n: round(v, 3) for n, v in sorted(eng.times.items(), key=lambda kv: -kv[1])}
     if getattr(eng, "stage_marks", None):
         extra["time_line_s"] = dict(eng.stage_marks)
+    md5 = hashlib.md5(tsv.encode()).hexdigest()
+    stages = {n: round(s, 3) for n, s in eng.stage_times}
+    # the oracle pipeline's output for this very family, recorded once on the GPU box's host cores (tens of minutes of CPU):
+    # scripts/e2e_oracle_check.py -> profiles/r03_e2e_oracle.json
+    oracle = {"oracle_md5": None, "oracle_checked": "no record for this family (scripts/e2e_oracle_check.py makes one)"}
+    try:
+        rec = json.load(open(ORACLE_RECORD))
+        if rec.get("key") == e2e_key(args, n_fam, total_bp, contigs, div):
+            oracle = {"oracle_md5": rec["oracle_md5"], "oracle_checked": "identical" if rec["oracle_md5"] == md5 else "DIFFERENT",
+                      "oracle_record": "profiles/r03_e2e_oracle.json"}
+    except (OSError, ValueError, KeyError):
+        pass
     return {**extra, "graph_stage": type(eng).__name__, "engine_stats": eng.stats,
             "what": f"{len(paths)} FASTA files on disk -> final synteny TSV (ntSynt -d {divergence_pct:g}: w_rounds {a.w_rounds}, "
                     f"indel {a.indel}, merge {a.merge}, block {a.block_size}), one GPU, files in the page cache",
-            "seconds": round(wall, 3), "stages_s": {n: round(s, 3) for n, s in eng.stage_times},
-            "blocks": len(tsv.splitlines()) // len(paths), "tsv_md5": hashlib.md5(tsv.encode()).hexdigest(),
+            "seconds": round(wall, 3), "stages_s": stages,
+            # the run ends when the 14.8 GB filter file is on disk: that artefact's share of the wall clock
+            "share_waiting_for_the_bf_file": round(stages.get("wait_for_files", 0.0) / wall, 3) if wall > 0 else None,
+            "blocks": len(tsv.splitlines()) // len(paths), "tsv_md5": md5, **oracle,
             "write_inputs_s": round(t_write, 1)}
 
 
@@ -306,14 +376,15 @@ def main():
     # ---- the family: genome g lives on rank g mod world ------------------------------------------------------
     mine = [g for g in range(n_fam) if g % world == rank]
     t0 = time.time()
-    genomes = [Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + g, div / 2.0) for g in mine]
+    genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in mine]
     t_synth = time.time() - t0
     bases = sum(g.total_bp for g in genomes)
+    fam_bases = family_bases(args, n_fam, total_bp, contigs)
     batch = name == "c2" and not args.no_batch and len(genomes) > 1 and world == 1
     units = [Genome.concat(ctx, genomes)] if batch else genomes
 
     # ---- common Bloom filter: per-genome filters, local AND, AND-all-reduce over the ranks (exchange 1) --------------
-    _, nbytes = bf_size_bytes(genomes[0].total_bp, args.fpr)        # every genome of the family has this size
+    _, nbytes = bf_size_bytes(fam_bases[0], args.fpr)               # sized by the first file of the family, on every rank (A1)
     ctx.profile(True)
     t0 = time.time()
     if torch_comm:
@@ -354,7 +425,7 @@ def main():
     # ---- cold leg: the first sketch of a genome nothing has been derived from yet ---------------------------------
     cold = None
     if world == 1 and not args.no_cold_leg:
-        fresh = Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + mine[0], div / 2.0)
+        fresh = family_genome(ctx, args, total_bp, contigs, mine[0], div / 2.0)
         ctx.sync()
         t1 = time.time()
         mx = sketch(ctx, fresh, k, w, common)
@@ -429,6 +500,27 @@ def main():
     def avg(n):
         return tm[n][0] / max(tm[n][1], 1)
 
+    nruns = None
+    if world == 1 and name == "c3" and not args.no_nruns_leg:
+        # SURVEY.md 8(d)'s N-run variant: 0.5 % of the bases in runs of 100-50,000 N -- the valid-k-mer path (run table, tiles that
+        # span runs) at full size, against the same common filter
+        g_n = family_genome(ctx, args, total_bp, contigs, mine[0], div / 2.0, n_runs=True)
+        for _ in range(2):
+            sketch(ctx, g_n, k, w, common).free()
+        ctx.sync()
+        t1 = time.time()
+        n_steps_n, n_mx_n = max(3, args.steps // 2), 0
+        for _ in range(n_steps_n):
+            mx = sketch(ctx, g_n, k, w, common)
+            n_mx_n = len(mx)
+            mx.free()
+        ctx.sync()
+        d_n = time.time() - t1
+        nruns = {"what": "genome 0 of the family with 0.5 % of its bases in N runs of 100-50,000 (SURVEY.md 8(d) variant), same filter",
+                 "value_Gbases_s": round(g_n.total_bp * n_steps_n / d_n / 1e9, 3), "ms_per_sketch": round(d_n / n_steps_n * 1e3, 3),
+                 "minimizers": n_mx_n, "bases": g_n.total_bp}
+        g_n.free()
+
     dense = None
     if args.mode != "dense" and not args.no_dense_leg and world == 1:
         ctx.sketch_mode("dense")
@@ -460,7 +552,7 @@ def main():
         # config 4's family on this one GPU: the N=1 point of the strong-scaling curve `--gpus N` measures
         for g in units:
             g.free()
-        fam = [Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + g, 0.10 / 2.0) for g in range(8)]
+        fam = [family_genome(ctx, args, total_bp, contigs, g, 0.10 / 2.0) for g in range(8)]
         c4 = BloomFilter(ctx, nbytes, k)
         c4.insert(fam[0])
         tmp = BloomFilter(ctx, nbytes, k)
@@ -483,16 +575,16 @@ def main():
         ctx.sync()
         d4 = time.time() - t1
         c4_n1 = {"workload": "8 synthetic 3000 Mbp genomes at 10% divergence on one GPU (bench.py --workload c4 --gpus 1)",
-                 "value_Gbases_s": round(8 * total_bp * 2 / d4 / 1e9, 3), "ms_per_step": round(d4 / 2 * 1e3, 2),
+                 "value_Gbases_s": round(sum(g.total_bp for g in fam) * 2 / d4 / 1e9, 3), "ms_per_step": round(d4 / 2 * 1e3, 2),
                  "common_filter_occupancy": c4.get_fpr(), "minimizers_per_step": n4}
         c4.free()
         for g in fam:
             g.free()
-        genomes = [Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + g, div / 2.0) for g in mine]
+        genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in mine]
 
     out = None
     if rank == 0:
-        value = bases_total(n_fam, genomes) * args.steps / dt / 1e9
+        value = sum(fam_bases) * args.steps / dt / 1e9
         pruned_run = tm["hash_select"][1] > 0
         if pruned_run:
             # (the library's rule: upper-halves kernel for k <= 32 while a 4096-index tile lists at most ~220 k-mers)
@@ -545,7 +637,10 @@ def main():
             "config": {"workload": f"{name}: {n_fam} synthetic {mbp:g} Mbp genomes ({contigs} contigs) at {div * 100:g}% divergence, "
                                    f"k={k} w={w} fpr={args.fpr}, genome g on GPU g mod {world}",
                        "sketch_mode": args.mode, "prune_c": c_used, "genomes_on_rank0": len(genomes), "exchanges": exchanges,
-                       "sketch_launch_sequences_per_step_rank0": len(units), "bases_per_step": bases_total(n_fam, genomes),
+                       "sketch_launch_sequences_per_step_rank0": len(units), "bases_per_step": sum(fam_bases),
+                       "family": "substitutions only" if args.substitutions_only else
+                                 "substitutions + per genome 5 inversions (1-5 Mbp), 2 inter-contig translocations, 20 indels (1-60 kbp), "
+                                 "60 small rearrangements (2-20 kbp moved / copied / inverted within 80 kbp), 200 indels of 1-50 bp",
                        "minimizers_per_step_rank0": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)",
                        "synth_s": round(t_synth, 3)},
             "roofline": {"bound": "hbm", "kernel": kern,
@@ -575,6 +670,8 @@ def main():
             out["roofline"]["traffic"] = pm
         if cold:
             out["cold"] = cold
+        if nruns:
+            out["nruns"] = nruns
         if c4_n1:
             out["c4_n1"] = c4_n1
     if world == 1:
@@ -610,11 +707,6 @@ def main():
         if comm is not None:
             comm.close()
         dist.destroy_process_group()
-
-
-def bases_total(n_fam, rank0_genomes):
-    "bases sketched per step by all ranks: every genome of the family has the size of rank 0's"
-    return n_fam * rank0_genomes[0].total_bp
 
 
 def pmc_traffic(name, pruned_run):

@@ -100,6 +100,22 @@ void nts_genome_free(nts_ctx* ctx, nts_genome* g);
  * read-back of a slice of any resident genome as upper-case ASCII (concatenated-sequence coordinates). */
 int nts_genome_synth(nts_ctx* ctx, uint64_t total_bp, uint32_t n_contigs, uint64_t seed_ancestor, uint64_t seed_genome,
                      double substitution_rate, nts_genome** out);
+/* The same family with structural events (inversions, translocations, indels, N runs, so that the block rules
+ * of bin/ntsynt_synteny.py:391-409 (indel split), :312-340 (erosion) and :434-472 (collinear merge) have work at full scale):
+ * the genome is given as a tiling of pieces in ascending `dst` order -- each a stretch [src, src + len) of the ancestor
+ * (coordinates of nts_genome_synth's concatenated ancestor), forwards or reverse-complemented, `len` bases of sequence of the
+ * genome's own (an insertion; `src` = offset in that stream), or a run of N -- cut into records of rec_len[r] bases.
+ * The plan is the caller's (ntsynt_amd/synth.py structural_plan); substitutions as in nts_genome_synth. */
+#define NTS_SYNTH_REVCOMP 1u
+#define NTS_SYNTH_NOVEL 2u
+#define NTS_SYNTH_NRUN 4u
+typedef struct
+{
+  uint64_t dst, len, src;
+  uint32_t flags, reserved;
+} nts_synth_piece;
+int nts_genome_synth_plan(nts_ctx* ctx, uint32_t n_rec, const uint64_t* rec_len, uint32_t n_pieces, const nts_synth_piece* pieces,
+                          uint64_t seed_ancestor, uint64_t seed_genome, double substitution_rate, nts_genome** out);
 int nts_genome_download(nts_ctx* ctx, const nts_genome* g, uint64_t offset, uint64_t len, uint8_t* ascii);
 /* total bases (sum of record lengths, what approximate_bf_size() counts) */
 uint64_t nts_genome_bases(const nts_genome* g);

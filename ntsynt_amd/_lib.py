@@ -64,6 +64,7 @@ SYMBOLS = [
     ("nts_bf_size_bytes_ex", ctypes.c_int, [u64, ctypes.c_double, ctypes.c_int, c_u64p, c_u64p]),
     ("nts_genome_upload", ctypes.c_int, [c_vp, c_vp, u64, c_u64p, c_u64p, u32, ctypes.POINTER(c_vp)]),
     ("nts_genome_synth", ctypes.c_int, [c_vp, u64, u32, u64, u64, ctypes.c_double, ctypes.POINTER(c_vp)]),
+    ("nts_genome_synth_plan", ctypes.c_int, [c_vp, u32, c_vp, u32, c_vp, u64, u64, ctypes.c_double, ctypes.POINTER(c_vp)]),
     ("nts_genome_download", ctypes.c_int, [c_vp, c_vp, u64, u64, c_vp]),
     ("nts_genome_concat", ctypes.c_int, [c_vp, u32, c_vp, ctypes.POINTER(c_vp)]),
     ("nts_genome_free", None, [c_vp, c_vp]),

@@ -1051,6 +1051,46 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ code, uint6
   }
 }
 
+// The same family with structural events: the genome is a tiling of pieces (ascending dst), each a stretch of the ancestor
+// read forwards or as its reverse complement, a stretch of sequence of the genome's own (an insertion), or a run of N.
+// Substitutions are keyed by the genome coordinate, as in k_synth.
+__global__ __launch_bounds__(256) void k_synth_plan(uint8_t* __restrict__ code, uint64_t n, const nts_synth_piece* __restrict__ pieces, uint32_t n_pieces,
+                                                    uint64_t seed_anc, uint64_t seed_gen, uint32_t thr)
+{
+  const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i0 >= n) return;
+  uint32_t lo = 0, hi = n_pieces; // the piece that holds i0
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (pieces[mid].dst <= i0)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  nts_synth_piece pc = pieces[lo];
+  for (int b = 0; b < 16; ++b) {
+    const uint64_t i = i0 + b;
+    if (i >= n) break;
+    while (i >= pc.dst + pc.len && lo + 1 < n_pieces) pc = pieces[++lo];
+    const uint64_t off = i - pc.dst;
+    const bool rev = pc.flags & NTS_SYNTH_REVCOMP;
+    const uint64_t sidx = rev ? pc.src + pc.len - 1 - off : pc.src + off;
+    uint32_t base;
+    if (pc.flags & NTS_SYNTH_NRUN)
+      base = CODE_INVALID;
+    else {
+      if (pc.flags & NTS_SYNTH_NOVEL)
+        base = (uint32_t)(mix64((seed_gen ^ 0x5bd1e995a7c3f1d7ULL) + sidx * 0x9E3779B97F4A7C15ULL) & 3u);
+      else
+        base = (uint32_t)(mix64(seed_anc + sidx * 0x9E3779B97F4A7C15ULL) & 3u);
+      if (rev) base = 3u - base;
+      const uint64_t y = mix64(seed_gen ^ (i * 0xD1B54A32D192ED03ULL));
+      if ((uint32_t)y < thr) base = (base + 1u + (uint32_t)((y >> 32) % 3u)) & 3u;
+    }
+    code[i] = (uint8_t)base;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ code, uint64_t n, uint8_t* __restrict__ ascii)
 {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1865,6 +1905,81 @@ int nts_genome_synth(nts_ctx* ctx, uint64_t total_bp, uint32_t n_contigs, uint64
     hipFree(g->d_rec_off);
     delete g;
     return fail(ctx, NTS_EHIP, std::string("nts_genome_synth: ") + hipGetErrorString(e));
+  }
+  *out = g;
+  return NTS_OK;
+}
+
+int nts_genome_synth_plan(nts_ctx* ctx, uint32_t n_rec, const uint64_t* rec_len, uint32_t n_pieces, const nts_synth_piece* pieces,
+                          uint64_t seed_ancestor, uint64_t seed_genome, double substitution_rate, nts_genome** out)
+{
+  if (!ctx || !out || !rec_len || !pieces || n_rec == 0 || n_pieces == 0 || substitution_rate < 0 || substitution_rate >= 1)
+    return fail(ctx, NTS_EINVAL, "nts_genome_synth_plan: bad arguments");
+  uint64_t n = 0;
+  for (uint32_t r = 0; r < n_rec; ++r) {
+    if (rec_len[r] == 0) return fail(ctx, NTS_EINVAL, "nts_genome_synth_plan: empty record");
+    n += rec_len[r];
+  }
+  uint64_t at = 0;
+  for (uint32_t p = 0; p < n_pieces; ++p) { // the pieces tile [0, n)
+    if (pieces[p].dst != at || pieces[p].len == 0) return fail(ctx, NTS_EINVAL, "nts_genome_synth_plan: the pieces do not tile the genome");
+    at += pieces[p].len;
+  }
+  if (at != n) return fail(ctx, NTS_EINVAL, "nts_genome_synth_plan: the pieces do not add up to the records");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  nts_genome* g = new nts_genome();
+  g->n = n;
+  g->n_rec = n_rec;
+  uint64_t off = 0;
+  for (uint32_t r = 0; r < n_rec; ++r) {
+    g->rec_off.push_back(off);
+    g->rec_len.push_back(rec_len[r]);
+    off += rec_len[r];
+  }
+  g->total_bases = n;
+  // maximal stretches of valid bases, clipped to records: the pieces that are not N runs, merged where they touch
+  {
+    uint32_t r = 0;
+    for (uint32_t p = 0; p < n_pieces; ++p) {
+      if (pieces[p].flags & NTS_SYNTH_NRUN) continue;
+      uint64_t a = pieces[p].dst;
+      const uint64_t b = a + pieces[p].len;
+      while (a < b) {
+        while (g->rec_off[r] + g->rec_len[r] <= a) ++r;
+        const uint64_t e = std::min(b, g->rec_off[r] + g->rec_len[r]);
+        if (!g->st_b.empty() && g->st_b.back() == a && a != g->rec_off[r])
+          g->st_b.back() = e;
+        else {
+          g->st_a.push_back(a);
+          g->st_b.push_back(e);
+        }
+        a = e;
+      }
+    }
+  }
+  nts_synth_piece* d_pieces = nullptr;
+  if (hipMalloc((void**)&g->d_code, PAD + n + PAD) != hipSuccess || hipMalloc((void**)&g->d_rec_off, (size_t)n_rec * 8) != hipSuccess ||
+      hipMalloc((void**)&d_pieces, (size_t)n_pieces * sizeof(nts_synth_piece)) != hipSuccess) {
+    hipFree(g->d_code);
+    hipFree(g->d_rec_off);
+    hipFree(d_pieces);
+    delete g;
+    return fail(ctx, NTS_ENOMEM, "nts_genome_synth_plan: hipMalloc");
+  }
+  hipMemsetAsync(g->d_code, CODE_INVALID, PAD, ctx->stream);
+  hipMemsetAsync(g->d_code + PAD + n, CODE_INVALID, PAD, ctx->stream);
+  hipMemcpyAsync(g->d_rec_off, g->rec_off.data(), (size_t)n_rec * 8, hipMemcpyHostToDevice, ctx->stream);
+  hipMemcpyAsync(d_pieces, pieces, (size_t)n_pieces * sizeof(nts_synth_piece), hipMemcpyHostToDevice, ctx->stream);
+  const uint32_t thr = (uint32_t)(substitution_rate * 4294967296.0);
+  hipLaunchKernelGGL(k_synth_plan, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_pieces, n_pieces, seed_ancestor,
+                     seed_genome, thr);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_pieces);
+  if (e != hipSuccess) {
+    hipFree(g->d_code);
+    hipFree(g->d_rec_off);
+    delete g;
+    return fail(ctx, NTS_EHIP, std::string("nts_genome_synth_plan: ") + hipGetErrorString(e));
   }
   *out = g;
   return NTS_OK;

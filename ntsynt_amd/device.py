@@ -157,6 +157,27 @@ class Genome:
         return g
 
     @classmethod
+    def synth_plan(cls, ctx, plan, seed_ancestor, seed_genome, substitution_rate):
+        """Synthetic genome with structural events generated in HBM (nts_genome_synth_plan): `plan` = (record lengths,
+        pieces) from ntsynt_amd.synth.structural_plan; relatives share seed_ancestor and the ancestor's layout."""
+        rec_len, pieces = plan
+        g = cls.__new__(cls)
+        g.ctx = ctx
+        rec_len = np.ascontiguousarray(rec_len, dtype=np.uint64)
+        pieces = np.ascontiguousarray(pieces)
+        assert pieces.dtype.itemsize == 32
+        g.names = [f"chr{i + 1}" for i in range(rec_len.size)]
+        g.rec_len = rec_len
+        g.rec_off = np.concatenate(([0], np.cumsum(rec_len[:-1]))).astype(np.uint64)
+        g.n_bytes = int(rec_len.sum())
+        h = c_vp()
+        ctx.check(ctx.lib.nts_genome_synth_plan(ctx.h, rec_len.size, rec_len.ctypes.data, pieces.size, pieces.ctypes.data,
+                                                int(seed_ancestor), int(seed_genome), float(substitution_rate), ctypes.byref(h)),
+                  "nts_genome_synth_plan")
+        g.h = h
+        return g
+
+    @classmethod
     def concat(cls, ctx, parts):
         """The batch of resident genomes `parts` as one resident genome (nts_genome_concat, a device-to-device copy):
         record ids of part p start at rec_base[p].  One sketch of the batch replaces one sketch per part --

@@ -155,3 +155,183 @@ def make_family(outdir, n_genomes, total_bp, n_contigs, divergence, seed=BASE_SE
         write_fasta(p, g, line_width=line_width)
         paths.append(p)
     return paths
+
+
+# ---- families generated in HBM (bench.py, scale tests): the plan of genome j's structural events ------------------------------
+# "a fixed small set of structural events per genome (e.g. 5 inversions of 1-5 Mbp, 2 inter-contig
+# translocations, 20 indels of 1-60 kbp) so that block breaks (ori_change, id_change, indel) are exercised", and a variant with
+# N runs (0.5 % of the bases in runs of 100-50,000).  The genome is described as a tiling of pieces of the ancestor
+# (include/ntsynt_hip.h nts_synth_piece); the bases themselves are generated on the device (nts_genome_synth_plan).
+PIECE_DTYPE = np.dtype([("dst", np.uint64), ("len", np.uint64), ("src", np.uint64), ("flags", np.uint32), ("reserved", np.uint32)])
+REVCOMP, NOVEL, NRUN = 1, 2, 4
+
+
+class _PieceTable:
+    "one contig as a list of [src, len, flags]"
+
+    def __init__(self, src, length):
+        self.p = [[int(src), int(length), 0]]
+
+    def size(self):
+        return sum(x[1] for x in self.p)
+
+    def split(self, pos):
+        "piece boundary at contig coordinate pos; returns the index of the piece that starts there"
+        at = 0
+        for i, (src, ln, fl) in enumerate(self.p):
+            if pos == at:
+                return i
+            if pos < at + ln:
+                cut = pos - at
+                if fl & REVCOMP:        # a reversed piece reads its source backwards: the head of the piece is the tail of the source
+                    first, second = [src + ln - cut, cut, fl], [src, ln - cut, fl]
+                else:
+                    first, second = [src, cut, fl], [src + cut, ln - cut, fl]
+                self.p[i:i + 1] = [first, second]
+                return i + 1
+            at += ln
+        assert pos == at
+        return len(self.p)
+
+    def cut(self, a, ln):
+        i0 = self.split(a)
+        i1 = self.split(a + ln)
+        out = self.p[i0:i1]
+        del self.p[i0:i1]
+        return out
+
+    def insert(self, a, pieces):
+        i = self.split(a)
+        self.p[i:i] = pieces
+
+    def invert(self, a, ln):
+        seg = self.cut(a, ln)
+        self.insert(a, [[s, n, f ^ REVCOMP] for s, n, f in reversed(seg)])
+
+
+def structural_plan(n_contigs, contig_bp, j, seed=BASE_SEED, inversions=5, translocations=2, indels=20, n_runs=False,
+                    indel_bp=None, micro=60, micro_bp=None, micro_shift=None, small_indels=200):
+    """(record lengths, pieces) of genome j of a family whose ancestor is n_contigs x contig_bp.  Sizes follow SURVEY.md 8(d) at
+    human scale (contigs of 125 Mbp) and shrink with the contigs below that; deterministic in (seed, j).
+
+    On top of SURVEY's list: `micro` small rearrangements (a segment of micro_bp bases moved or copied up to micro_shift bases
+    away, or inverted in place -- bubbles, short blocks, and neighbouring collinear blocks for the merge rule) and
+    `small_indels` of 1-50 bases (neighbouring minimizers that are adjacent in some assemblies only: light edges for the last
+    round's erosion)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919 * (j + 1)))
+    scale = min(1.0, contig_bp / 125e6)
+    tabs = [_PieceTable(c * contig_bp, contig_bp) for c in range(n_contigs)]
+    novel = 0
+    lo_i, hi_i = indel_bp or (max(30, int(1000 * scale)), max(120, int(60000 * scale)))
+    for _ in range(inversions):
+        t = tabs[int(rng.integers(0, n_contigs))]
+        ln = int(rng.uniform(1e6, 5e6) * scale)
+        if ln < 60 or t.size() < 6 * ln:
+            continue
+        t.invert(int(rng.integers(ln, t.size() - 2 * ln)), ln)
+    for _ in range(translocations if n_contigs >= 2 else 0):
+        a, b = (int(x) for x in rng.choice(n_contigs, size=2, replace=False))
+        ln = int(rng.uniform(0.5e6, 2e6) * scale)
+        if ln < 60 or tabs[a].size() < 6 * ln or tabs[b].size() < 6 * ln:
+            continue
+        seg = tabs[a].cut(int(rng.integers(ln, tabs[a].size() - 2 * ln)), ln)
+        tabs[b].insert(int(rng.integers(ln, tabs[b].size() - ln)), seg)
+    for _ in range(indels):
+        t = tabs[int(rng.integers(0, n_contigs))]
+        ln = int(rng.integers(lo_i, hi_i + 1))
+        if t.size() < 8 * ln:
+            continue
+        at = int(rng.integers(ln, t.size() - 2 * ln))
+        if rng.random() < 0.5:
+            t.cut(at, ln)
+        else:
+            t.insert(at, [[novel, ln, NOVEL]])
+            novel += ln
+    lo_m, hi_m = micro_bp or (max(40, int(2000 * scale)), max(80, int(20000 * scale)))
+    shift = micro_shift or max(200, int(80000 * scale))
+    for _ in range(micro):
+        t = tabs[int(rng.integers(0, n_contigs))]
+        ln = int(rng.integers(lo_m, hi_m + 1))
+        if t.size() < 4 * (ln + shift):
+            continue
+        st = int(rng.integers(ln + shift, t.size() - 2 * (ln + shift)))
+        kind = rng.random()
+        if kind < 0.4:                          # move
+            seg = t.cut(st, ln)
+            t.insert(st + int(rng.integers(-shift, shift + 1)), seg)
+        elif kind < 0.7:                        # copy
+            i0, i1 = t.split(st), t.split(st + ln)
+            seg = [list(x) for x in t.p[i0:i1]]
+            t.insert(st + int(rng.integers(-shift, shift + 1)), seg)
+        else:                                   # invert in place
+            t.invert(st, ln)
+    for _ in range(small_indels):
+        t = tabs[int(rng.integers(0, n_contigs))]
+        ln = int(rng.integers(1, 51))
+        at = int(rng.integers(1000, t.size() - 1000)) if t.size() > 4000 else 0
+        if not at:
+            continue
+        if rng.random() < 0.5:
+            t.cut(at, ln)
+        else:
+            t.insert(at, [[novel, ln, NOVEL]])
+            novel += ln
+    if n_runs:                                  # 0.5 % of the bases in runs of 100-50,000 (scaled)
+        for t in tabs:
+            budget = int(0.005 * t.size())
+            while budget > 0:
+                ln = int(min(budget, rng.integers(max(2, int(100 * scale)), max(3, int(50000 * scale)) + 1)))
+                if t.size() < 4 * ln:
+                    break
+                at = int(rng.integers(0, t.size() - ln))
+                t.cut(at, ln)
+                t.insert(at, [[0, ln, NRUN]])
+                budget -= ln
+    rec_len = np.array([t.size() for t in tabs], dtype=np.uint64)
+    rows = [x for t in tabs for x in t.p]
+    pieces = np.zeros(len(rows), dtype=PIECE_DTYPE)
+    pieces["src"] = [r[0] for r in rows]
+    pieces["len"] = [r[1] for r in rows]
+    pieces["flags"] = [r[2] for r in rows]
+    pieces["dst"] = np.concatenate(([0], np.cumsum(pieces["len"][:-1]))).astype(np.uint64)
+    return rec_len, pieces
+
+
+def _mix64(x):
+    "the device generator's mixer (csrc/ntsynt_hip.hip mix64) on uint64 arrays"
+    x = x.copy()
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xff51afd7ed558ccd)
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xc4ceb9fe1a85ec53)
+        x ^= x >> np.uint64(33)
+    return x
+
+
+def plan_bases(plan, seed_ancestor, seed_genome, substitution_rate):
+    """What nts_genome_synth_plan generates, evaluated with numpy (tests only: small plans): codes 0..3 = A, C, G, T, 4 = N."""
+    rec_len, pieces = plan
+    n = int(rec_len.sum())
+    out = np.empty(n, dtype=np.uint8)
+    thr = np.uint64(int(substitution_rate * 4294967296.0))
+    with np.errstate(over="ignore"):
+        for pc in pieces:
+            d, ln, src, fl = int(pc["dst"]), int(pc["len"]), int(pc["src"]), int(pc["flags"])
+            if fl & NRUN:
+                out[d:d + ln] = 4
+                continue
+            off = np.arange(ln, dtype=np.uint64)
+            sidx = (np.uint64(src + ln - 1) - off) if fl & REVCOMP else (np.uint64(src) + off)
+            if fl & NOVEL:
+                base = _mix64(np.uint64(seed_genome ^ 0x5bd1e995a7c3f1d7) + sidx * np.uint64(0x9E3779B97F4A7C15)) & np.uint64(3)
+            else:
+                base = _mix64(np.uint64(seed_ancestor) + sidx * np.uint64(0x9E3779B97F4A7C15)) & np.uint64(3)
+            if fl & REVCOMP:
+                base = np.uint64(3) - base
+            i = np.uint64(d) + off
+            y = _mix64(np.uint64(seed_genome) ^ (i * np.uint64(0xD1B54A32D192ED03)))
+            hit = (y & np.uint64(0xFFFFFFFF)) < thr
+            sub = (base + np.uint64(1) + (y >> np.uint64(32)) % np.uint64(3)) & np.uint64(3)
+            out[d:d + ln] = np.where(hit, sub, base).astype(np.uint8)
+    return out

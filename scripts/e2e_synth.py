@@ -24,6 +24,7 @@ def main():
     ap.add_argument("-w", type=int, default=1000)
     ap.add_argument("--fpr", type=float, default=0.025)
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--substitutions-only", action="store_true")
     args = ap.parse_args()
     import bench
     work = tempfile.mkdtemp(prefix="nts_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
