@@ -2871,6 +2871,8 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     S.tile_off = d_toff;
     S.tile_cnt = d_tcnt;
     S.tile_ordered = d_tord;
+    // k_hash_select_hi drops accepted k-mers that cannot be a window's minimum (NTS_SELECT_ELIM=0: keeps them all; same result)
+    S.w_elim = (getenv("NTS_SELECT_ELIM") && atoi(getenv("NTS_SELECT_ELIM")) == 0) ? 0u : w;
     if (accept_all) {
       AcceptParams A;
       A.code = S.code;

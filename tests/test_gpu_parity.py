@@ -475,6 +475,18 @@ def test_select_kernels_agree(ctx, monkeypatch, k, w, c, tpw):
                         assert np.array_equal(a, b.astype(a.dtype)), (impl, k, w, c, bf_o is not None)
                     cand, _, _ = ctx.sketch_stats()
                     assert cand > 0
+                    if impl == "hi":
+                        # the same without dropping the accepted k-mers that cannot be a window's minimum inside the select
+                        # kernel (NTS_SELECT_ELIM=0): same list, more candidates handed to the window kernel
+                        monkeypatch.setenv("NTS_SELECT_ELIM", "0")
+                        kept = sketch(ctx, d, k, w, bf_d).to_numpy()
+                        monkeypatch.delenv("NTS_SELECT_ELIM")
+                        for a, b2 in zip(kept, exp):
+                            assert np.array_equal(a, b2.astype(a.dtype)), ("no elimination", k, w, c)
+                        cand_all, _, _ = ctx.sketch_stats()
+                        assert cand <= cand_all
+                        if k <= 32 and w >= 400:
+                            assert cand < 0.8 * cand_all, (cand, cand_all)
     finally:
         ctx.sketch_select("auto")
         ctx.sketch_mode("auto", 0)
