@@ -2028,6 +2028,7 @@ static int bf_create_alloc(nts_ctx* ctx, uint64_t bytes, uint64_t alloc, nts_bf*
     delete bf;
     return fail(ctx, NTS_EHIP, "hipMemset bloom");
   }
+  bf->popcnt = 0;
   *out = bf;
   return NTS_OK;
 }
@@ -2115,6 +2116,7 @@ static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nt
 {
   if (!ctx || !next || !g || k == 0) return fail(ctx, NTS_EINVAL, "bloom pass: bad arguments");
   if (prev && prev->bytes != next->bytes) return fail(ctx, NTS_EINVAL, "bloom pass: filters differ in size");
+  const bool was_empty = next->popcnt == 0; // (a new or cleared filter)
   next->popcnt = -1;
   ++next->version;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2125,7 +2127,7 @@ static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nt
   if (prev) {
     rc = launch_hash<MODE_CASCADE>(ctx, "bf_cascade", g, *T, k, prev, next, nullptr);
   } else {
-    rc = ctx->bf_build_mode == 1 ? 1 : bf_insert_binned(ctx, next, g, *T, k, ctx->bf_build_mode == 2);
+    rc = ctx->bf_build_mode == 1 ? 1 : bf_insert_binned(ctx, next, g, *T, k, ctx->bf_build_mode == 2, was_empty);
     if (rc == 1) rc = launch_hash<MODE_INSERT>(ctx, "bf_insert", g, *T, k, nullptr, next, nullptr);
   }
   if (rc) return rc;

@@ -95,7 +95,7 @@ def test_bloom_insert_cascade_and(ctx, k):
 
 
 @pytest.mark.parametrize("nbytes", [3 << 20, 100 << 20])   # 24 final buckets (one partition level) / 800 (two levels)
-def test_bloom_binned_build_equals_atomic_and_oracle(ctx, nbytes):
+def test_bloom_binned_build_equals_atomic_and_oracle(ctx, nbytes, monkeypatch):
     """nts_bf_insert's partitioned build (hash -> bucket passes -> LDS bitmaps) sets the same bits as one atomic OR
     per k-mer and as the oracle: random records with N runs (tiles that cross run boundaries take the direct path),
     a repeat that piles 300k copies of a handful of k-mers into a few buckets (capacity overflow -> direct atomics),
@@ -112,19 +112,31 @@ def test_bloom_binned_build_equals_atomic_and_oracle(ctx, nbytes):
     want2 = want | O.bf_build(og2, k, nbytes)
     got = {}
     try:
-        for mode in ("atomic", "binned"):
-            ctx.bf_build_mode(mode)
+        # binned into an empty filter: bitmaps stored without reading the filter, indices that bypass the buckets parked in a list
+        # and set afterwards; "read+or": the same build made to read and OR (NTS_BIN_STORE=0); "list full": the parking list
+        # cut to 1000 entries, so that it runs over and the finish falls back to read-and-OR on the device's own say
+        for mode in ("atomic", "binned", "binned read+or", "binned list full"):
+            ctx.bf_build_mode(mode.split()[0])
+            monkeypatch.delenv("NTS_BIN_STORE", raising=False)
+            monkeypatch.delenv("NTS_BIN_LATE_CAP", raising=False)
+            if mode == "binned read+or":
+                monkeypatch.setenv("NTS_BIN_STORE", "0")
+            if mode == "binned list full":
+                monkeypatch.setenv("NTS_BIN_LATE_CAP", "1000")
             bf = BloomFilter(ctx, nbytes, k)
             bf.insert(dg)
             got[mode] = bf.to_numpy()
             assert bf.popcount() == int(np.unpackbits(want).sum())
             bf.insert(dg2)                       # OR into a non-empty filter
             assert np.array_equal(bf.to_numpy(), want2), mode
+            bf.clear()                           # a cleared filter counts as empty again
+            bf.insert(dg2)
+            assert np.array_equal(bf.to_numpy(), O.bf_build(og2, k, nbytes)), mode
             bf.free()
     finally:
         ctx.bf_build_mode("auto")
-    assert np.array_equal(got["atomic"], want)
-    assert np.array_equal(got["binned"], want)
+    for mode, bits in got.items():
+        assert np.array_equal(bits, want), mode
 
 
 
