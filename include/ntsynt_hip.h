@@ -474,8 +474,11 @@ int nts_fasta_read(const char* path, nts_fasta* out);
  * host) go to HBM through pinned staging, kernels find the header lines, drop line ends, compact and encode the bases into
  * a resident genome and produce the record table and the faidx columns; the host reads only the header lines.  `meta` as
  * nts_fasta_read fills it, except seq == NULL (the bases never exist on the host; nts_mx_kmers serves `--seq` output).
- * Same rules as nts_fasta_read; in addition a blank or tab inside a sequence line is NTS_EFORMAT instead of a base. */
+ * Same rules as nts_fasta_read (white space at either end of a sequence line is dropped, inside a line it is an invalid base).
+ * nts_ingest_trim: gives back what the ingest keeps between files -- the image of the largest file read so far (as large as
+ * that file, in HBM) and the pinned staging lanes -- once the last genome of a run is resident. */
 int nts_genome_from_fasta(nts_ctx* ctx, const char* path, nts_genome** out, nts_fasta* meta);
+int nts_ingest_trim(nts_ctx* ctx);
 /* nts_write_indexlr_tsv for records whose bases are not on the host (fa->seq == NULL): `kmers` = nts_mx_kmers' output, or
  * NULL without --seq */
 int nts_write_indexlr_tsv_kmers(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,

@@ -217,23 +217,26 @@ extern "C" int nts_fasta_read(const char* path, nts_fasta* out)
       in_record = true;
       first_line = true;
     } else if (in_record) {
-      size_t len = line_end - i;
-      size_t bases = len;
-      if (bases && data[i + bases - 1] == '\r') --bases;
+      const size_t len = line_end - i;
+      // white space at either end of the line goes (same rule as csrc/nts_fasta_dev.inc); carriage returns go wherever they are
+      auto blank = [](uint8_t c) { return c == ' ' || c == '\t' || c == '\v' || c == '\f' || c == '\r'; };
+      size_t a = i, b = line_end;
+      while (a < b && blank(data[a])) ++a;
+      while (b > a && blank(data[b - 1])) --b;
+      const size_t w0 = w;
+      if (memchr(data + a, '\r', b - a) == nullptr) {
+        memcpy(seq + w, data + a, b - a);
+        w += b - a;
+      } else {
+        for (size_t q = a; q < b; ++q)
+          if (data[q] != '\r') seq[w++] = data[q];
+      }
       if (first_line) {
         if (rec_len.size() && line_end > i) {
-          fai_bases.back() = (uint32_t)bases;
+          fai_bases.back() = (uint32_t)(w - w0);
           fai_width.back() = (uint32_t)(len + (nl ? 1 : 0));
         }
         first_line = false;
-      }
-      // sequence bytes: everything except CR (LF is already excluded)
-      if (memchr(data + i, '\r', len) == nullptr) {
-        memcpy(seq + w, data + i, len);
-        w += len;
-      } else {
-        for (size_t q = i; q < line_end; ++q)
-          if (data[q] != '\r') seq[w++] = data[q];
       }
     }
     i = nl ? line_end + 1 : n;

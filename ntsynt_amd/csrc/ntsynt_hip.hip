@@ -27,6 +27,7 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 

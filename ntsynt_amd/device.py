@@ -97,6 +97,10 @@ class Context:
                 # 4 SIMDs per CU, each issuing one wave-instruction per `cycles`: the clock the two figures imply
                 "implied_clock_GHz": round(per_cu * cyc.value / 4 / 1e9, 3)}
 
+    def trim_ingest(self):
+        "give back the FASTA ingest's workspaces (the raw image of the largest file, pinned staging): nts_ingest_trim"
+        self.check(self.lib.nts_ingest_trim(self.h), "nts_ingest_trim")
+
     def close(self):
         if self.h:
             self.lib.nts_destroy(self.h)

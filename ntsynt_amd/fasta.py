@@ -157,6 +157,14 @@ def read_fasta_numpy(path):
         fields = bytes(data[s + 1:e]).split()
         names.append(fields[0].decode() if fields else "")
     keep = (data != 10) & (data != 13)
+    # white space that runs up to the start or the end of its line goes (csrc/nts_fasta_dev.inc fa_is_base)
+    blank = np.isin(data, np.array([32, 9, 11, 12, 13], dtype=np.uint8))
+    pos = np.arange(n, dtype=np.int64)
+    nxt = np.minimum.accumulate(np.where(~blank, pos, n)[::-1])[::-1]            # next byte at or after i that is not blank
+    prv = np.maximum.accumulate(np.where(~blank, pos, -1))                        # last byte at or before i that is not blank
+    trailing = blank & ((nxt == n) | (data[np.minimum(nxt, n - 1)] == 10))
+    leading = blank & ((prv < 0) | (data[np.maximum(prv, 0)] == 10))
+    keep &= ~(trailing | leading)
     if gt.size == 0:
         keep[:] = False
     else:
@@ -174,9 +182,7 @@ def read_fasta_numpy(path):
         j = np.searchsorted(nl, s0)
         line_end = int(nl[j]) if j < nl.size and nl[j] < s1 else s1
         width = (line_end - s0 + 1) if (j < nl.size and nl[j] < s1) else (s1 - s0)
-        bases = line_end - s0
-        if bases > 0 and data[line_end - 1] == 13:
-            bases -= 1
+        bases = int(csum[line_end] - csum[s0])
         if ln == 0:
             bases = width = 0
         fai.append((name, int(ln), int(s0), int(bases), int(width)))

@@ -162,7 +162,7 @@ class GpuBackend:
         return out
 
     # below this many bases per assembly the fixed cost of a launch sequence shows: sketch the assemblies as one batch
-    BATCH_BELOW_BP = 1 << 30
+    BATCH_BELOW_BP = int(os.environ.get("NTS_BATCH_BELOW_BP", 1 << 30))     # (0: always one launch sequence per genome -- the path of 1 Gbp+ assemblies)
 
     def sketch_batch(self, genomes, k, w, bf, masks=None):
         """Sketches of several resident genomes with one sequence of launches (Genome.concat): the same lists as sketch()
@@ -420,6 +420,14 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         genomes.wait_all()
         meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine}
         st.mark("genomes_resident")
+        # the loaders are done: their contexts (the raw image of the largest file in HBM, pinned staging) go; the genomes belong
+        # to the run's context from here on
+        for p in mine:
+            genomes[p].ctx = backend.ctx
+        for c in load_ctxs:
+            c.close()
+    elif isinstance(backend, GpuBackend):
+        backend.ctx.trim_ingest()
 
     # The reference's experimental repeat filter (config "repeat": rules make_repeat_bf and indexlr -r, smk:65-85): k-mers seen
     # twice within a genome, excluded from the whole-genome sketches; the refinement rounds do not use it (ntsynt_run.py gets
@@ -548,8 +556,20 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     try:
         eng.run(first)
     except BaseException:
-        # a run that dies after its first round must not leave a plausible-looking block table behind
-        for name in (f"{out_prefix}.synteny_blocks.tsv", f"{out_prefix}.pre-collinear-merge.synteny_blocks.tsv"):
+        # a run that dies after its first round must not leave a plausible-looking block table behind -- nor a filter file or
+        # minimizer TSVs cut short: the writers still stream from `bf` and the lists, so they are waited for before anything
+        # they read is freed (by the unwinding), and what they wrote goes
+        for f in pending_files:
+            try:
+                f.result()
+            except Exception:                                   # noqa: BLE001 -- the run is failing already
+                pass
+        writers.shutdown()
+        doomed = [f"{out_prefix}.synteny_blocks.tsv", f"{out_prefix}.pre-collinear-merge.synteny_blocks.tsv"]
+        if rank == 0 and bf is not None:
+            doomed.append(f"{prefix}.common.bf")
+        doomed += [tsv_names[i] for i, p in enumerate(fastas) if owner[p] == rank and write_mx_tsv]
+        for name in doomed:
             if os.path.exists(name):
                 os.remove(name)
         raise

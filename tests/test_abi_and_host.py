@@ -79,7 +79,9 @@ def test_fasta_reader_matches_oracle_reader(tmp_path):
 def test_native_fasta_edge_cases(tmp_path):
     from ntsynt_amd import fasta as fa
     cases = [b"", b"\n \n", b">only\n", b">a\nAC\n\nGT\n>b x y\n", b"junk\n>a\tdesc\r\nAC\r\nG\r\n>b\r\n\r\nT",
-             b">a\nACGT"]
+             b">a\nACGT",
+             # white space at the ends of sequence lines goes, inside a line it stays (an invalid base)
+             b">a desc\nACGT  \nAC\t\n \tGGT\r\nTT AC\n\x0c\n>b\n   \nACGTACGT \t \r\nAC\tGT\n>c\nAAAA   "]
     for i, raw in enumerate(cases):
         p = tmp_path / f"c{i}.fa"
         p.write_bytes(raw)
@@ -87,6 +89,10 @@ def test_native_fasta_edge_cases(tmp_path):
         assert a.names == c.names, raw
         assert a.rec_len.tolist() == c.rec_len.tolist(), raw
         assert bytes(a.seq) == bytes(c.seq), raw
+        assert a.fai_rows == c.fai_rows, raw
+        if raw.startswith(b">a desc"):
+            from oracle import nts_oracle as O
+            assert bytes(a.seq) == b"ACGTACGGTTT ACACGTACGTAC\tGTAAAA" == O.read_fasta(str(p)).blob
     # not FASTA: FASTQ, or text without a single header -> a dedicated error instead of an empty assembly
     for i, raw in enumerate([b"@r1\nACGT\n+\nIIII\n", b"no header at all\nACGT\n"]):
         p = tmp_path / f"bad{i}.fq"

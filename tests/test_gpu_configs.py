@@ -306,11 +306,16 @@ def test_sparse_filter_summary_path_matches_oracle(ctx, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------------ C5
-def test_c5_parameter_set_at_100mbp_files_to_tsv(tmp_path):
+@pytest.mark.parametrize("mbp,per_genome", [(100, False), (40, True)])
+def test_c5_parameter_set_at_100mbp_files_to_tsv(tmp_path, monkeypatch, mbp, per_genome):
     """`ntSynt -d 1.3` resolves to w_rounds 250 100, indel 50000, merge 100000, block 1000 (bin/ntSynt:92-94): that
-    parameter set on 3 x 100 Mbp FASTA files, end to end, against the oracle pipeline."""
+    parameter set on 3 x 100 Mbp FASTA files, end to end, against the oracle pipeline.  per_genome: the batch sketch switched
+    off (GpuBackend.BATCH_BELOW_BP = 0), i.e. one launch sequence per genome and refinement round and the lists taken apart
+    nowhere -- the path every assembly of 1 Gbp and more takes (at full size: scripts/e2e_oracle_check.py,
+    profiles/r03_e2e_oracle.json)."""
     from ntsynt_amd import cli, pipeline, synth
-    paths = synth.make_family(str(tmp_path), 3, 100_000_000, 6, 0.013, seed=77, micro=12)
+    monkeypatch.setattr(pipeline.GpuBackend, "BATCH_BELOW_BP", 0 if per_genome else 1 << 30)
+    paths = synth.make_family(str(tmp_path), 3, mbp * 1_000_000, 6, 0.013, seed=77, micro=12)
     parser = cli.build_parser()
     a = parser.parse_args(paths + ["-d", "1.3", "-p", "c5"])
     cli.resolve(parser, a)

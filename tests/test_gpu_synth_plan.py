@@ -60,12 +60,15 @@ def test_rejects_a_plan_that_does_not_tile(ctx):
         Genome.synth_plan(ctx, (rec_len, bad), 5, 6, 0.01)
 
 
-def test_pipeline_on_a_structural_family_matches_the_oracle(ctx, tmp_path):
+@pytest.mark.parametrize("erode_on_host", [False, True])
+def test_pipeline_on_a_structural_family_matches_the_oracle(ctx, tmp_path, monkeypatch, erode_on_host):
     """three genomes with inversions, translocations, indels and soft-masked stretches, written to FASTA from HBM like
     bench.py's e2e leg does; both synteny TSVs byte-identical to the oracle pipeline's, and the rules have fired"""
     import bench
     from ntsynt_amd import pipeline
     from ntsynt_amd.device import Genome
+    if erode_on_host:       # every erosion walk through nts_engine_erode's host path (the one for walks over branching vertices)
+        monkeypatch.setenv("NTS_ERODE_HOST", "1")
     paths = []
     for j in range(3):
         plan = synth.structural_plan(4, 1_500_000, j, seed=31, inversions=3, translocations=1, indels=10, indel_bp=(100, 3000),
