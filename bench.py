@@ -115,34 +115,76 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_graph_stage(k, w, lists):
-    """The reference's stage 3, initial round (load_minimizers -> make_minimizer_graph -> simplification -> filter -> find_paths ->
-    synteny blocks -> TSV text; bin/ntsynt_synteny.py:593-647) as the oracle restates it -- single-threaded Python like the
-    reference's -- on the minimizers of the first contig of every genome (sketched on the GPU beforehand)."""
+def cpu_e2e_sample(k, w, fpr, slices, params, threads):
+    """The oracle pipeline end to end on a bounded sample (size pass, Bloom build, sketch, graph stage, refinement
+    rounds, each timed, inputs in memory-backed files): the first bases of every genome of the family, one FASTA record each, with
+    the parameters the product's e2e leg runs with.  Sketch and Bloom build on `threads` threads, the graph stage single-threaded
+    Python like the reference's."""
+    from oracle import nts_oracle as O
     from oracle import synteny_oracle as SO
-    tables = {}
-    n_mx = 0
-    for j, (h1, pos) in enumerate(lists):
-        recs = [("chr1", [(str(h), int(p)) for h, p in zip(h1.tolist(), pos.tolist())])]
-        tables[f"syn{j}.fa.k{k}.w{w}.tsv"] = SO.mx_tables_from_tokens(recs)
-        n_mx += len(h1)
     cwd = os.getcwd()
-    tmp = tempfile.mkdtemp(prefix="nts_cpu_graph_")
-    os.chdir(tmp)
+    tmp = tempfile.mkdtemp(prefix="nts_cpu_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    t = {}
     try:
-        t = time.time()
-        eng = SO.SyntenyOracle(list(tables), {}, k, w, [], 50000, 100000, 1000, "cpu")
+        paths = []
+        for j, a in enumerate(slices):
+            p = os.path.join(tmp, f"syn{j}.fa")
+            with open(p, "wb") as fh:              # six records: the reference parallelises over records (cpp:128,145; indexlr -t)
+                per = (a.size + 5) // 6
+                for r in range(6):
+                    fh.write(b">chr%d\n" % (r + 1))
+                    fh.write(a[r * per:(r + 1) * per].tobytes())
+                    fh.write(b"\n")
+            paths.append(p)
+        os.chdir(tmp)
+        t0 = time.time()
+        first_bp = O.read_fasta(sorted(paths)[0]).total_bp                 # approximate_bf_size's own pass over the first file
+        t["size_pass"] = time.time() - t0
+        t0 = time.time()
+        genomes = {p: O.read_fasta(p) for p in paths}
+        t["read_fasta"] = time.time() - t0
+        t0 = time.time()
+        bf = O.common_bf(genomes, k, fpr, threads)
+        t["make_common_bf"] = time.time() - t0
+        t0 = time.time()
+        tables, by_tsv = {}, {}
+        n_mx = 0
+        for p in paths:
+            tsv = f"{os.path.basename(p)}.k{k}.w{w}.tsv"
+            mins = O.minimize(genomes[p], k, w, bf, threads)
+            n_mx += sum(len(m[0]) for m in mins)
+            tables[tsv] = SO.mx_tables_from_tokens(SO.mx_records_from_arrays(genomes[p].names, mins))
+            by_tsv[tsv] = genomes[p]
+        t["indexlr"] = time.time() - t0
+        eng = SO.SyntenyOracle(list(tables), by_tsv, k, w, params["w_rounds"], params["indel"], params["merge"], params["block_size"], "cpu",
+                               bf=bf, threads=threads)
         eng.load(tables)
+        inner = eng.refine
+        spent = {}
+
+        def timed_refine(blocks):
+            t1 = time.time()
+            out = inner(blocks)
+            spent["refine"] = time.time() - t1
+            return out
+        eng.refine = timed_refine
+        t0 = time.time()
         eng.main()
-        dt = time.time() - t
+        t["ntsynt_synteny"] = time.time() - t0
+        t["of_which_refinement_rounds"] = spent.get("refine", 0.0)
+        blocks = len(eng.outputs["cpu.synteny_blocks.tsv"].splitlines()) // len(paths)
     finally:
         os.chdir(cwd)
         shutil.rmtree(tmp, ignore_errors=True)
-    return {"seconds": round(dt, 2), "minimizers": n_mx, "minimizers_per_s": round(n_mx / dt), "threads": 1,
-            "what": "initial round of the graph stage on the first contig of every genome (no refinement rounds)"}
+    total = sum(v for n, v in t.items() if n != "of_which_refinement_rounds")
+    bases = sum(int(a.size) for a in slices)
+    return {"what": f"oracle pipeline on the first {slices[0].size / 1e6:.0f} Mbp of each of the {len(slices)} genomes (cut into six records each), "
+                    f"ntSynt's parameters of the e2e leg, {threads} threads for Bloom build and sketch, graph stage single-threaded",
+            "first_file_bp": int(first_bp), "seconds": round(total, 2), "stages_s": {n: round(v, 3) for n, v in t.items()},
+            "Gbases_s_end_to_end": round(bases / total / 1e9, 4), "minimizers": n_mx, "blocks": blocks}
 
 
-def cpu_baseline(k, w, fpr, sample, bf_np, budget_s=24.0, graph_lists=None):
+def cpu_baseline(k, w, fpr, sample, bf_np, budget_s=20.0, e2e_slices=None, e2e_par=None):
     """The CPU oracle (a port of btllib's algorithm class: rolling ntHash, ring-buffer window minimum, byte-atomic Bloom
     insert, one probe per k-mer) on this box's host cores, per stage: Bloom build and sketch, each at the
     reference's default parallelism -- make_common_bf with 12 threads (bin/ntSynt:59), indexlr 5 threads x 2 genomes at
@@ -186,8 +228,14 @@ def cpu_baseline(k, w, fpr, sample, bf_np, budget_s=24.0, graph_lists=None):
             "sketch_Gbases_s": round(rate(lambda: O.minimize(g_sk, k, w, bf_np, threads=thr_sk, native=native), g_sk, slot), 4),
             "sketch_threads": thr_sk,
         }
-    if graph_lists:
-        stages["graph_stage"] = cpu_graph_stage(k, w, graph_lists)
+    if e2e_slices:
+        stages["end_to_end_sample"] = cpu_e2e_sample(k, w, fpr, e2e_slices, e2e_par, cores)
+        try:                                   # and the one full-size run on record (scripts/e2e_oracle_check.py)
+            rec = json.load(open(ORACLE_RECORD))
+            stages["end_to_end_full_size_on_record"] = {"seconds": rec["oracle_seconds"], "threads": rec["oracle_threads"], "key": rec["key"],
+                                                        "source": "profiles/r03_e2e_oracle.json"}
+        except (OSError, ValueError, KeyError):
+            pass
     return {"value": stages["all_cores"]["sketch_Gbases_s"], "unit": "Gbases/s", "cores": cores, "kind": "port",
             "cpu_model": cpu_model(), "logical_cpus_visible": os.cpu_count(), "stages": stages,
             "sample": f"first {sample.size / 1e6:.0f} Mbp of genome 0 read back from HBM, cut into 4 records per thread "
@@ -543,7 +591,8 @@ def main():
     valu = None
     if world == 1:
         # VALU roof of the issue-bound kernel: measured issue rate of its instruction mix's slowest member (nts_bench_valu)
-        rows = {kind: ctx.bench_valu(kind, 8, 20000) for kind in ("v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64", "roll31 step (9 instructions)")}
+        rows = {kind: ctx.bench_valu(kind, 8, 20000) for kind in ("v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64", "v_add3_u32",
+                                                                  "v_cmp_ge_u32+v_addc_co_u32", "roll31 step (9 instructions)")}
         valu = {"wave_instr_per_s_per_cu": {n: round(r["wave_instr_per_s_per_cu"] / 1e9, 3) for n, r in rows.items()},
                 "unit": "G wave-instructions/s/CU", "how": "nts_bench_valu: 8 waves per SIMD, eight independent chains per lane, wall clock"}
 
@@ -606,21 +655,33 @@ def main():
             # the microbenchmark measures for the classes of the kernel's instruction mix
             key = "k_hash_select_hi" if hi_kernel else "k_hash_select"
             per_64 = 17.2 if hi_kernel else 29.8
-            try:
-                sq = json.load(open(os.path.join(ROOT, "profiles", "r02_sq_counters.json")))
-                per_64 = float(sq["kernels"][key]["valu_wave_instructions_per_64_kmers"])
-            except (OSError, KeyError, ValueError):
-                pass
+            for rnd in (3, 2):
+                try:
+                    sq = json.load(open(os.path.join(ROOT, "profiles", f"r0{rnd}_sq_counters.json")))
+                    per_64 = float(sq["kernels"][key]["valu_wave_instructions_per_64_kmers"])
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
             n_cu = 256
             ach_v = per_64 * per_launch_bases / 64.0 / (a_ms * 1e-3) / n_cu / 1e9
             rate = valu["wave_instr_per_s_per_cu"]
             fast, slow = rate["v_xor_b32"], min(rate["v_alignbit_b32"], rate["v_lshl_add_u64"])
-            if hi_kernel:
+            mix_file = os.path.join(ROOT, "profiles", "r03_valu_mix.json")
+            if hi_kernel and os.path.exists(mix_file):
+                # the mix counted from the kernel's ISA (profiles/valu_mix.py: one turn of the tile loop, straight-line code), each
+                # class priced at its measured issue rate; what the PMC count holds beyond that range at the mix's average
+                mx = json.load(open(mix_file))["classes"]
+                n2, n3, nc = mx["two-operand 32-bit"], mx["three-operand or 64-bit"], mx["compare / carry"]
+                pair = rate["v_cmp_ge_u32+v_addc_co_u32"]
+                peak_v = (n2 + n3 + nc) / (n2 / fast + n3 / min(slow, rate["v_add3_u32"]) + nc / pair)
+                mix = (f"counted from the ISA (profiles/r03_valu_mix.json): {n2} two-operand 32-bit, {n3} three-operand or 64-bit, "
+                       f"{nc} compare / carry instructions per tile of 4096 k-mers, each class at its measured rate")
+            elif hi_kernel:
                 # per k-mer: the 9-instruction rolling step (measured as a unit) + 2 two-operand instructions for the table offset;
                 # the rest (listing, full hashes of the listed k-mers, probes, output: per_64 - 11 per k-mer) priced half and half
                 rest = max(per_64 - 11.0, 0.0)
                 peak_v = per_64 / (9.0 / rate["roll31 step (9 instructions)"] + 2.0 / fast + rest * 0.5 / fast + rest * 0.5 / slow)
-                mix = "9 (rolling step, measured as a unit) + 2 two-operand + the rest half two-operand, half three-operand"
+                mix = "assumed: 9 (rolling step, measured as a unit) + 2 two-operand + the rest half two-operand, half three-operand"
             else:
                 # the rolling step is ~12 two-operand 32-bit operations (xor / and / shift class) and ~17 three-operand or 64-bit ones
                 # (alignbit, bfi, lshl_add_u64 class): the roof of that mix
@@ -665,9 +726,15 @@ def main():
                       if ins_ms > 0 else None,
                       "occupancy_one_genome": round(occ_single, 6), "occupancy_common": occ_common},
         }
-        pm = pmc_traffic(name, pruned_run)
+        pm = pmc_traffic(name, pruned_run, bpb * per_launch_bases,
+                         (0.25 + L2_LINE * probe_frac + 16.0 * cand / per_launch_bases) * per_launch_bases if pruned_run else None)
         if pm:
             out["roofline"]["traffic"] = pm
+            # the same launch priced at what it really moves (a probe = one 128-byte line)
+            out["roofline"]["achieved_at_128B_per_probe"] = {
+                "GBs": round(pm["bytes_per_launch"] / (a_ms * 1e-3) / 1e9, 1) if a_ms > 0 else None,
+                "frac": round(pm["bytes_per_launch"] / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if a_ms > 0 else None,
+                "what": "corrected PMC bytes per launch / this run's average launch duration"}
         if cold:
             out["cold"] = cold
         if nruns:
@@ -676,16 +743,14 @@ def main():
             out["c4_n1"] = c4_n1
     if world == 1:
         sample = bf_np = None
-        graph_lists = None
+        e2e_slices = e2e_par = None
         if not args.no_cpu_baseline:
             sample = genomes[0].download(0, min(genomes[0].total_bp, 100_000_000))
             bf_np = common.to_numpy()
-            graph_lists = []
-            for g in genomes:                                         # minimizers of every genome's first contig, for the CPU graph stage
-                mx = sketch(ctx, g, k, w, common)
-                h1, rec, pos = mx.to_numpy()
-                mx.free()
-                graph_lists.append((h1[rec == 0], pos[rec == 0]))
+            # the first 30 Mbp of every genome: the oracle pipeline's end-to-end sample
+            e2e_slices = [g.download(0, min(int(g.rec_len[0]), 30_000_000)) for g in genomes]
+            pa, _ = e2e_params(args, [f"syn{j}.fa" for j in range(len(genomes))], div)
+            e2e_par = {"w_rounds": pa.w_rounds, "indel": pa.indel, "merge": pa.merge, "block_size": pa.block_size}
         if not args.no_e2e:
             for g in genomes:                                        # everything of the sketch legs goes, the pipeline
                 g.free()                                             # starts from files like a user's run
@@ -699,7 +764,7 @@ def main():
                 if not args.e2e_dir:
                     shutil.rmtree(workdir, ignore_errors=True)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(k, w, args.fpr, sample, bf_np, graph_lists=graph_lists)
+            out["cpu_baseline"] = cpu_baseline(k, w, args.fpr, sample, bf_np, e2e_slices=e2e_slices, e2e_par=e2e_par)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -709,18 +774,30 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(name, pruned_run):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_pmc_traffic.json: rocprofv3
-    --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if name != "c3" or not os.path.exists(path):
+def pmc_traffic(name, pruned_run, algorithmic_bytes=None, line_bytes=None):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/rNN_pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command), corrected as MI355X_MICROARCH.md's HBM
+    section prescribes for gfx950: FETCH_SIZE tallies every 128-byte request at 64 B, so it is doubled (the probes of this
+    kernel are 128-byte requests one and all: profiles/r02_probe_granularity.md; so are its 16-byte-per-lane LDS-DMA reads of
+    the base words); WRITE_SIZE is taken as it is (uncalibrated in the guide)."""
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (3, 2)) if os.path.exists(q)), None)
+    if name != "c3" or path is None:
         return None
     kernels = json.load(open(path))["kernels"]
     k = (kernels.get("k_hash_select_hi") or kernels.get("k_hash_select")) if pruned_run else kernels.get("k_hash<0>")
     if not k:
         return None
-    raw = (k["fetch_MB_per_launch_max"] + k["write_MB_per_launch_max"]) * 1024 * 1024
-    return {"bytes_per_launch": int(raw), "raw_fetch_plus_write_bytes": int(raw), "source": "profiles/r02_pmc_traffic.json"}
+    fetch = k["fetch_MB_per_launch_max"] * 1024 * 1024
+    write = k["write_MB_per_launch_max"] * 1024 * 1024
+    out = {"bytes_per_launch": int(2 * fetch + write), "raw_fetch_size_bytes": int(fetch), "raw_write_size_bytes": int(write),
+           "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 128-byte requests at 64 B)",
+           "source": os.path.relpath(path, ROOT)}
+    if algorithmic_bytes:
+        out["ratio_to_algorithmic_bytes_at_64B_per_probe"] = round(out["bytes_per_launch"] / algorithmic_bytes, 2)
+    if line_bytes:
+        out["algorithmic_bytes_at_128B_per_probe"] = int(line_bytes)
+        out["ratio_to_algorithmic_bytes_at_128B_per_probe"] = round(out["bytes_per_launch"] / line_bytes, 2)
+    return out
 
 
 if __name__ == "__main__":

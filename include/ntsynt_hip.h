@@ -230,11 +230,11 @@ int nts_sketch(nts_ctx* ctx,
    absent from `filter`; either may be NULL.  With a filter-out filter the call takes the every-k-mer-probed kernels. */
 int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const nts_bf* filter, const nts_bf* filter_out,
                   const nts_interval* mask, uint64_t n_mask, nts_mx** out);
-/* Sketch policy.  mode 0 = auto (pruned when w >= 200 and c = 12 / accepted share stays below w/4, below 0.15 w for w < 512),
+/* Sketch policy.  mode 0 = auto (pruned when w >= 200 and c = 10.5 / accepted share stays below w/4, below 0.15 w for w < 512),
  * 1 = dense (probe the filter for every k-mer), 2 = pruned: only k-mers whose hash is <= (c / w) * 2^64 are probed;
  * windows holding no accepted candidate are re-evaluated densely, so the result is identical
  * (ntsynt_amd/csrc/nts_pruned.inc).  prune_c = 0: c is chosen per call from the filter's occupancy
- * (c = 12 / accepted share, at least 8); otherwise c = prune_c. */
+ * (c = 10.5 / accepted share, at least 8: DESIGN.md 4.1); otherwise c = prune_c. */
 int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c);
 /* Dense sketch over a sparse filter (many divergent genomes: nearly no k-mer is common to all): when occupancy x 2^shift is
  * small, a summary of the filter with one bit per 2^shift filter bits (<= 1 MiB, L2-resident; built once per filter state) is

@@ -16,7 +16,8 @@ import json
 import re
 import sys
 
-KEEP = ["k_hash_select", "k_hash_select_hi", "k_sparse_win", "k_cand_compact", "k_bin1", "k_bin2", "k_bin3", "k_hash<0>", "k_window_min"]
+KEEP = ["k_hash_select", "k_hash_select_hi", "k_sparse_win", "k_cand_compact", "k_cand_compact_slots", "k_bin1", "k_bin2", "k_bin3", "k_hash<0>", "k_window_min",
+        "k_hash_accept4r", "k_hash_accept4", "k_hash_accept"]
 import os
 
 # k-mers per launch: NTS_PROF_KMERS for the bench command's genomes (round 2: 3 Gbp genomes, one launch sequence each);
@@ -47,9 +48,11 @@ def main():
                     e[c] = v
                     if c == "SQ_INSTS_VALU":
                         dur[k] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    what = os.environ.get("NTS_PROF_WORKLOAD") or (
+        "one 3 Gbp genome per launch (bench.py's default family)" if "NTS_PROF_KMERS" in os.environ
+        else "sketch kernels: the batch of three 100 Mbp genomes; k_bin*: one genome")
     res = {"workload": "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dense-leg under rocprofv3 --pmc "
-                       "(three passes); largest launch of each kernel (sketch kernels: the batch of three 100 Mbp genomes; "
-                       "k_bin*: one genome)", "kernels": {}}
+                       f"(three passes); largest launch of each kernel ({what}); k-mers per launch taken as {BATCH_KMERS:.0f}", "kernels": {}}
     for k in KEEP:
         if k not in out:
             continue

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof
 mkdir -p $O
-LEGS="--no-cpu-baseline --no-e2e --no-c4-leg --no-cold-leg"
+LEGS="--no-cpu-baseline --no-e2e --no-c4-leg --no-cold-leg --no-nruns-leg"
 B1="python bench.py --steps 1 --warmup 0 $LEGS --no-dense-leg"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --steps 5 --warmup 2 $LEGS > $O/stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 1 --warmup 0 $LEGS > $O/pf.log 2>&1
@@ -15,13 +15,22 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_sq1 -o s -- $B1 > $O/sq1.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_sq2 -o s -- $B1 > $O/sq2.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/pmc_sq3 -o s -- $B1 > $O/sq3.log 2>&1
-NTS_PROF_KMERS=2999999448 python profiles/sq_summarize.py $O/pmc_sq1 $O/pmc_sq2 $O/pmc_sq3 > $O/sq_counters.json
+NTS_PROF_KMERS=3000000000 python profiles/sq_summarize.py $O/pmc_sq1 $O/pmc_sq2 $O/pmc_sq3 > $O/sq_counters.json
 F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
 python profiles/pmc_summarize.py "$F" "$W" $O/pmc_traffic "python bench.py --steps 1 --warmup 0 $LEGS (3 x 3 Gbp, one launch sequence per genome; pruned step + dense leg + Bloom build)"
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_c3.csv
 python profiles/summarize.py $O/kernel_stats_c3.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 $LEGS (3 x 3 Gbp)" > $O/kernel_stats_c3.md
-# config 4 on one GPU (8 x 3 Gbp at 10 %: summary-first dense pass)
+# config 4 on one GPU (8 x 3 Gbp at 10 %: accepted-list path), kernel stats + SQ counters and traffic of its select kernel
+C4="python bench.py --workload c4 --steps 1 --warmup 0 $LEGS --no-dense-leg"
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c4_sq1 -o s -- $C4 > $O/c4sq1.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/c4_sq2 -o s -- $C4 > $O/c4sq2.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/c4_sq3 -o s -- $C4 > $O/c4sq3.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/c4_f -o f -- $C4 > $O/c4f.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/c4_w -o w -- $C4 > $O/c4w.log 2>&1
+NTS_PROF_KMERS=3000000000 NTS_PROF_WORKLOAD="config 4 on one GPU: 8 x 3 Gbp at 10 %, one genome per launch" python profiles/sq_summarize.py $O/c4_sq1 $O/c4_sq2 $O/c4_sq3 > $O/c4_sq_counters.json
+python profiles/pmc_summarize.py "$(find $O/c4_f -name '*counter_collection.csv' | head -1)" "$(find $O/c4_w -name '*counter_collection.csv' | head -1)" $O/c4_pmc_traffic "$C4 (8 x 3 Gbp at 10 % on one GPU)"
+rm -rf $O/c4_sq1 $O/c4_sq2 $O/c4_sq3 $O/c4_f $O/c4_w
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats4 -o s -- python bench.py --workload c4 --steps 2 --warmup 1 $LEGS --no-dense-leg > $O/stats4.log 2>&1
 find $O/stats4 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_c4.csv
 python profiles/summarize.py $O/kernel_stats_c4.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload c4 --steps 2 --warmup 1 (8 x 3 Gbp at 10 % on one GPU)" > $O/kernel_stats_c4.md

@@ -185,7 +185,9 @@ def test_c2_three_100mbp_genomes_with_filter_full_size(ctx):
 def test_c4_one_gpu_share_of_eight_divergent_3gbp_genomes(ctx):
     """Config 4 as one rank sees it: its own 3 Gbp genome, the common filter = AND of the eight genomes' filters (10 %
     pairwise divergence: a 24-mer survives in all eight with probability 0.95^192, so the filter is all but empty and
-    the library takes the every-k-mer-probed path).  Properties + oracle on slices read back from HBM."""
+    the library looks every k-mer up in the filter's L2-resident summary first and takes the accepted k-mers as the candidate
+    list: k_hash_accept*; the every-k-mer-probed kernels and the forced pruned path are compared with it below).  Properties +
+    oracle on slices read back from HBM."""
     from ntsynt_amd.device import BloomFilter, Genome, bf_size_bytes, sketch
     k, w, contigs, total = 24, 1000, 24, 3_000_000_000
     _, nbytes = bf_size_bytes(total, 0.025)
