@@ -237,7 +237,7 @@ int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, con
  * (c = 10.5 / accepted share, at least 8: DESIGN.md 4.1); otherwise c = prune_c. */
 int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c);
 /* Dense sketch over a sparse filter (many divergent genomes: nearly no k-mer is common to all): when occupancy x 2^shift is
- * small, a summary of the filter with one bit per 2^shift filter bits (<= 1 MiB, L2-resident; built once per filter state) is
+ * small, a summary of the filter with one bit per 2^shift filter bits (<= 4 MiB: mostly L2-resident; built once per filter state) is
  * consulted first and only a set summary bit leads to a read of the filter; key tiles without an accepted k-mer are skipped
  * by the window kernel.  In auto mode the accepted k-mers themselves become the candidate list (no keys, no window kernel), and
  * when the filter holds few enough set bits a copy of it folded onto 2^19 bits is looked at first, from LDS.  Identical output.

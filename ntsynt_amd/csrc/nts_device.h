@@ -147,6 +147,13 @@ struct FastMod
   }
 };
 
+// slot of filter bit `idx` in the second folded table of a sparse filter (2^19 bits): a multiplicative hash of the index
+// (filters hold fewer than 2^38 bits: idx >> 6 fits 32 bits)
+__host__ __device__ __forceinline__ uint32_t fold2_slot(uint64_t idx)
+{
+  return ((uint32_t)(idx >> 6) * 0x9E3779B1u + (uint32_t)(idx & 63u) * 0x85EBCA6Bu) >> 13;
+}
+
 // Bloom bit `idx` lives in byte idx/8 at bit idx%8 (LSB first) == bit idx%32 of little-endian
 // 32-bit word idx/32.
 __device__ __forceinline__ bool bf_test(const uint32_t* __restrict__ words, uint64_t idx)

@@ -586,7 +586,7 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash(const uint8_t* __restrict
 // ---- dense sketch over a sparse filter ------------------------------------------------------------------------------
 // When the common filter is all but empty (many divergent genomes: BASELINE's 8 x 3 Gbp at 10 % leaves 3e-6 of the bits),
 // almost every probe of the every-k-mer-probed path fetches a 128-byte line of zeros from HBM.  A summary with one bit per
-// 2^shift filter bits (<= 1 MiB, resident in the L2) answers those probes; only where the summary bit is set is the filter
+// 2^shift filter bits (<= 4 MiB, mostly resident in the L2) answers those probes; only where the summary bit is set is the filter
 // itself read.  Same keys as k_hash<MODE_KEYS> bit for bit; key tiles without a single accepted k-mer are not written at all
 // and flagged in tile_any, so that the window kernel skips them.
 __global__ __launch_bounds__(256) void k_bf_summary(const uint4* __restrict__ words, uint64_t n16, uint32_t shift, uint32_t* __restrict__ summary,
@@ -603,6 +603,19 @@ __global__ __launch_bounds__(256) void k_bf_summary(const uint4* __restrict__ wo
       if (v.y) atomicOr(&fold[(w0 + 1) & (fold_words - 1)], v.y);
       if (v.z) atomicOr(&fold[(w0 + 2) & (fold_words - 1)], v.z);
       if (v.w) atomicOr(&fold[(w0 + 3) & (fold_words - 1)], v.w);
+      // a second table behind the first, addressed by a multiplicative hash of the index (fold2_slot): another look in LDS that is
+      // independent of the first and of the summary (k_hash_accept4r)
+      const uint32_t vv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t m = vv[q];
+        while (m) {
+          const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+          m &= m - 1u;
+          const uint32_t s2 = fold2_slot(i * 128u + 32u * q + b);
+          atomicOr(&fold[fold_words + (s2 >> 5)], 1u << (s2 & 31u));
+        }
+      }
     }
   }
 }
@@ -2765,6 +2778,7 @@ int ensure_pack(nts_ctx* ctx, const nts_genome* g)
 // exclusive scan of per-tile / per-workgroup counts: one single-workgroup kernel while the list is short (one launch,
 // ~4 us), the library's two-kernel scan beyond (a single workgroup would take ~0.1 ms over 2*10^5 counts)
 constexpr uint64_t SCAN1_MAX = 8192;
+constexpr uint32_t SUMMARY_LOG2_BITS = 25; // a sparse filter's summary: at most 2^25 bits = 4 MiB (config 4 on one GPU, 2^23 .. 2^26: 324 / 338 / 349 / 331 Gbases/s; NTS_SUMMARY_LOG2_BITS overrides)
 
 template <typename T>
 struct WidenU64
@@ -2888,6 +2902,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       A.fm = S.fm;
       A.summary = ctx->cur_summary;
       A.shift = ctx->cur_summary_shift;
+      A.probe_mask = (getenv("NTS_ACC_NO_LOOKUP") && atoi(getenv("NTS_ACC_NO_LOOKUP"))) ? 0u : ~0u;
       A.seg_j = d_sj;
       A.seg_key = d_sk;
       A.seg_cap = cseg_cap;
@@ -2900,12 +2915,21 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
         // bases from the 2-bit image in registers (k_hash_accept4r); NTS_ACCEPT_REG=0: the LDS-staged kernel (tests)
         if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
         if (!ctx->acc4r_lds_set) {
-          HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4r), hipFuncAttributeMaxDynamicSharedMemorySize,
+          HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4r<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(Accept4rLds)));
+          HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4r<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(Accept4rLds)));
           ctx->acc4r_lds_set = true;
         }
-        hipLaunchKernelGGL(k_hash_accept4r, dim3((uint32_t)((n_kt + 3) / 4)), dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A, g->d_pack,
-                           ctx->cur_fold, n_kt);
+        // (persistent workgroups, one per CU -- 128 KiB of LDS each --, each loops over groups of four tiles; NTS_ACC4R_WGS overrides)
+        const uint64_t groups4 = (n_kt + 3) / 4;
+        const uint64_t wgs = getenv("NTS_ACC4R_WGS") ? (uint64_t)std::max(1, atoi(getenv("NTS_ACC4R_WGS"))) : 256ull;
+        if (getenv("NTS_ACC4R_BLOCK") && atoi(getenv("NTS_ACC4R_BLOCK")) == 4)
+          hipLaunchKernelGGL(k_hash_accept4r<4>, dim3((uint32_t)std::min<uint64_t>(groups4, wgs)), dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A,
+                             g->d_pack, ctx->cur_fold, n_kt);
+        else
+          hipLaunchKernelGGL(k_hash_accept4r<8>, dim3((uint32_t)std::min<uint64_t>(groups4, wgs)), dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A,
+                             g->d_pack, ctx->cur_fold, n_kt);
       } else if (ctx->cur_fold) {
         if (!ctx->acc4_lds_set) {
           HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3274,7 +3298,8 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     SK_TRY(nts_bf_popcount(ctx, filter, &pc));
     const double bits = (double)filter->bytes * 8.0;
     uint32_t shift = 7;
-    while ((bits / (double)(1ull << shift)) > (double)(1u << 23) && shift < 30) ++shift; // summary <= 2^23 bits = 1 MiB
+    const uint32_t sum_log2 = getenv("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(getenv("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
+    while ((bits / (double)(1ull << shift)) > (double)(1ull << sum_log2) && shift < 30) ++shift; // summary <= 2^sum_log2 bits
     if ((double)pc / bits * (double)(1ull << shift) < 0.3) {
       if (filter->summary_version != filter->version || filter->summary_shift != shift) {
         const uint64_t n_gran = ((uint64_t)filter->bytes * 8 + (1ull << shift) - 1) >> shift;
@@ -3287,8 +3312,8 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
           filter->summary_words = words;
         }
         SK_HIP(hipMemsetAsync(filter->d_summary, 0, filter->summary_words * 4, ctx->stream));
-        if (!filter->d_fold) SK_HIP(hipMalloc((void**)&filter->d_fold, FOLD_WORDS * 4));
-        SK_HIP(hipMemsetAsync(filter->d_fold, 0, FOLD_WORDS * 4, ctx->stream));
+        if (!filter->d_fold) SK_HIP(hipMalloc((void**)&filter->d_fold, 2 * FOLD_WORDS * 4)); // (two tables: k_bf_summary)
+        SK_HIP(hipMemsetAsync(filter->d_fold, 0, 2 * FOLD_WORDS * 4, ctx->stream));
         const uint64_t n16 = (filter->bytes + 15) / 16;
         ScopedTimer t(ctx, "bf_summary");
         hipLaunchKernelGGL(k_bf_summary, dim3((uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 16)), dim3(256), 0, ctx->stream,
