@@ -47,7 +47,7 @@ constexpr int WIN_THREADS = 512;     // 8 waves share one tile: shorter phases, 
 constexpr uint32_t WIN_TILE = 4096;    // windows per workgroup
 constexpr uint32_t WIN_CHUNK = 16;     // elements scanned sequentially by one lane
 constexpr uint32_t WIN_MAX_W = 12000;  // LDS bound: (WIN_TILE + w) * 8 B + tables <= 160 KiB
-constexpr uint32_t MAIL_WORDS = 4096;  // 64-bit words of the pinned result mailbox (nts_ctx::mail)
+constexpr uint32_t MAIL_WORDS = 32768; // 64-bit words of the pinned result mailbox (nts_ctx::mail)
 
 std::string g_init_error;
 
@@ -2516,7 +2516,7 @@ int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_
   return NTS_OK;
 }
 
-constexpr uint32_t GAP_PEEK = 1024; // uncovered ranges fetched together with the counters
+constexpr uint32_t GAP_PEEK = 8192; // uncovered ranges fetched together with the counters (a second round trip for more: 0.1 ms per 3 Gbp sketch when a family with insertions had 1500)
 
 // small device results -> the context's pinned mailbox (up to 6 ranges of 64-bit words)
 struct MailParams
@@ -3275,7 +3275,8 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     // Measured at 3 x 3 Gbp, w = 1000, p = 0.70, with k_hash_select_hi and the uncovered ranges probed only where a window
     // reads them: c = 12 / 13 / 14 / 15 / 16 -> 1021 / 1085 / 1124 / 1134 / 1124 Gbases/s; with k_hash_select, whose rolling
     // cost twice as much per k-mer, and whole key tiles probed around every range, the optimum was c = 18, cp = 12.)
-    const double cp = 10.5;
+    const double cp = 11.0; // (round 3, with the select kernel dropping hopeless candidates and a family with insertions: c = 13 .. 17 ->
+                            //  1280 / 1397 / 1420 / 1476 / 1413 Gbases/s; c = 16 at p = 0.70)
     const double want = std::max(8.0, std::ceil(cp / std::max(p, 1e-4)));
     // (measured: at a quarter of the k-mers as candidates the pruned pass is still twice as fast as the dense one;
     // at 40 % single lanes run out of slots in most tiles and it is half as fast)
