@@ -20,7 +20,7 @@ def short(name):
         return "rocprim (sort/scan)"
     m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", name)
     if m:
-        return m.group(1) if m.group(1) in ("k_hash_select", "k_hash_select_hi") else m.group(0)   # (template variants: one row)
+        return m.group(1) if m.group(1) in ("k_hash_select", "k_hash_select_hi", "k_hash_accept4r") else m.group(0)   # (template variants: one row)
     m = re.search(r"(__amd_rocclr_[A-Za-z]+)", name)
     return m.group(1) if m else name[:60]
 
