@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="c2: one launch sequence per genome instead of one per step")
     ap.add_argument("--no-nruns-leg", action="store_true")
+    ap.add_argument("--at-once", action="store_true", help="the timed steps sketch the genomes of a GPU at once (device.SketchPool) "
+                                                           "instead of one after the other (an experiment: DESIGN.md section 8)")
     ap.add_argument("--substitutions-only", action="store_true", help="genomes differ by substitutions only (round 2's family)")
     ap.add_argument("--e2e-dir", default=None, help="where the e2e leg writes its FASTA files [a temp dir]")
     return ap.parse_args()
@@ -378,7 +380,7 @@ def main():
         raise SystemExit(f"workload {name}: {n_fam} genomes cannot occupy {world} GPUs")
     import torch
     import torch.distributed as dist
-    from ntsynt_amd.device import BloomFilter, Comm, Context, Genome, allgather_minimizers, bf_size_bytes, sketch
+    from ntsynt_amd.device import BloomFilter, Comm, Context, Genome, SketchPool, allgather_minimizers, bf_size_bytes, sketch
     # The process group carries the communicator id, the barriers and the max-over-ranks of the clock; the two exchanges run
     # inside libntsynt_hip.so.  NTS_BENCH_BACKEND=gloo + NTS_RCCL_LIB=<tests/rccl_standin>: ranks sharing the visible GPUs (boxes
     # with fewer GPUs than ranks, tests/test_gpu_multirank.py) -- same code path, not a measurement; the measured one is nccl.
@@ -489,12 +491,25 @@ def main():
                 "first_sketch_after_its_bloom_insert_ms": round(t_first * 1e3, 2), "minimizers": n_cold,
                 "includes": "2-bit image, run table of valid k-mers, first-k-mer tables, workspace allocation"}
 
+    # --at-once: the genomes of a step are sketched at once, each on a context of its own (device.SketchPool; NTS_SKETCH_POOL=3
+    # in the pipeline): one genome's latency-bound tail and the host's round trips overlap another's rolling.  Between +6 %
+    # and -18 % in throughput from run to run, and the kernels' own durations are then measured under each
+    # other's load -- the timed steps run one genome after the other.
+    pool = None
+    if len(units) > 1 and name != "c4" and args.at_once:
+        pool = SketchPool(ctx, min(len(units), 3))
+        pool.configure(lambda c: c.sketch_mode(args.mode, args.prune_c))
+
     def step():
         held, n = [], 0
-        for g in units:
-            mx = sketch(ctx, g, k, w, common)
-            n += len(mx)
-            held.append(mx)
+        if pool is not None:
+            held = pool.sketch(units, k, w, common)
+            n = sum(len(mx) for mx in held)
+        else:
+            for g in units:
+                mx = sketch(ctx, g, k, w, common)
+                n += len(mx)
+                held.append(mx)
         if world > 1:                                               # exchange 2: every rank receives every list
             if comm is not None:
                 everything = comm.allgather_minimizers(held, mine, n_fam)
@@ -515,10 +530,16 @@ def main():
         if torch.cuda.is_available():
             torch.cuda.synchronize()
 
+    def all_ctx(fn):
+        (pool.configure if pool is not None else (lambda f: f(ctx)))(fn)
+
+    def timing_of(n):
+        return pool.timing(n) if pool is not None else ctx.timing(n)
+
     def timed(n_warm, n_steps, level=2):
         for _ in range(n_warm):
             step()
-        ctx.profile(level)              # 2: HIP events around the dominant kernel only (every pair is a bubble in the stream)
+        all_ctx(lambda c: c.profile(level))   # 2: HIP events around the dominant kernel only (every pair is a bubble in the stream)
         fence()
         t_start = time.time()
         n_mx = 0
@@ -533,13 +554,23 @@ def main():
         return el, n_mx
 
     dt, n_mx = timed(args.warmup, args.steps)
-    tm = {n: ctx.timing(n) for n in SKETCH_KERNELS}
+    tm = {n: timing_of(n) for n in SKETCH_KERNELS}
     # the other kernels of the call: one more pass, untimed, with every kernel group bracketed by events
-    ctx.profile(1)
+    all_ctx(lambda c: c.profile(1))
     step()
     fence()
-    detail = {n: ctx.timing(n) for n in SKETCH_KERNELS}
-    ctx.profile(2)
+    detail = {n: timing_of(n) for n in SKETCH_KERNELS}
+    # and the dominant kernel alone on the GPU: one genome after the other on one stream (with the genomes sketched at once its
+    # launches share the chip with another genome's tail kernels, so the duration above is the one under that load)
+    alone_ms = None
+    if pool is not None:
+        ctx.profile(2)
+        for g in units:
+            sketch(ctx, g, k, w, common).free()
+        ctx.sync()
+        a_ms_, a_n_ = ctx.timing("hash_select")
+        alone_ms = a_ms_ / max(a_n_, 1)
+    all_ctx(lambda c: c.profile(2))
     cand, gaps, gap_kmers = ctx.sketch_stats()
     c_used = getattr(ctx, "last_prune_c", 0)
     per_launch_bases = bases / len(units)
@@ -570,6 +601,10 @@ def main():
         g_n.free()
 
     dense = None
+    n_at_once = len(pool.ctxs) if pool is not None else 1
+    if pool is not None:                  # the remaining legs run one sketch at a time on the main context
+        pool.close()
+        pool = None
     if args.mode != "dense" and not args.no_dense_leg and world == 1:
         ctx.sketch_mode("dense")
         n_d = max(2, args.steps // 2)
@@ -702,13 +737,16 @@ def main():
                        "family": "substitutions only" if args.substitutions_only else
                                  "substitutions + per genome 5 inversions (1-5 Mbp), 2 inter-contig translocations, 20 indels (1-60 kbp), "
                                  "60 small rearrangements (2-20 kbp moved / copied / inverted within 80 kbp), 200 indels of 1-50 bp",
-                       "minimizers_per_step_rank0": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)",
+                       "minimizers_per_step_rank0": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)" + (f"; the {n_at_once} genomes of a GPU sketched at once, a stream each" if n_at_once > 1 else ""),
                        "synth_s": round(t_synth, 3)},
             "roofline": {"bound": "hbm", "kernel": kern,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_base": round(bpb, 3),
                          "avg_launch_ms": round(a_ms, 4), "launches": tm["hash_select" if pruned_run else "hash_probe"][1],
+                         "genomes_sketched_at_once": n_at_once,
+                         "avg_launch_ms_alone_on_the_gpu": round(alone_ms, 4) if alone_ms else None,
+                         "frac_alone_on_the_gpu": round(bpb * per_launch_bases / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alone_ms else None,
                          "other_kernels_avg_ms": {n: round(detail[n][0] / detail[n][1], 4) for n in SKETCH_KERNELS if detail[n][1]},
                          "candidates_per_launch": cand, "uncovered_ranges": gaps, "uncovered_kmers": gap_kmers,
                          # the formulation with one sector read per k-mer moves 65.03 B/base, i.e. at

@@ -17,6 +17,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <mutex>
 #include <thread>
 
 #include <algorithm>
@@ -146,6 +147,7 @@ struct nts_bf
   mutable uint64_t summary_version = ~0ULL;
   mutable double summary_density = 1.0;
   mutable uint32_t* d_fold = nullptr; // the filter folded onto 2^19 bits (bit i mod 2^19), built with the summary: LDS-resident first look
+  mutable std::mutex mu;              // sketches of several genomes may run on contexts of their own at once (SketchPool): the summary is built once
 };
 
 struct nts_mx
@@ -3295,6 +3297,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   ctx->last_summary = 0;
   bool accept_all = false;
   if (!pruned && filter && filter->owned && ctx->summary_mode == 0 && !filter_out) {
+    std::lock_guard<std::mutex> summary_lock(filter->mu);
     uint64_t pc = 0;
     SK_TRY(nts_bf_popcount(ctx, filter, &pc));
     const double bits = (double)filter->bytes * 8.0;
@@ -3319,6 +3322,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
         ScopedTimer t(ctx, "bf_summary");
         hipLaunchKernelGGL(k_bf_summary, dim3((uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 16)), dim3(256), 0, ctx->stream,
                            (const uint4*)filter->d_words, n16, shift, filter->d_summary, filter->d_fold, FOLD_WORDS);
+        SK_HIP(hipStreamSynchronize(ctx->stream)); // (another context may read the summary from its own stream as soon as the lock is free)
         filter->summary_shift = shift;
         filter->summary_version = filter->version;
       }

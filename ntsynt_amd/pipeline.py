@@ -98,6 +98,7 @@ class GpuBackend:
         self.ctx = ctx or Context(device)
         self.device = self.ctx.device
         self.comm = None
+        self._pool = None                  # device.SketchPool: large assemblies sketched at once
         self._batch = None                 # (key, Genome): the run's assemblies as one resident batch genome
 
     # genomes
@@ -189,8 +190,15 @@ class GpuBackend:
     def sketch_dev(self, genomes, k, w, bf, masks=None, repeat=None):
         """sketch_batch with the lists left in HBM: [Minimizers] (one per genome) for the device-resident graph stage; a
         batch genome's list is taken apart on the device (nts_mx_split).  repeat: filter-out filter (indexlr -r), per genome."""
-        from .device import Genome, sketch
+        from .device import Genome, SketchPool, sketch
         if repeat is not None or len(genomes) < 2 or max(g.total_bp for g in genomes) >= self.BATCH_BELOW_BP:
+            # large assemblies: one launch sequence per genome; NTS_SKETCH_POOL=3: up to three genomes at once on contexts of their
+            # own (device.SketchPool: +6 % sketch throughput at 3 x 3 Gbp for ~4 GB of workspaces per context; off by default)
+            n_pool = min(len(genomes), int(os.environ.get("NTS_SKETCH_POOL", "1")))
+            if n_pool > 1 and repeat is None:
+                if self._pool is None:
+                    self._pool = SketchPool(self.ctx, n_pool)
+                return self._pool.sketch(genomes, k, w, bf, masks)
             return [sketch(self.ctx, g, k, w, bf, masks[i] if masks else None, repeat=repeat) for i, g in enumerate(genomes)]
         key = tuple(id(g) for g in genomes)
         if self._batch is None or self._batch[0] != key:
@@ -252,6 +260,9 @@ class GpuBackend:
         if self.comm is not None:
             self.comm.close()
             self.comm = None
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
         if self.own_ctx:
             self.ctx.close()
 

@@ -317,6 +317,8 @@ def test_c5_parameter_set_at_100mbp_files_to_tsv(tmp_path, monkeypatch, mbp, per
     profiles/r03_e2e_oracle.json)."""
     from ntsynt_amd import cli, pipeline, synth
     monkeypatch.setattr(pipeline.GpuBackend, "BATCH_BELOW_BP", 0 if per_genome else 1 << 30)
+    if per_genome:
+        monkeypatch.setenv("NTS_SKETCH_POOL", "3")          # ... and the three genomes of a round sketched at once (device.SketchPool)
     paths = synth.make_family(str(tmp_path), 3, mbp * 1_000_000, 6, 0.013, seed=77, micro=12)
     parser = cli.build_parser()
     a = parser.parse_args(paths + ["-d", "1.3", "-p", "c5"])

@@ -564,3 +564,50 @@ def test_sketch_with_filter_out_repeat_filter(ctx, k, w, with_common):
             x.free()
         for d in dg:
             d.free()
+
+
+def test_sketch_pool_equals_one_after_the_other(ctx):
+    """device.SketchPool: several genomes sketched at once, each on a context of its own from a thread of its own, give the lists
+    sketch() gives one after the other -- with and without hard masks, dense and pruned, more genomes than contexts; and a
+    sparse filter, whose summary the contexts share (built once, under the filter's lock)."""
+    from ntsynt_amd.device import BloomFilter, SketchPool, sketch
+    k, w = 24, 300
+    fams = [_family(500 + j, lengths=[300000, 120000, 4000]) for j in range(5)]
+    og = [to_oracle(n, s2) for n, s2 in fams]
+    dg = [to_device(ctx, n, s2) for n, s2 in fams]
+    nbytes = O.bf_ctor_bytes(O.bf_approx_bytes(og[0].total_bp, 0.025))
+    obf = O.bf_build(og[0], k, nbytes)
+    dbf = BloomFilter(ctx, nbytes, k)
+    dbf.from_numpy(obf)
+    sparse = obf.copy()
+    sparse[np.arange(sparse.size) % 97 != 0] = 0                 # an all-but-empty filter: the summary-first path
+    sbf = BloomFilter(ctx, nbytes, k)
+    sbf.from_numpy(sparse)
+    masks = [[(0, 1000 * (j + 1), 50000 + 1000 * j), (1, 0, 3000)] for j in range(5)]
+    pool = SketchPool(ctx, 3)
+    try:
+        for mode in ("auto", "dense", "pruned"):
+            pool.configure(lambda c: c.sketch_mode(mode, 12 if mode == "pruned" else 0))
+            for bf_d, mk in ((dbf, None), (dbf, masks), (None, None), (sbf, None)):
+                got = pool.sketch(dg, k, w, bf_d, mk)
+                for j, mx in enumerate(got):
+                    one = sketch(ctx, dg[j], k, w, bf_d, mk[j] if mk else None)
+                    for a, b in zip(mx.to_numpy(), one.to_numpy()):
+                        assert np.array_equal(a, b), (mode, j)
+                    one.free()
+                for mx in got:
+                    mx.free()
+        exp = oracle_flat(O.minimize(og[2], k, w, obf))
+        pool.configure(lambda c: c.sketch_mode("auto", 0))
+        got = pool.sketch(dg, k, w, dbf)
+        for a, b in zip(got[2].to_numpy(), exp):
+            assert np.array_equal(a, b.astype(a.dtype))
+        for mx in got:
+            mx.free()
+    finally:
+        pool.close()
+        ctx.sketch_mode("auto", 0)
+        for d in dg:
+            d.free()
+        dbf.free()
+        sbf.free()
