@@ -108,6 +108,7 @@ struct nts_ctx
   };
   std::vector<IoLane> io_up, io_down;
   const nts_bf* cur_rep = nullptr; // filter-out filter of the running nts_sketch_ex call (indexlr -r), or null
+  bool elim_needs_full_cap = false; // a call's candidate lists did not fit half the capacity sized for the accepted k-mers (run_pruned)
   int select_impl = 0;  // candidate selection of the pruned sketch: 0 auto, 1 full-width kernel, 2 upper-halves kernel also for assemblies in pieces
   int summary_mode = 0; // 0 auto, 1 never (tests)
   uint32_t last_summary = 0;
@@ -2849,6 +2850,11 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   PR_WS(d_ghi, uint64_t*, "gap_hi", gap_cap * 8);
   // room for the ACCEPTED candidates (share p_accept of the candidates, 1 if unknown); too little is seen and retried
   uint64_t cseg_cap = (uint64_t)((double)V * frac * std::min(1.0, 1.5 * p_accept + (accept_all ? 1e-4 : 0.02)) * 1.25 / N_SEG) + 8192;
+  // the upper-halves kernel drops about 70 % of the accepted k-mers again (those that cannot win a window) -- where its tiles lie inside
+  // one run; the window and gather kernels are launched over the capacity, so half of it is what they get until a call has
+  // needed more (an assembly in pieces: the retry below, once per context)
+  const bool elim_on = sel_hi && !(getenv("NTS_SELECT_ELIM") && atoi(getenv("NTS_SELECT_ELIM")) == 0);
+  if (elim_on && !ctx->elim_needs_full_cap) cseg_cap = cseg_cap / 2 + 8192;
   unsigned long long ctl[N_SEG + 1];
   std::vector<uint64_t> glo(GAP_PEEK), ghi(GAP_PEEK);
   uint64_t m = 0, n_gap = 0, n_sparse = 0;
@@ -3053,6 +3059,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       if (listed > m_max) worst = std::max<uint64_t>(worst, listed / N_SEG + 1); // the compacted array was cut short
     }
     if (worst <= cseg_cap) break;
+    if (elim_on) ctx->elim_needs_full_cap = true;
     if (attempt == 1) return fail(ctx, NTS_EHIP, "candidate segments overflowed twice");
     cseg_cap = worst + 1024; // candidate lists were truncated: everything downstream of them is void; run again
   }
