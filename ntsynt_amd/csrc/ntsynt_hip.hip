@@ -1695,50 +1695,36 @@ static int genome_finish(nts_ctx* ctx, nts_genome* g)
 {
   const uint64_t n = g->n;
   const uint32_t n_rec = g->n_rec;
-  // valid stretches: count, append, sort
-  unsigned long long* d_cnt = nullptr;
-  if (hipMalloc((void**)&d_cnt, 3 * sizeof(unsigned long long)) != hipSuccess) return fail(ctx, NTS_ENOMEM, "hipMalloc counters");
+  // valid stretches: count, append, sort.  (Scratch from the context's workspaces: every hipFree waits for the whole device, and
+  // the pipeline builds the filter of the previous genome on another context while this one comes up.)
+  unsigned long long* d_cnt = (unsigned long long*)ws_get(ctx, "gf_cnt", 3 * sizeof(unsigned long long));
+  if (!d_cnt) return NTS_ENOMEM;
   hipMemsetAsync(d_cnt, 0, 3 * sizeof(unsigned long long), ctx->stream);
   const uint64_t sblocks = (n + 1 + 4095) / 4096;
   hipLaunchKernelGGL(k_stretch<0>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, nullptr, nullptr,
                      nullptr);
   unsigned long long n_st = 0;
   hipMemcpyAsync(&n_st, d_cnt, sizeof(n_st), hipMemcpyDeviceToHost, ctx->stream);
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    hipFree(d_cnt);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess)
     return fail(ctx, NTS_EHIP, std::string("encode/stretch count: ") + hipGetErrorString(hipGetLastError()));
-  }
   std::vector<uint64_t> hs(n_st), he(n_st);
   if (n_st) {
-    uint64_t *d_s = nullptr, *d_e = nullptr, *d_s2 = nullptr, *d_e2 = nullptr;
-    void* d_tmp = nullptr;
+    uint64_t* d_s = (uint64_t*)ws_get(ctx, "gf_s", n_st * 8);
+    uint64_t* d_e = (uint64_t*)ws_get(ctx, "gf_e", n_st * 8);
+    uint64_t* d_s2 = (uint64_t*)ws_get(ctx, "gf_s2", n_st * 8);
+    uint64_t* d_e2 = (uint64_t*)ws_get(ctx, "gf_e2", n_st * 8);
+    if (!d_s || !d_e || !d_s2 || !d_e2) return NTS_ENOMEM;
     size_t tmp_bytes = 0;
-    bool ok = hipMalloc((void**)&d_s, n_st * 8) == hipSuccess && hipMalloc((void**)&d_e, n_st * 8) == hipSuccess &&
-              hipMalloc((void**)&d_s2, n_st * 8) == hipSuccess && hipMalloc((void**)&d_e2, n_st * 8) == hipSuccess;
-    if (ok) {
-      hipLaunchKernelGGL(k_stretch<1>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, d_s, d_e,
-                         d_cnt + 1);
-      rocprim::radix_sort_keys(nullptr, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
-      ok = hipMalloc(&d_tmp, tmp_bytes) == hipSuccess;
-    }
-    if (ok) {
-      rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
-      rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_e, d_e2, n_st, 0, 64, ctx->stream);
-      hipMemcpyAsync(hs.data(), d_s2, n_st * 8, hipMemcpyDeviceToHost, ctx->stream);
-      hipMemcpyAsync(he.data(), d_e2, n_st * 8, hipMemcpyDeviceToHost, ctx->stream);
-      ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
-    }
-    hipFree(d_s);
-    hipFree(d_e);
-    hipFree(d_s2);
-    hipFree(d_e2);
-    hipFree(d_tmp);
-    if (!ok) {
-      hipFree(d_cnt);
-      return fail(ctx, NTS_EHIP, "stretch detection failed");
-    }
+    hipLaunchKernelGGL(k_stretch<1>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, d_s, d_e, d_cnt + 1);
+    rocprim::radix_sort_keys(nullptr, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
+    void* d_tmp = ws_get(ctx, "gf_tmp", std::max<size_t>(tmp_bytes, 16));
+    if (!d_tmp) return NTS_ENOMEM;
+    rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
+    rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_e, d_e2, n_st, 0, 64, ctx->stream);
+    hipMemcpyAsync(hs.data(), d_s2, n_st * 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(he.data(), d_e2, n_st * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, NTS_EHIP, "stretch detection failed");
   }
-  hipFree(d_cnt);
   // clip stretches to records (k-mers never span two records)
   uint32_t r = 0;
   for (size_t s = 0; s < hs.size(); ++s) {
@@ -2214,8 +2200,8 @@ int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set)
     return NTS_OK;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  unsigned long long* d = nullptr;
-  HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(unsigned long long)));
+  unsigned long long* d = (unsigned long long*)ws_get(ctx, "popcnt", 64); // (not hipMalloc + hipFree: a hipFree waits for the whole device)
+  if (!d) return NTS_ENOMEM;
   hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream);
   const uint64_t n16 = (bf->bytes + 15) / 16;
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
@@ -2226,7 +2212,6 @@ int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set)
   unsigned long long h = 0;
   hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
   hipError_t e = hipStreamSynchronize(ctx->stream);
-  hipFree(d);
   if (e != hipSuccess) return fail(ctx, NTS_EHIP, std::string("popcount: ") + hipGetErrorString(e));
   bf->popcnt = (int64_t)h;
   *bits_set = h;
