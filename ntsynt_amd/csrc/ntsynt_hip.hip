@@ -1141,8 +1141,56 @@ __global__ __launch_bounds__(256) void k_bench_probe(const uint32_t* __restrict_
 }
 
 // compact index -> (record, position in record), and the printed hash h1.  With a second list (b_j / b_k, its length at
-// nb_dev; disjoint indices) the two ordered lists are merged on the way: every element finds its slot by a binary search
-// in the other list -- the few winners of the uncovered ranges join the sparse winners without a pass of their own.
+// nb_dev; disjoint indices) the two ordered lists are merged on the way: every element finds its slot by a search in the
+// other list -- the few winners of the uncovered ranges join the sparse winners without a pass of their own.
+//
+// The searches (slot in the other list, run, record) of the 6 M elements of the first list were chains of 5-13 dependent loads
+// each -- 0.12 ms per 3 Gbp genome, most of the kernel.  The list is ordered: k_fin_chunks makes the three searches once per
+// FIN_CHUNK consecutive elements (for the chunk's first index), and an element walks on from its chunk's answers -- nearly always
+// zero steps; after FIN_WALK steps it searches the rest (an assembly in thousands of pieces).
+constexpr uint32_t FIN_CHUNK = 1024, FIN_WALK = 6;
+
+__device__ __forceinline__ uint32_t fin_last_le(const uint64_t* __restrict__ a, uint32_t lo, uint32_t hi, uint64_t x) // last i in [lo, hi): a[i] <= x
+{
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (a[mid] <= x)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ uint64_t fin_lower_bound(const uint64_t* __restrict__ a, uint64_t lo, uint64_t hi, uint64_t x) // first i in [lo, hi): a[i] >= x
+{
+  while (lo < hi) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if (a[mid] < x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_fin_chunks(const uint64_t* __restrict__ j_sorted, uint64_t na_host, const uint64_t* __restrict__ n_out_dev,
+                                                    const uint64_t* __restrict__ b_j, const uint64_t* __restrict__ nb_dev,
+                                                    const uint64_t* __restrict__ run_pos, const uint64_t* __restrict__ run_vstart, uint32_t n_runs,
+                                                    const uint64_t* __restrict__ rec_off, uint32_t n_rec, uint64_t* __restrict__ c_b,
+                                                    uint32_t* __restrict__ c_run, uint32_t* __restrict__ c_rec)
+{
+  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // elements of the first list: all of them without a second list (their number is then n_out, or *n_out_dev)
+  const uint64_t na = b_j ? na_host : (n_out_dev ? *n_out_dev : na_host);
+  if (c * FIN_CHUNK >= na) return;
+  const uint64_t j = j_sorted[c * FIN_CHUNK];
+  c_b[c] = b_j ? fin_lower_bound(b_j, 0, *nb_dev, j) : 0;
+  const uint32_t run = fin_last_le(run_vstart, 0, n_runs, j);
+  c_run[c] = run;
+  c_rec[c] = fin_last_le(rec_off, 0, n_rec, run_pos[run] + (j - run_vstart[run]));
+}
+
 __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j_sorted,
                                                   const uint64_t* __restrict__ key_sorted,
                                                   uint64_t n_out,
@@ -1157,49 +1205,59 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j
                                                   const uint64_t* __restrict__ rec_off,
                                                   uint32_t n_rec,
                                                   uint32_t k,
+                                                  const uint64_t* __restrict__ c_b, const uint32_t* __restrict__ c_run, const uint32_t* __restrict__ c_rec,
                                                   uint64_t* __restrict__ h1,
                                                   uint32_t* __restrict__ rec,
                                                   uint64_t* __restrict__ pos)
 {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (n_out_dev ? *n_out_dev : n_out)) return;
-  uint64_t i = t, j, key;
-  if (b_j == nullptr) {
-    j = j_sorted[t];
-    key = key_sorted[t];
-  } else {
-    const uint64_t nb = *nb_dev;
-    const bool from_a = t < na;
-    const uint64_t self = from_a ? t : t - na;
-    j = from_a ? j_sorted[self] : b_j[self];
-    key = from_a ? key_sorted[self] : b_k[self];
-    const uint64_t* other = from_a ? b_j : j_sorted;
-    uint64_t lo = 0, hi = from_a ? nb : na;
-    while (lo < hi) {
-      const uint64_t mid = lo + ((hi - lo) >> 1);
-      if (other[mid] < j)
-        lo = mid + 1;
-      else
-        hi = mid;
+  const bool merging = b_j != nullptr;
+  const bool from_a = !merging || t < na;
+  const uint64_t self = from_a ? t : t - na;
+  const uint64_t j = from_a ? j_sorted[self] : b_j[self];
+  const uint64_t key = from_a ? key_sorted[self] : b_k[self];
+  uint64_t i = self;
+  uint32_t run, a;
+  if (from_a) {
+    const uint64_t c = self / FIN_CHUNK;
+    if (merging) { // slot among the second list's elements: from the chunk's answer on
+      const uint64_t nb = *nb_dev;
+      uint64_t lo = c_b[c];
+      uint32_t steps = 0;
+      while (lo < nb && b_j[lo] < j) {
+        ++lo;
+        if (++steps == FIN_WALK) {
+          lo = fin_lower_bound(b_j, lo, nb, j);
+          break;
+        }
+      }
+      i = self + lo;
     }
-    i = self + lo;
+    run = c_run[c];
+    for (uint32_t steps = 0; run + 1 < n_runs && run_vstart[run + 1] <= j;) {
+      ++run;
+      if (++steps == FIN_WALK) {
+        run = fin_last_le(run_vstart, run, n_runs, j);
+        break;
+      }
+    }
+  } else { // (the few elements of the second list: whole searches)
+    i = self + fin_lower_bound(j_sorted, 0, na, j);
+    run = fin_last_le(run_vstart, 0, n_runs, j);
   }
-  uint32_t lo = 0, hi = n_runs;
-  while (hi - lo > 1) {
-    const uint32_t mid = lo + ((hi - lo) >> 1);
-    if (run_vstart[mid] <= j)
-      lo = mid;
-    else
-      hi = mid;
-  }
-  const uint64_t gp = run_pos[lo] + (j - run_vstart[lo]);
-  uint32_t a = 0, z = n_rec;
-  while (z - a > 1) {
-    const uint32_t mid = a + ((z - a) >> 1);
-    if (rec_off[mid] <= gp)
-      a = mid;
-    else
-      z = mid;
+  const uint64_t gp = run_pos[run] + (j - run_vstart[run]);
+  if (from_a) {
+    a = c_rec[self / FIN_CHUNK];
+    for (uint32_t steps = 0; a + 1 < n_rec && rec_off[a + 1] <= gp;) {
+      ++a;
+      if (++steps == FIN_WALK) {
+        a = fin_last_le(rec_off, a, n_rec, gp);
+        break;
+      }
+    }
+  } else {
+    a = fin_last_le(rec_off, 0, n_rec, gp);
   }
   h1[i] = extend_h1(key, k);
   rec[i] = a;
@@ -3345,10 +3403,19 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     if (count) {
       SK_TRY(alloc_result(ctx, mx, count));
       {
+        // one search per FIN_CHUNK elements of the first list (k_fin_chunks), the elements walk on from there
+        const uint64_t n_first = res.b_j ? res.na : count;
+        const uint64_t n_chunks = n_first / FIN_CHUNK + 1;
+        SK_WS(d_cb, uint64_t*, "fin_chunks", n_chunks * 16);
+        uint32_t* const d_crun = (uint32_t*)(d_cb + n_chunks);
+        uint32_t* const d_crec = d_crun + n_chunks;
         ScopedTimer t(ctx, "finalize");
+        hipLaunchKernelGGL(k_fin_chunks, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, ctx->stream, res.d_j, n_first,
+                           res.d_ctl ? res.d_ctl + 1 : nullptr, res.b_j, res.b_j ? res.d_ctl : nullptr, T->d_run_pos, T->d_run_vstart, T->n_runs,
+                           g->d_rec_off, g->n_rec, d_cb, d_crun, d_crec);
         hipLaunchKernelGGL(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, res.d_j, res.d_key, (uint64_t)count,
-                           res.d_ctl ? res.d_ctl + 1 : nullptr, res.b_j, res.b_key, res.b_j ? res.d_ctl : nullptr, res.na, T->d_run_pos, T->d_run_vstart, T->n_runs, g->d_rec_off, g->n_rec, k, mx->d_h1,
-                           mx->d_rec, mx->d_pos);
+                           res.d_ctl ? res.d_ctl + 1 : nullptr, res.b_j, res.b_key, res.b_j ? res.d_ctl : nullptr, res.na, T->d_run_pos, T->d_run_vstart, T->n_runs, g->d_rec_off, g->n_rec, k,
+                           d_cb, d_crun, d_crec, mx->d_h1, mx->d_rec, mx->d_pos);
       }
       SK_HIP(hipGetLastError());
     }
