@@ -125,17 +125,35 @@ struct FastMod
 {
   uint64_t m;
   uint64_t inv; // floor(2^64 / m)   (m >= 2)
+  // The words the short forms below work on, as fields of their own: derived from m and inv inside the kernel, the optimiser
+  // proves `(uint32_t)inv == inv` on the branch where inv fits 32 bits and goes back to the generic 64 x 64 product (six of the
+  // quarter-rate multiplies instead of three).
+  uint32_t inv32, m_lo, m_hi;
+  uint32_t form; // 0 generic; 1: m > 2^32 (inv and the quotient fit 32 bits); 2: 2^32 < m < 2^38
   __device__ __forceinline__ uint64_t operator()(uint64_t h) const
   {
     // Filters above 512 MiB (m > 2^32 bits, every genome beyond ~100 Mbp): inv and the quotient fit 32 bits, and the
-    // 64 x 64 -> 128-bit product and the 64 x 64 multiply-back collapse to two and three 32-bit multiplies -- about 13
-    // instructions instead of 22, in kernels that are bound by VALU issue (k_bin1, the sparse-filter select kernels).
-    if ((inv >> 32) == 0) { // (uniform: the same for every lane of a launch)
-      const uint32_t inv32 = (uint32_t)inv;
+    // 64 x 64 -> 128-bit product and the 64 x 64 multiply-back collapse to 32-bit multiplies, in kernels that are bound by
+    // VALU issue (k_bin1, the sparse-filter select kernels).
+    if (form != 0) { // (uniform: the same for every lane of a launch)
       const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
       const uint64_t u = (uint64_t)hi * inv32 + __umulhi(lo, inv32); // (h * inv) >> 32; its high word is floor(h * inv / 2^64)
       const uint32_t q = (uint32_t)(u >> 32);
-      const uint64_t qm = (uint64_t)q * (uint32_t)m + ((uint64_t)(q * (uint32_t)(m >> 32)) << 32); // q * m mod 2^64 (q * m <= h)
+      if (form == 2) {
+        // filters below 32 GiB: the remainder r = h - q * m is below 2 m < 2^39, so its upper word is wanted modulo 128 only
+        // and q * (m >> 32) shrinks to a 24-bit multiply of two small numbers -- three quarter-rate multiplies in all, each of
+        // them the issue time of four plain instructions
+        const uint64_t p = (uint64_t)q * m_lo;
+        const uint32_t p_lo = (uint32_t)p;
+        const uint32_t r_lo = lo - p_lo;
+        uint32_t qm_hi; // (spelled out: left to itself the optimiser folds this product into a third 64-bit multiply-add)
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(qm_hi) : "s"(m_hi & 0x3Fu), "v"(q & 0x7Fu));
+        const uint32_t r_hi = (hi - (uint32_t)(p >> 32) - qm_hi - (lo < p_lo ? 1u : 0u)) & 0x7Fu;
+        uint64_t r = ((uint64_t)r_hi << 32) | r_lo;
+        if (r >= m) r -= m;
+        return r;
+      }
+      const uint64_t qm = (uint64_t)q * m_lo + ((uint64_t)(q * m_hi) << 32); // q * m mod 2^64 (q * m <= h)
       uint64_t r = h - qm;
       if (r >= m) r -= m;
       return r;

@@ -1372,6 +1372,11 @@ FastMod make_fastmod(uint64_t m)
   // floor(2^64 / m) for m >= 2, not a power of two or otherwise: (2^64-1)/m differs only when m | 2^64
   unsigned __int128 one = ((unsigned __int128)1) << 64;
   fm.inv = (uint64_t)(one / m);
+  fm.inv32 = (uint32_t)fm.inv;
+  fm.m_lo = (uint32_t)m;
+  fm.m_hi = (uint32_t)(m >> 32);
+  fm.form = (fm.inv >> 32) ? 0u : ((m >> 38) ? 1u : 2u);
+  if (const char* e = getenv("NTS_FASTMOD_FORM")) fm.form = std::min<uint32_t>(fm.form, (uint32_t)atoi(e)); // (tests: the longer forms)
   return fm;
 }
 
