@@ -166,6 +166,10 @@ int nts_bench_random_probe(nts_ctx* ctx, const nts_bf* bf, uint64_t n_probes, ui
  * launch, from which wave-instructions per second per CU = 4 * waves_per_simd * instr_per_wave / wall follow. */
 int nts_bench_valu(nts_ctx* ctx, int kind, uint32_t waves_per_simd, uint32_t iters, double* wall_ms, double* cycles_per_instr,
                    double* instr_per_wave);
+/* Diagnostic: out[i] = h[i] mod bits computed by the device code every probe and insert goes through (nts::FastMod: a
+ * generic form and two short ones for bits > 2^32 and 2^32 < bits < 2^38; `form` = -1 takes the one the library would, 0..2
+ * caps it) -- btllib's `hashes[0] % array_bits`.  h and out are host arrays of n words. */
+int nts_mod_indices(nts_ctx* ctx, uint64_t bits, int form, const uint64_t* h, uint64_t n, uint64_t* out);
 /* Non-owning filter over caller-provided HBM (e.g. the buffer a collective runs on): `device_ptr` must be
  * 16-byte aligned and hold `bytes` rounded up to a multiple of 16, the tail zeroed.  nts_bf_free() on a
  * wrapped filter releases only the handle. */

@@ -87,6 +87,7 @@ SYMBOLS = [
     ("nts_bench_random_probe", ctypes.c_int, [c_vp, c_vp, u64, u32, ctypes.POINTER(ctypes.c_double), c_u64p]),
     ("nts_bench_valu", ctypes.c_int, [c_vp, ctypes.c_int, u32, u32, ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    ("nts_mod_indices", ctypes.c_int, [c_vp, u64, ctypes.c_int, c_vp, u64, c_vp]),
     ("nts_bf_wrap", ctypes.c_int, [c_vp, c_vp, u64, ctypes.POINTER(c_vp)]),
     ("nts_and_raw", ctypes.c_int, [c_vp, c_vp, c_vp, u64]),
     ("nts_comm_unique_id", ctypes.c_int, [c_vp]),

@@ -84,6 +84,7 @@ struct nts_ctx
   std::vector<std::pair<void*, uint64_t>> mx_pool; // recycled result allocations
   size_t win_lds_set = 0;
   bool bin_lds_set = false;
+  uint32_t n_cus = 0; // compute units of the device (asked once)
   bool small_gap_path = true; // uncovered ranges: device-side sort + merge when they are few (nts_pruned.inc)
   bool sel_ctl_clean = false; // the pruned pass's control block was cleared by the previous call's last kernel
   int bf_build_mode = 0; // 0 auto (binned build for large genomes), 1 one atomic per k-mer, 2 binned whenever it applies
@@ -1365,6 +1366,11 @@ int hash_params_for(nts_ctx* ctx, uint32_t k, HashParams* out)
   return NTS_OK;
 }
 
+__global__ __launch_bounds__(256) void k_mod_indices(uint64_t* __restrict__ h, uint64_t n, FastMod fm)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) h[i] = fm(h[i]);
+}
+
 FastMod make_fastmod(uint64_t m)
 {
   FastMod fm;
@@ -2309,6 +2315,23 @@ int nts_bench_random_probe(nts_ctx* ctx, const nts_bf* bf, uint64_t n_probes, ui
   if (e != hipSuccess) return fail(ctx, NTS_EHIP, std::string("bench: ") + hipGetErrorString(e));
   *avg_ms = ms / repeats;
   if (hits) *hits = h;
+  return NTS_OK;
+}
+
+int nts_mod_indices(nts_ctx* ctx, uint64_t bits, int form, const uint64_t* h, uint64_t n, uint64_t* out)
+{
+  if (!ctx || bits < 2 || !h || !out || form < -1 || form > 2) return fail(ctx, NTS_EINVAL, "nts_mod_indices: bad arguments");
+  if (n == 0) return NTS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t* d = (uint64_t*)ws_get(ctx, "mod_idx", n * 8);
+  if (!d) return NTS_ENOMEM;
+  FastMod fm = make_fastmod(bits);
+  if (form >= 0) fm.form = std::min<uint32_t>(fm.form, (uint32_t)form);
+  HIP_TRY(ctx, hipMemcpyAsync(d, h, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_mod_indices, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65535)), dim3(256), 0, ctx->stream, d, n, fm);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, d, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return NTS_OK;
 }
 

@@ -458,3 +458,24 @@ def test_repeat_filter_matches_oracle(ctx, tmp_path):
                     "-p", str(tmp_path / "rep")], check=True, env=dict(os.environ, PYTHONPATH=root), stdout=subprocess.DEVNULL)
     bits, kk = read_bf(str(tmp_path / "rep.bf"))
     assert kk == k and np.array_equal(bits, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [143_467_638 * 8, (1 << 32) + 1, 14_811_708_827 * 8, (1 << 37) - 1, (1 << 38) - 3, (1 << 38) + 5,
+                                  (1 << 40) + 12345, 2, 3, (1 << 32), (1 << 32) - 1])
+def test_filter_index_arithmetic_all_forms(ctx, bits):
+    """h mod bits as the device computes it (nts_mod_indices -> nts::FastMod, every form the filter size admits) against Python
+    integers: the generic 64 x 64 form, the short form for bits > 2^32 and the shorter one below 2^38 that every human-scale
+    filter takes (btllib: hashes[0] % array_bits)."""
+    import ctypes
+    rng = np.random.default_rng(bits % 1000003)
+    h = rng.integers(0, 1 << 64, size=200_000, dtype=np.uint64)
+    edge = [0, 1, bits - 1, bits, bits + 1, 2 * bits - 1, 2 * bits, (1 << 64) - 1, (1 << 64) - bits, ((1 << 64) // bits) * bits,
+            ((1 << 64) // bits) * bits - 1, (1 << 63), (1 << 32) - 1, (1 << 32)]
+    h[:len(edge)] = np.array([e % (1 << 64) for e in edge], dtype=np.uint64)
+    want = np.array([int(x) % bits for x in h], dtype=np.uint64)
+    for form in (-1, 0, 1, 2):
+        out = np.empty_like(h)
+        ctx.check(ctx.lib.nts_mod_indices(ctx.h, bits, form, h.ctypes.data_as(ctypes.c_void_p), h.size,
+                                          out.ctypes.data_as(ctypes.c_void_p)), "nts_mod_indices")
+        assert np.array_equal(out, want), (bits, form)
