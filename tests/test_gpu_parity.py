@@ -412,9 +412,11 @@ def test_fragmented_assembly_sketch_and_bloom(ctx, lo, hi):
         ctx.sketch_mode("auto", 64)
 
 
-@pytest.mark.parametrize("k", [1, 129, 200])
+@pytest.mark.parametrize("k", [1, 2, 25, 63, 64, 65, 100, 128, 129, 200])
 def test_long_and_degenerate_k_end_to_end(ctx, k):
-    """k beyond the LDS-staged fast paths (and k = 1): Bloom build (both builds), pruned and dense sketch vs the oracle"""
+    """k beyond the LDS-staged fast paths (and k = 1): Bloom build (both builds), pruned and dense sketch vs the oracle; odd k and
+    the ends of the ranges the partitioned build treats differently (first k-mer from the two-bases LDS table up to 64, from the
+    per-base table up to 128, its own kernel beyond)"""
     from ntsynt_amd.device import BloomFilter, sketch
     names, seqs = _family(600 + k, lengths=[90000, 150, 40000, 0, 260], n_frac=0.001)
     og, dg = to_oracle(names, seqs), to_device(ctx, names, seqs)
