@@ -1,0 +1,25 @@
+import os, mmap, time, threading, tempfile, sys
+CH = 64 << 20
+total = 8 << 30
+d = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
+for flags, name in ((0, "cached"), (os.O_DIRECT, "direct")):
+    for nt in (4, 16):
+        path = os.path.join(d, "f")
+        try:
+            fd = os.open(path, os.O_CREAT | os.O_TRUNC | os.O_WRONLY | flags, 0o644)
+        except OSError as e:
+            print(name, "open failed", e); continue
+        buf = mmap.mmap(-1, CH); buf.write(b"\x07" * CH)
+        nxt = [0]; lock = threading.Lock(); err = []
+        def work():
+            while True:
+                with lock:
+                    o = nxt[0]; nxt[0] += CH
+                if o >= total: return
+                try: os.pwrite(fd, buf, o)
+                except OSError as e: err.append(e); return
+        t = time.time(); th = [threading.Thread(target=work) for _ in range(nt)]
+        [x.start() for x in th]; [x.join() for x in th]; dt = time.time() - t
+        os.close(fd); os.unlink(path)
+        print(name, nt, "threads", round(total / dt / 1e9, 2), "GB/s", err[:1], flush=True)
+import subprocess; print(subprocess.run("df -h /tmp . | head; mount | grep -E ' / | /tmp ' | head -3", shell=True, capture_output=True, text=True).stdout)
