@@ -81,3 +81,26 @@ def test_select_hi_pipeline_has_only_its_own_vector_memory_operations(code_objec
         # the probes are read from LDS only behind a full wait
         after = ins[wait_at + 1:]
         assert any(i == "s_waitcnt vmcnt(0)" for i in after)
+
+
+def test_bloom_build_kernels_keep_their_occupancy_and_batched_loads(code_object):
+    """k_bin1 (persistent, two workgroups of 1024 lanes per CU) and k_bin2 (four of 512) are tuned to 64 registers; what made
+    them fast was found in the ISA (csrc/nts_bloom_bin.inc): no scratch traffic on the tile paths -- in k_bin1 a
+    spill reload would queue behind the stores of the tile before --, and k_bin2's four 16-byte loads of a whole tile issued
+    together (the optimiser sinks each load to its first use unless a statement takes all sixteen values)."""
+    co, notes = code_object
+    k1, k2 = "_ZN12_GLOBAL__N_16k_bin1ENS_9BinParamsE", "_ZN12_GLOBAL__N_16k_bin2ENS_10Bin2ParamsE"
+    for sym in (k1, k2):
+        assert sym in notes, f"{sym} not found (renamed? update this guard with it)"
+    m1, m2 = _kernel_meta(notes, k1), _kernel_meta(notes, k2)
+    assert int(m1["vgpr_count"]) <= 64 and int(m2["vgpr_count"]) <= 64, (m1, m2)
+    assert int(m1["group_segment_fixed_size"]) * 2 <= 160 * 1024, m1      # two workgroups of k_bin1 per CU
+    assert int(m2["group_segment_fixed_size"]) * 4 <= 160 * 1024, m2      # four of k_bin2
+    assert m2["private_segment_fixed_size"] == "0", m2
+    i1, i2 = _disassemble(co, k1), _disassemble(co, k2)
+    # k_bin1: at most the one reload of the rare path (a lane with a run boundary among its k-mers)
+    assert sum(i.startswith("scratch_load") for i in i1) <= 1, [i for i in i1 if i.startswith("scratch_")]
+    # k_bin2, whole-tile path: four global_load_dwordx4 with no wait for vector memory between them
+    loads = [n for n, i in enumerate(i2) if i.startswith("global_load_dwordx4")]
+    assert len(loads) == 4, loads
+    assert not [i for i in i2[loads[0]:loads[-1]] if i.startswith("s_waitcnt") and "vmcnt" in i]
