@@ -93,6 +93,45 @@ def test_white_space_in_sequence_lines(ctx, tmp_path):
     assert host.fai_rows[0][3:] == (4, 7) and host.fai_rows[2][3:] == (4, 7)         # bases / bytes of the first line
 
 
+def test_odd_bytes_across_many_tiles(ctx, tmp_path):
+    """the register path of the parse kernels (whole 16 KiB tiles of sequence lines): lines of every width, LF and CRLF mixed, blanks
+    and tabs at the ends of lines and inside them, form feeds, control bytes, '>' in the middle of a line, lower case, N runs,
+    empty lines, a header every now and then -- device parse == host reader, bases and faidx columns"""
+    rng = np.random.default_rng(20260929)
+    out = []
+    for r in range(40):
+        out.append(b">rec%d some text\t here\n" % r if r % 3 else b">rec%d\r\n" % r)
+        for _ in range(int(rng.integers(1, 400))):
+            width = int(rng.integers(1, 200))
+            line = bytearray(rng.choice(np.frombuffer(b"ACGTacgtNnRYU", np.uint8), size=width).tobytes())
+            what = int(rng.integers(0, 12))
+            if what == 0:
+                line += b"  \t"
+            elif what == 1:
+                line[:0] = b" \t "
+            elif what == 2 and width > 4:
+                line[width // 2] = ord(" ")
+            elif what == 3 and width > 4:
+                line[width // 3] = ord(">")
+            elif what == 4 and width > 4:
+                line[width // 2] = 1
+            elif what == 5:
+                line += b"\x0c"
+            elif what == 6:
+                line = bytearray(b"")
+            elif what == 7 and width > 6:
+                line[2:5] = b"\t\t\t"
+            out.append(bytes(line) + (b"\r\n" if rng.random() < 0.3 else b"\n"))
+    raw = b"".join(out)
+    assert len(raw) > 40 * 16384
+    p = tmp_path / "odd.fa"
+    p.write_bytes(raw)
+    _same(ctx, str(p))
+    q = tmp_path / "odd_no_final_newline.fa"
+    q.write_bytes(raw.rstrip(b"\r\n") + b"ACGT")
+    _same(ctx, str(q))
+
+
 def test_device_parse_rejects_what_is_not_fasta(ctx, tmp_path):
     for i, raw in enumerate([b"@r1\nACGT\n+\nIIII\n", b"no header at all\nACGT\n"]):
         p = tmp_path / f"bad{i}.fq"
