@@ -353,26 +353,36 @@ __global__ __launch_bounds__(256) void k_stretch(const uint8_t* __restrict__ cod
 {
   const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
   if (base >= n + 1) return;
-  // bytes base-1 .. base+15 ; position n is the (invalid) pad byte so a trailing stretch gets its end
-  uint32_t local = 0;
-  bool prev = code[(int64_t)base - 1] < CODE_INVALID;
-  for (int j = 0; j < 16; ++j) {
-    const uint64_t i = base + j;
-    if (i > n) break;
-    const bool cur = code[i] < CODE_INVALID;
-    if (cur != prev) {
-      if (PASS == 0) {
-        local += cur ? 1u : 0u;
-      } else {
-        if (cur)
-          starts[atomicAdd(&cursors[0], 1ULL)] = i;
-        else
-          ends[atomicAdd(&cursors[1], 1ULL)] = i;
-      }
+  // bytes base-1 .. base+15 ; position n is the (invalid) pad byte so a trailing stretch gets its end.  The lane's sixteen bytes
+  // in one 16-byte load (code + base is 16-byte aligned, PAD bytes follow the sequence), validity of all of them as a 16-bit
+  // mask by word arithmetic -- byte by byte, lanes 16 bytes apart, this was 2.8 ms per pass over a 3 Gbp genome
+  const uint4 v = *reinterpret_cast<const uint4*>(code + base);
+  const bool prev = code[(int64_t)base - 1] < CODE_INVALID;
+  auto invalid4 = [](uint32_t x) -> uint32_t { // bit b: byte b of x is an invalid code (>= 4)
+    const uint32_t t = x & 0xFCFCFCFCu;
+    const uint32_t nz = (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
+    return (((nz >> 7) * 0x01020408u) >> 24) & 0xFu;
+  };
+  const uint32_t inv = invalid4(v.x) | (invalid4(v.y) << 4) | (invalid4(v.z) << 8) | (invalid4(v.w) << 12);
+  const uint32_t valid = ~inv & 0xFFFFu;
+  const uint64_t left = n + 1 - base; // positions base .. n count
+  const uint32_t lim = left >= 16 ? 0xFFFFu : ((1u << (uint32_t)left) - 1u);
+  const uint32_t diff = (valid ^ (((valid << 1) | (prev ? 1u : 0u)) & 0xFFFFu)) & lim;
+  uint32_t st = diff & valid, en = diff & ~valid;
+  if (PASS == 0) {
+    if (st) atomicAdd(counter, (unsigned long long)__popc(st));
+  } else {
+    while (st) {
+      const uint32_t j = (uint32_t)__ffs((int)st) - 1u;
+      st &= st - 1u;
+      starts[atomicAdd(&cursors[0], 1ULL)] = base + j;
     }
-    prev = cur;
+    while (en) {
+      const uint32_t j = (uint32_t)__ffs((int)en) - 1u;
+      en &= en - 1u;
+      ends[atomicAdd(&cursors[1], 1ULL)] = base + j;
+    }
   }
-  if (PASS == 0 && local) atomicAdd(counter, (unsigned long long)local);
 }
 
 // ---- canonical ntHash over the compact k-mer numbering ------------------------------------------
