@@ -2,13 +2,15 @@ import os, mmap, time, threading, tempfile, sys
 CH = 64 << 20
 total = 8 << 30
 d = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
-for flags, name in ((0, "cached"), (os.O_DIRECT, "direct")):
-    for nt in (4, 16):
+for flags, name in ((0, "cached"), (os.O_DIRECT, "direct"), (os.O_DIRECT, "direct+fallocate"), (0, "cached+fallocate")):
+    for nt in (4, 16, 32):
         path = os.path.join(d, "f")
         try:
             fd = os.open(path, os.O_CREAT | os.O_TRUNC | os.O_WRONLY | flags, 0o644)
         except OSError as e:
             print(name, "open failed", e); continue
+        if "fallocate" in name:
+            os.posix_fallocate(fd, 0, total)
         buf = mmap.mmap(-1, CH); buf.write(b"\x07" * CH)
         nxt = [0]; lock = threading.Lock(); err = []
         def work():
