@@ -183,7 +183,9 @@ def cpu_e2e_sample(k, w, fpr, slices, params, threads):
     return {"what": f"oracle pipeline on the first {slices[0].size / 1e6:.0f} Mbp of each of the {len(slices)} genomes (cut into six records each), "
                     f"ntSynt's parameters of the e2e leg, {threads} threads for Bloom build and sketch, graph stage single-threaded",
             "first_file_bp": int(first_bp), "seconds": round(total, 2), "stages_s": {n: round(v, 3) for n, v in t.items()},
-            "Gbases_s_end_to_end": round(bases / total / 1e9, 4), "minimizers": n_mx, "blocks": blocks}
+            "Gbases_s_end_to_end": round(bases / total / 1e9, 4), "minimizers": n_mx, "blocks": blocks,
+            # ru_maxrss is a high-water mark of the whole process: what stands here includes the earlier legs' host buffers
+            "process_peak_host_rss_bytes_after_this_leg": __import__("resource").getrusage(0).ru_maxrss * 1024}
 
 
 def cpu_baseline(k, w, fpr, sample, bf_np, budget_s=20.0, e2e_slices=None, e2e_par=None):
@@ -362,6 +364,11 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
             # the run ends when the 14.8 GB filter file is on disk: that artefact's share of the wall clock
             "share_waiting_for_the_bf_file": round(stages.get("wait_for_files", 0.0) / wall, 3) if wall > 0 else None,
             "blocks": len(tsv.splitlines()) // len(paths), "tsv_md5": md5, **oracle,
+            # the reference's other published figure (README.md:156-158: "34 GB / 32 GB" peak memory, host RAM there): the library's
+            # HBM high-water mark over the run (nts_mem_stats: every device allocation of every context) and this process's peak host
+            # RSS (ru_maxrss: since process start, so the sketch legs' host buffers are in it)
+            "peak_hbm_bytes": (eng.memory or {}).get("peak_hbm_bytes"), "peak_host_rss_bytes": (eng.memory or {}).get("peak_host_rss_bytes"),
+            "hbm_live_at_marks_GB": {n: round(v / 1e9, 2) for n, v in ((eng.memory or {}).get("hbm_live_at_marks") or {}).items()},
             "write_inputs_s": round(t_write, 1)}
 
 

@@ -61,6 +61,15 @@ void* nts_stream(nts_ctx* ctx);
 int nts_profile(nts_ctx* ctx, int enable);
 int nts_timing(nts_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
 
+/* Device memory of this process's library allocations (all contexts): bytes live now and their high-water mark since the
+ * last reset, plus what the device reports as in use / in total (hipMemGetInfo on the context's device: includes other
+ * users of the GPU, e.g. a caller's torch tensors).  Replaces the peak-memory column of the reference's `--benchmark`
+ * wrappers (`/usr/bin/time -v` / memusg per rule, bin/ntsynt_run_pipeline.smk:26-35; README.md:156-158 quotes wall clock and
+ * peak memory per run).  Any out-pointer may be NULL; ctx may be NULL (device figures are then 0).
+ * nts_mem_reset_peak: the mark restarts from the bytes live now. */
+int nts_mem_stats(nts_ctx* ctx, uint64_t* live_bytes, uint64_t* peak_bytes, uint64_t* device_used_bytes, uint64_t* device_total_bytes);
+void nts_mem_reset_peak(void);
+
 /* ---- A1: Bloom filter sizing ----------------------------------------------------------------
  * replaces approximate_bf_size(), src/ntsynt_make_common_bf.cpp:28-40, and the byte rounding of
  * the btllib::KmerBloomFilter constructor used at :122-123.  approx_bytes = ceil(-n/ln(1-fpr))/8
@@ -234,11 +243,11 @@ int nts_sketch(nts_ctx* ctx,
    absent from `filter`; either may be NULL.  With a filter-out filter the call takes the every-k-mer-probed kernels. */
 int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const nts_bf* filter, const nts_bf* filter_out,
                   const nts_interval* mask, uint64_t n_mask, nts_mx** out);
-/* Sketch policy.  mode 0 = auto (pruned when w >= 200 and c = 10.5 / accepted share stays below w/4, below 0.15 w for w < 512),
+/* Sketch policy.  mode 0 = auto (pruned when w >= 200 and c = 11 / accepted share stays below w/4, below 0.15 w for w < 512),
  * 1 = dense (probe the filter for every k-mer), 2 = pruned: only k-mers whose hash is <= (c / w) * 2^64 are probed;
  * windows holding no accepted candidate are re-evaluated densely, so the result is identical
  * (ntsynt_amd/csrc/nts_pruned.inc).  prune_c = 0: c is chosen per call from the filter's occupancy
- * (c = 10.5 / accepted share, at least 8: DESIGN.md 4.1); otherwise c = prune_c. */
+ * (c = 11 / accepted share, at least 8: DESIGN.md 4.1); otherwise c = prune_c. */
 int nts_sketch_mode(nts_ctx* ctx, int mode, uint32_t prune_c);
 /* Dense sketch over a sparse filter (many divergent genomes: nearly no k-mer is common to all): when occupancy x 2^shift is
  * small, a summary of the filter with one bit per 2^shift filter bits (<= 4 MiB: mostly L2-resident; built once per filter state) is

@@ -60,6 +60,8 @@ SYMBOLS = [
     ("nts_stream", c_vp, [c_vp]),
     ("nts_profile", ctypes.c_int, [c_vp, ctypes.c_int]),
     ("nts_timing", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), c_u64p]),
+    ("nts_mem_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u64p, c_u64p]),
+    ("nts_mem_reset_peak", None, []),
     ("nts_bf_size_bytes", ctypes.c_int, [u64, ctypes.c_double, c_u64p, c_u64p]),
     ("nts_bf_size_bytes_ex", ctypes.c_int, [u64, ctypes.c_double, ctypes.c_int, c_u64p, c_u64p]),
     ("nts_genome_upload", ctypes.c_int, [c_vp, c_vp, u64, c_u64p, c_u64p, u32, ctypes.POINTER(c_vp)]),

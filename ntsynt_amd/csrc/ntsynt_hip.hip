@@ -39,6 +39,54 @@
 
 using namespace nts;
 
+// ---- device memory accounting ---------------------------------------------------------------------------------------
+// Every device allocation of the library goes through dev_malloc / dev_free: live bytes and their high-water mark per
+// process (all contexts), read by nts_mem_stats.  The reference publishes exactly two figures per run, wall clock and peak
+// memory (README.md:156-158; `--benchmark` records the RSS of every rule, bin/ntsynt_run_pipeline.smk:26-35); its HBM
+// counterpart is this mark.
+namespace nts_mem {
+std::mutex mu;
+std::map<void*, size_t> sizes;
+std::atomic<uint64_t> live{0}, peak{0};
+
+inline hipError_t dev_malloc(void** p, size_t n)
+{
+  const hipError_t e = ::hipMalloc(p, n);
+  if (e == hipSuccess && *p) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      sizes[*p] = n;
+    }
+    const uint64_t now = live.fetch_add(n) + n;
+    uint64_t seen = peak.load();
+    while (now > seen && !peak.compare_exchange_weak(seen, now)) {
+    }
+  }
+  return e;
+}
+
+template <class T>
+inline hipError_t dev_malloc(T** p, size_t n)
+{
+  return dev_malloc((void**)p, n);
+}
+
+inline hipError_t dev_free(void* p)
+{
+  if (p) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = sizes.find(p);
+    if (it != sizes.end()) {
+      live.fetch_sub(it->second);
+      sizes.erase(it);
+    }
+  }
+  return ::hipFree(p);
+}
+} // namespace nts_mem
+using nts_mem::dev_free;
+using nts_mem::dev_malloc;
+
 namespace {
 
 constexpr uint64_t PAD = 256;          // invalid bytes before and after the sequence
@@ -185,15 +233,15 @@ void* ws_get(nts_ctx* ctx, const char* name, size_t bytes)
   if (b.second >= bytes && b.first) return b.first;
   if (b.first) {
     hipStreamSynchronize(ctx->stream);
-    hipFree(b.first);
+    dev_free(b.first);
     b.first = nullptr;
     b.second = 0;
   }
   const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, want);
+  hipError_t e = dev_malloc(&p, want);
   if (e != hipSuccess) {
-    e = hipMalloc(&p, std::max<size_t>(bytes, 256));
+    e = dev_malloc(&p, std::max<size_t>(bytes, 256));
     if (e != hipSuccess) {
       ctx->err = std::string("hipMalloc scratch '") + name + "': " + hipGetErrorString(e);
       return nullptr;
@@ -209,7 +257,7 @@ void* ws_get(nts_ctx* ctx, const char* name, size_t bytes)
 void ws_release(nts_ctx* ctx)
 {
   for (auto& kv : ctx->ws)
-    if (kv.second.first) hipFree(kv.second.first);
+    if (kv.second.first) dev_free(kv.second.first);
   ctx->ws.clear();
 }
 
@@ -1363,10 +1411,10 @@ int hash_params_for(nts_ctx* ctx, uint32_t k, HashParams* out)
         tab4[((size_t)g * 256 + v) * 2 + 1] = r;
       }
     uint64_t* d = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&d, tab.size() * 8));
+    HIP_TRY(ctx, dev_malloc((void**)&d, tab.size() * 8));
     hipError_t e = hipMemcpy(d, tab.data(), tab.size() * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-      hipFree(d);
+      dev_free(d);
       HIP_TRY(ctx, e);
     }
     it = ctx->init_tabs.emplace(k, d).first;
@@ -1542,7 +1590,7 @@ struct GenomeTables
       }
       uint64_t* d = nullptr;
       if (owned) {
-        HIP_TRY(ctx, hipMalloc((void**)&d, ts.size() * 8));
+        HIP_TRY(ctx, dev_malloc((void**)&d, ts.size() * 8));
         HIP_TRY(ctx, hipMemcpy(d, ts.data(), ts.size() * 8, hipMemcpyHostToDevice));
         e.second = d;
       } else {
@@ -1559,12 +1607,12 @@ struct GenomeTables
   void release()
   {
     if (!owned) return;
-    hipFree(d_run_pos);
-    hipFree(d_run_vstart);
-    hipFree(d_rec_vstart);
-    hipFree(d_rec_nv);
+    dev_free(d_run_pos);
+    dev_free(d_run_vstart);
+    dev_free(d_rec_vstart);
+    dev_free(d_rec_nv);
     for (auto& kv : win_tiles)
-      if (kv.second.second) hipFree(kv.second.second);
+      if (kv.second.second) dev_free(kv.second.second);
   }
 };
 
@@ -1592,7 +1640,7 @@ int get_tables(nts_ctx* ctx, const nts_genome* g, uint32_t k, const nts_interval
     T->owned = true;
     T->n_runs = (uint32_t)T->rt.pos.size();
     auto up = [&](const std::vector<uint64_t>& h, uint64_t** d) -> bool {
-      if (hipMalloc((void**)d, std::max<size_t>(h.size(), 1) * 8) != hipSuccess) return false;
+      if (dev_malloc((void**)d, std::max<size_t>(h.size(), 1) * 8) != hipSuccess) return false;
       return h.empty() || hipMemcpy(*d, h.data(), h.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
     };
     if (!up(T->rt.pos, &T->d_run_pos) || !up(T->rt.vstart, &T->d_run_vstart) || !up(T->rt.rec_vstart, &T->d_rec_vstart) ||
@@ -1701,10 +1749,10 @@ void nts_destroy(nts_ctx* ctx)
   for (hipEvent_t e : ctx->spare_events) hipEventDestroy(e);
   hipStreamSynchronize(ctx->stream);
   ws_release(ctx);
-  for (auto& p : ctx->mx_pool) hipFree(p.first);
+  for (auto& p : ctx->mx_pool) dev_free(p.first);
   io_release(ctx->io_up);
   io_release(ctx->io_down);
-  for (auto& kv : ctx->init_tabs) hipFree(kv.second);
+  for (auto& kv : ctx->init_tabs) dev_free(kv.second);
   if (ctx->mail) hipHostFree(ctx->mail);
   if (ctx->stage) hipHostFree(ctx->stage);
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
@@ -1736,6 +1784,25 @@ int nts_profile(nts_ctx* ctx, int enable)
   ctx->timings.clear();
   ctx->profiling = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
   return NTS_OK;
+}
+
+int nts_mem_stats(nts_ctx* ctx, uint64_t* live_bytes, uint64_t* peak_bytes, uint64_t* device_used_bytes, uint64_t* device_total_bytes)
+{
+  if (live_bytes) *live_bytes = nts_mem::live.load();
+  if (peak_bytes) *peak_bytes = nts_mem::peak.load();
+  size_t fr = 0, tot = 0;
+  if (ctx && (device_used_bytes || device_total_bytes)) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemGetInfo(&fr, &tot));
+  }
+  if (device_used_bytes) *device_used_bytes = tot - fr;
+  if (device_total_bytes) *device_total_bytes = tot;
+  return NTS_OK;
+}
+
+void nts_mem_reset_peak(void)
+{
+  nts_mem::peak.store(nts_mem::live.load());
 }
 
 int nts_timing(nts_ctx* ctx, const char* name, double* total_ms, uint64_t* launches)
@@ -1822,7 +1889,7 @@ static int genome_finish(nts_ctx* ctx, nts_genome* g)
       a = rb;
     }
   }
-  if (hipMalloc((void**)&g->d_rec_off, std::max<uint32_t>(n_rec, 1) * 8) != hipSuccess ||
+  if (dev_malloc((void**)&g->d_rec_off, std::max<uint32_t>(n_rec, 1) * 8) != hipSuccess ||
       (n_rec && hipMemcpy(g->d_rec_off, g->rec_off.data(), n_rec * 8, hipMemcpyHostToDevice) != hipSuccess))
     return fail(ctx, NTS_ENOMEM, "hipMalloc record offsets");
   return NTS_OK;
@@ -1846,13 +1913,13 @@ int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64
   g->rec_len.assign(rec_len, rec_len + n_rec);
   for (uint32_t r = 0; r < n_rec; ++r) g->total_bases += rec_len[r];
   const uint64_t dev_bytes = PAD + n + PAD;
-  hipError_t e = hipMalloc((void**)&g->d_code, dev_bytes);
+  hipError_t e = dev_malloc((void**)&g->d_code, dev_bytes);
   if (e != hipSuccess) {
     delete g;
     return fail(ctx, NTS_ENOMEM, std::string("hipMalloc genome: ") + hipGetErrorString(e));
   }
   auto bail = [&](int code, const std::string& msg) {
-    hipFree(g->d_code);
+    dev_free(g->d_code);
     delete g;
     return fail(ctx, code, msg);
   };
@@ -1866,8 +1933,8 @@ int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64
     hipLaunchKernelGGL(k_encode, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n);
   }
   if (int rc = genome_finish(ctx, g)) {
-    hipFree(g->d_code);
-    hipFree(g->d_rec_off);
+    dev_free(g->d_code);
+    dev_free(g->d_rec_off);
     delete g;
     return rc;
   }
@@ -1893,9 +1960,9 @@ int nts_genome_concat(nts_ctx* ctx, uint32_t n_parts, const nts_genome* const* p
   nts_genome* g = new nts_genome();
   g->n = n;
   g->n_rec = (uint32_t)n_rec;
-  if (hipMalloc((void**)&g->d_code, PAD + n + PAD) != hipSuccess ||
-      hipMalloc((void**)&g->d_rec_off, std::max<uint64_t>(n_rec, 1) * 8) != hipSuccess) {
-    hipFree(g->d_code);
+  if (dev_malloc((void**)&g->d_code, PAD + n + PAD) != hipSuccess ||
+      dev_malloc((void**)&g->d_rec_off, std::max<uint64_t>(n_rec, 1) * 8) != hipSuccess) {
+    dev_free(g->d_code);
     delete g;
     return fail(ctx, NTS_ENOMEM, "nts_genome_concat: hipMalloc");
   }
@@ -1921,8 +1988,8 @@ int nts_genome_concat(nts_ctx* ctx, uint32_t n_parts, const nts_genome* const* p
   if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
   if (!ok) {
     const std::string msg = std::string("nts_genome_concat: ") + hipGetErrorString(hipGetLastError());
-    hipFree(g->d_code);
-    hipFree(g->d_rec_off);
+    dev_free(g->d_code);
+    dev_free(g->d_rec_off);
     delete g;
     return fail(ctx, NTS_EHIP, msg);
   }
@@ -1941,9 +2008,9 @@ void nts_genome_free(nts_ctx* ctx, nts_genome* g)
     kv.second->release();
     delete kv.second;
   }
-  if (g->d_rec_off) hipFree(g->d_rec_off);
-  if (g->d_code) hipFree(g->d_code);
-  if (g->d_pack) hipFree(g->d_pack);
+  if (g->d_rec_off) dev_free(g->d_rec_off);
+  if (g->d_code) dev_free(g->d_code);
+  if (g->d_pack) dev_free(g->d_pack);
   delete g;
 }
 
@@ -1971,8 +2038,8 @@ int nts_genome_synth(nts_ctx* ctx, uint64_t total_bp, uint32_t n_contigs, uint64
     g->st_b.push_back(per * (r + 1));
   }
   g->total_bases = n;
-  if (hipMalloc((void**)&g->d_code, PAD + n + PAD) != hipSuccess || hipMalloc((void**)&g->d_rec_off, n_contigs * 8) != hipSuccess) {
-    hipFree(g->d_code);
+  if (dev_malloc((void**)&g->d_code, PAD + n + PAD) != hipSuccess || dev_malloc((void**)&g->d_rec_off, n_contigs * 8) != hipSuccess) {
+    dev_free(g->d_code);
     delete g;
     return fail(ctx, NTS_ENOMEM, "nts_genome_synth: hipMalloc");
   }
@@ -1983,8 +2050,8 @@ int nts_genome_synth(nts_ctx* ctx, uint64_t total_bp, uint32_t n_contigs, uint64
   hipLaunchKernelGGL(k_synth, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, g->d_code + PAD, n, seed_ancestor, seed_genome, thr);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
-    hipFree(g->d_code);
-    hipFree(g->d_rec_off);
+    dev_free(g->d_code);
+    dev_free(g->d_rec_off);
     delete g;
     return fail(ctx, NTS_EHIP, std::string("nts_genome_synth: ") + hipGetErrorString(e));
   }
@@ -2040,11 +2107,11 @@ int nts_genome_synth_plan(nts_ctx* ctx, uint32_t n_rec, const uint64_t* rec_len,
     }
   }
   nts_synth_piece* d_pieces = nullptr;
-  if (hipMalloc((void**)&g->d_code, PAD + n + PAD) != hipSuccess || hipMalloc((void**)&g->d_rec_off, (size_t)n_rec * 8) != hipSuccess ||
-      hipMalloc((void**)&d_pieces, (size_t)n_pieces * sizeof(nts_synth_piece)) != hipSuccess) {
-    hipFree(g->d_code);
-    hipFree(g->d_rec_off);
-    hipFree(d_pieces);
+  if (dev_malloc((void**)&g->d_code, PAD + n + PAD) != hipSuccess || dev_malloc((void**)&g->d_rec_off, (size_t)n_rec * 8) != hipSuccess ||
+      dev_malloc((void**)&d_pieces, (size_t)n_pieces * sizeof(nts_synth_piece)) != hipSuccess) {
+    dev_free(g->d_code);
+    dev_free(g->d_rec_off);
+    dev_free(d_pieces);
     delete g;
     return fail(ctx, NTS_ENOMEM, "nts_genome_synth_plan: hipMalloc");
   }
@@ -2056,10 +2123,10 @@ int nts_genome_synth_plan(nts_ctx* ctx, uint32_t n_rec, const uint64_t* rec_len,
   hipLaunchKernelGGL(k_synth_plan, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_pieces, n_pieces, seed_ancestor,
                      seed_genome, thr);
   hipError_t e = hipStreamSynchronize(ctx->stream);
-  hipFree(d_pieces);
+  dev_free(d_pieces);
   if (e != hipSuccess) {
-    hipFree(g->d_code);
-    hipFree(g->d_rec_off);
+    dev_free(g->d_code);
+    dev_free(g->d_rec_off);
     delete g;
     return fail(ctx, NTS_EHIP, std::string("nts_genome_synth_plan: ") + hipGetErrorString(e));
   }
@@ -2099,14 +2166,14 @@ static int bf_create_alloc(nts_ctx* ctx, uint64_t bytes, uint64_t alloc, nts_bf*
   nts_bf* bf = new nts_bf();
   bf->bytes = bytes;
   bf->alloc_bytes = alloc;
-  hipError_t e = hipMalloc((void**)&bf->d_words, alloc);
+  hipError_t e = dev_malloc((void**)&bf->d_words, alloc);
   if (e != hipSuccess) {
     delete bf;
     return fail(ctx, NTS_ENOMEM, std::string("hipMalloc bloom: ") + hipGetErrorString(e));
   }
   e = hipMemsetAsync(bf->d_words, 0, alloc, ctx->stream);
   if (e != hipSuccess) {
-    hipFree(bf->d_words);
+    dev_free(bf->d_words);
     delete bf;
     return fail(ctx, NTS_EHIP, "hipMemset bloom");
   }
@@ -2142,9 +2209,9 @@ void nts_bf_free(nts_ctx* ctx, nts_bf* bf)
 {
   if (!bf) return;
   if (ctx) hipSetDevice(ctx->device);
-  if (bf->d_words && bf->owned) hipFree(bf->d_words);
-  if (bf->d_summary) hipFree(bf->d_summary);
-  if (bf->d_fold) hipFree(bf->d_fold);
+  if (bf->d_words && bf->owned) dev_free(bf->d_words);
+  if (bf->d_summary) dev_free(bf->d_summary);
+  if (bf->d_fold) dev_free(bf->d_fold);
   delete bf;
 }
 
@@ -2182,6 +2249,12 @@ uint64_t nts_bf_bytes(const nts_bf* bf)
 
 void* nts_bf_device_ptr(nts_bf* bf)
 {
+  // the caller may write through this pointer (collectives on the filter's own memory): what the library remembers about the
+  // filter's contents -- "holds no bit" (the store-only finish of the partitioned build), the cached popcount, the summary -- is void
+  if (bf) {
+    bf->popcnt = -1;
+    ++bf->version;
+  }
   return bf ? (void*)bf->d_words : nullptr;
 }
 
@@ -2514,8 +2587,8 @@ int nts_hash_all(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t** h0, u
   const RunTable& rt = T->rt;
   uint64_t* d_keys = nullptr;
   uint64_t* d_lin = nullptr;
-  HIP_TRY(ctx, hipMalloc((void**)&d_keys, key_buffer_elems(rt.n_valid) * 8));
-  HIP_TRY(ctx, hipMalloc((void**)&d_lin, std::max<uint64_t>(rt.n_valid, 1) * 8));
+  HIP_TRY(ctx, dev_malloc((void**)&d_keys, key_buffer_elems(rt.n_valid) * 8));
+  HIP_TRY(ctx, dev_malloc((void**)&d_lin, std::max<uint64_t>(rt.n_valid, 1) * 8));
   rc = launch_hash<MODE_KEYS>(ctx, "hash_only", g, *T, k, nullptr, nullptr, d_keys);
   uint64_t* host = (uint64_t*)malloc(std::max<uint64_t>(rt.n_valid, 1) * 8);
   if (rc == NTS_OK && rt.n_valid) {
@@ -2523,8 +2596,8 @@ int nts_hash_all(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t** h0, u
     hipMemcpyAsync(host, d_lin, rt.n_valid * 8, hipMemcpyDeviceToHost, ctx->stream);
   }
   hipError_t e = hipStreamSynchronize(ctx->stream);
-  hipFree(d_keys);
-  hipFree(d_lin);
+  dev_free(d_keys);
+  dev_free(d_lin);
   if (rc != NTS_OK || e != hipSuccess) {
     free(host);
     return rc != NTS_OK ? rc : fail(ctx, NTS_EHIP, std::string("hash_all: ") + hipGetErrorString(e));
@@ -2848,11 +2921,11 @@ int ensure_pack(nts_ctx* ctx, const nts_genome* g)
   const uint64_t n_words = (g->n + PAD) / 16; // the trailing pad is readable: look-ahead past the last base stays in bounds
   uint32_t* p = nullptr;
   // (320 more words that nothing looks at: k_hash_select_hi stages 272 words from the word of a tile's first base on)
-  HIP_TRY(ctx, hipMalloc((void**)&p, (n_words + 320) * 4));
+  HIP_TRY(ctx, dev_malloc((void**)&p, (n_words + 320) * 4));
   if (n_words) hipLaunchKernelGGL(k_pack2, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, g->d_code + PAD, n_words, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
-    hipFree(p);
+    dev_free(p);
     HIP_TRY(ctx, e);
   }
   g->d_pack = p;
@@ -2991,7 +3064,12 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       A.fm = S.fm;
       A.summary = ctx->cur_summary;
       A.shift = ctx->cur_summary_shift;
-      A.probe_mask = (getenv("NTS_ACC_NO_LOOKUP") && atoi(getenv("NTS_ACC_NO_LOOKUP"))) ? 0u : ~0u;
+      A.probe_mask = ~0u;
+      if (getenv("NTS_ACC_NO_LOOKUP") && atoi(getenv("NTS_ACC_NO_LOOKUP"))) { // a measurement switch that changes the RESULT: never silently
+        A.probe_mask = 0u;
+        static std::once_flag warned;
+        std::call_once(warned, [] { fprintf(stderr, "[ntsynt_hip] NTS_ACC_NO_LOOKUP is set: sparse-filter sketches return WRONG results (timing experiment only)\n"); });
+      }
       A.seg_j = d_sj;
       A.seg_key = d_sk;
       A.seg_cap = cseg_cap;
@@ -3226,7 +3304,7 @@ int alloc_result(nts_ctx* ctx, nts_mx* mx, uint64_t count)
   }
   if (!mx->d_h1) {
     const uint64_t cap = need + need / 8 + 4096;
-    HIP_TRY(ctx, hipMalloc((void**)&mx->d_h1, cap));
+    HIP_TRY(ctx, dev_malloc((void**)&mx->d_h1, cap));
     mx->cap_bytes = cap;
   }
   mx->d_pos = mx->d_h1 + count;
@@ -3360,7 +3438,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
         p = share((double)rt.n_valid);
       }
     }
-    // c*p = 10.5 accepted candidates per window on average.  (More would not empty the list of uncovered ranges:
+    // c*p = 11 accepted candidates per window on average (`cp` below; 10.5 until round 3).  (More would not empty the list of uncovered ranges:
     // beyond the ~V*(cp/w)*exp(-cp) chance ones there are the stretches the other genomes do not share at all.
     // Measured at 3 x 3 Gbp, w = 1000, p = 0.70, with k_hash_select_hi and the uncovered ranges probed only where a window
     // reads them: c = 12 / 13 / 14 / 15 / 16 -> 1021 / 1085 / 1124 / 1134 / 1124 Gbases/s; with k_hash_select, whose rolling
@@ -3397,14 +3475,14 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
         const uint64_t n_gran = ((uint64_t)filter->bytes * 8 + (1ull << shift) - 1) >> shift;
         const uint64_t words = (n_gran + 31) / 32 + 4;
         if (filter->summary_words < words) {
-          if (filter->d_summary) hipFree(filter->d_summary);
+          if (filter->d_summary) dev_free(filter->d_summary);
           filter->d_summary = nullptr;
           filter->summary_words = 0;
-          SK_HIP(hipMalloc((void**)&filter->d_summary, words * 4));
+          SK_HIP(dev_malloc((void**)&filter->d_summary, words * 4));
           filter->summary_words = words;
         }
         SK_HIP(hipMemsetAsync(filter->d_summary, 0, filter->summary_words * 4, ctx->stream));
-        if (!filter->d_fold) SK_HIP(hipMalloc((void**)&filter->d_fold, 2 * FOLD_WORDS * 4)); // (two tables: k_bf_summary)
+        if (!filter->d_fold) SK_HIP(dev_malloc((void**)&filter->d_fold, 2 * FOLD_WORDS * 4)); // (two tables: k_bf_summary)
         SK_HIP(hipMemsetAsync(filter->d_fold, 0, 2 * FOLD_WORDS * 4, ctx->stream));
         const uint64_t n16 = (filter->bytes + 15) / 16;
         ScopedTimer t(ctx, "bf_summary");
@@ -3509,7 +3587,7 @@ void nts_mx_free(nts_ctx* ctx, nts_mx* mx)
     if (ctx && ctx->mx_pool.size() < 8 && mx->cap_bytes)
       ctx->mx_pool.push_back({ mx->d_h1, mx->cap_bytes });
     else
-      hipFree(mx->d_h1);
+      dev_free(mx->d_h1);
   }
   delete mx;
 }
@@ -3563,7 +3641,7 @@ int nts_mx_upload(nts_ctx* ctx, const uint64_t* h1, const uint32_t* rec, const u
   nts_mx* mx = new nts_mx();
   mx->n = n;
   if (n) {
-    if (hipMalloc((void**)&mx->d_h1, n * 20) != hipSuccess) {
+    if (dev_malloc((void**)&mx->d_h1, n * 20) != hipSuccess) {
       nts_mx_free(ctx, mx);
       return fail(ctx, NTS_ENOMEM, "nts_mx_upload: hipMalloc");
     }

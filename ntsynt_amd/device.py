@@ -53,6 +53,7 @@ class Context:
         (probe only k-mers whose hash is <= prune_c/w of the hash range; identical output)."""
         code = {"auto": 0, "dense": 1, "pruned": 2}[mode]
         self.check(self.lib.nts_sketch_mode(self.h, code, int(prune_c)), "nts_sketch_mode")
+        self._sketch_mode = (mode, int(prune_c))
 
     def sketch_summary(self, mode=None):
         """Summary-first probing of sparse filters in the dense sketch (nts_sketch_summary): mode 'auto' / 'never' / 'no-lds'
@@ -96,6 +97,16 @@ class Context:
                 "cycles_per_wave_instr_per_simd": round(cyc.value, 3), "wave_instr_per_s_per_cu": per_cu,
                 # 4 SIMDs per CU, each issuing one wave-instruction per `cycles`: the clock the two figures imply
                 "implied_clock_GHz": round(per_cu * cyc.value / 4 / 1e9, 3)}
+
+    def mem_stats(self):
+        """Device memory of the library's allocations in this process: dict(live, peak, device_used, device_total) in bytes
+        (nts_mem_stats; `peak` is the high-water mark since the last mem_reset_peak())."""
+        a, b, c, d = u64(), u64(), u64(), u64()
+        self.check(self.lib.nts_mem_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)), "nts_mem_stats")
+        return {"live": a.value, "peak": b.value, "device_used": c.value, "device_total": d.value}
+
+    def mem_reset_peak(self):
+        self.lib.nts_mem_reset_peak()
 
     def trim_ingest(self):
         "give back the FASTA ingest's workspaces (the raw image of the largest file, pinned staging): nts_ingest_trim"
@@ -502,6 +513,8 @@ class SketchPool:
                 out[i] = sketch(self.ctxs[c], genomes[i], k, w, bf, masks[i] if masks else None, repeat=repeat)
         for f in [self._pool.submit(lane, c) for c in range(lanes)]:
             f.result()
+        for mx in out:            # the lanes are done: the lists belong to the caller's context from here on (they outlive the pool)
+            mx.ctx = self.main
         return out
 
     def timing(self, name):

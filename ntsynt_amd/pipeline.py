@@ -76,17 +76,43 @@ class Stages:
         self.rows.append((name, time.time() - t0))
 
     def mark(self, label):
-        "a point on the run's time line (seconds since the first mark), for e2e breakdowns"
+        "a point on the run's time line (seconds since the first mark), for e2e breakdowns; with `mem` set, the HBM bytes live there"
         now = time.time()
         if not hasattr(self, "t0"):
             self.t0 = now
             self.marks = []
+            self.hbm_marks = []
         self.marks.append((label, round(now - self.t0, 4)))
+        if self.mem is not None:
+            try:
+                self.hbm_marks.append((label, self.mem()["live"]))
+            except Exception:                                   # noqa: BLE001 -- a closed context: the time line still stands
+                pass
 
-    def write(self, path):
+    mem = None                  # callable -> dict(live=...) (device.Context.mem_stats), set by run() on the GPU backend
+
+    def memory(self):
+        """Peak memory of the run, the second figure the reference publishes per run (README.md:156-158; `--benchmark` records
+        the RSS of every rule, smk:26-35): the library's HBM high-water mark (nts_mem_stats, all contexts of the process, since
+        the run began) and the process's peak host RSS (ru_maxrss: since process start -- a monotone figure)."""
+        import resource
+        out = {"peak_host_rss_bytes": int(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss) * 1024}
+        if self.mem is not None:
+            try:
+                m = self.mem()
+                out["peak_hbm_bytes"] = int(m["peak"])
+                out["hbm_live_at_marks"] = dict(self.hbm_marks)
+            except Exception:                                   # noqa: BLE001
+                pass
+        return out
+
+    def write(self, path, memory=None):
         with open(path, "w", encoding="utf-8") as fh:
             for name, dt in self.rows:
                 fh.write(f"{name}\t{dt:.6f}\n")
+            for name in ("peak_hbm_bytes", "peak_host_rss_bytes"):
+                if memory and name in memory:
+                    fh.write(f"{name}\t{memory[name]}\n")
 
 
 class GpuBackend:
@@ -198,6 +224,8 @@ class GpuBackend:
             if n_pool > 1 and repeat is None:
                 if self._pool is None:
                     self._pool = SketchPool(self.ctx, n_pool)
+                    mode, c = getattr(self.ctx, "_sketch_mode", ("auto", 0))     # the pool's contexts follow the main one's policy
+                    self._pool.configure(lambda cx: cx is self.ctx or cx.sketch_mode(mode, c))
                 return self._pool.sketch(genomes, k, w, bf, masks)
             return [sketch(self.ctx, g, k, w, bf, masks[i] if masks else None, repeat=repeat) for i, g in enumerate(genomes)]
         key = tuple(id(g) for g in genomes)
@@ -343,6 +371,16 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     own_backend = backend is None
     backend = backend or GpuBackend(device, ctx)
     st = Stages()
+    if isinstance(backend, GpuBackend):
+        lib = backend.ctx.lib                                  # (ctx = NULL: live / peak of the process, readable after the contexts closed)
+        lib.nts_mem_reset_peak()
+
+        def _mem():
+            import ctypes
+            a, b = ctypes.c_uint64(), ctypes.c_uint64()
+            lib.nts_mem_stats(None, ctypes.byref(a), ctypes.byref(b), None, None)
+            return {"live": a.value, "peak": b.value}
+        st.mem = _mem
     st.mark("start")
     if world > 1 and hasattr(backend, "init_comm"):
         backend.init_comm()
@@ -372,7 +410,14 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         n_loaders = max(1, min(int(os.environ.get("NTS_LOADERS", "1")), len(mine)))
         load_ctxs = [Context(backend.device) for _ in range(n_loaders)]
         genomes = _Arriving(sorted(mine), [(lambda p, c=c: fa.read_fasta_device(c, p)[0]) for c in load_ctxs], arrived)
-        genomes[sorted(mine)[0]]                               # the first one sizes the filter
+        try:
+            genomes[sorted(mine)[0]]                           # the first one sizes the filter
+        except BaseException:
+            for pool_ in genomes._pools:                       # (a loader failed: nothing of its context may outlive the call)
+                pool_.shutdown(wait=True, cancel_futures=True)
+            for c in load_ctxs:
+                c.close()
+            raise
     else:
         genomes = load_genomes(backend, mine)
         for p in mine:
@@ -428,15 +473,20 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         st.stop()
         st.mark("common_filter_done")
     if overlap_load:
-        genomes.wait_all()
+        try:
+            genomes.wait_all()
+        finally:
+            # the loaders are done (or failed: wait_all re-raises a loader's exception): their contexts (the raw image of the
+            # largest file in HBM, pinned staging) go either way
+            for pool_ in genomes._pools:
+                pool_.shutdown(wait=True)
+            for p in mine:
+                if dict.__contains__(genomes, p):
+                    dict.__getitem__(genomes, p).ctx = backend.ctx      # the genomes belong to the run's context from here on
+            for c in load_ctxs:
+                c.close()
         meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine}
         st.mark("genomes_resident")
-        # the loaders are done: their contexts (the raw image of the largest file in HBM, pinned staging) go; the genomes belong
-        # to the run's context from here on
-        for p in mine:
-            genomes[p].ctx = backend.ctx
-        for c in load_ctxs:
-            c.close()
     elif isinstance(backend, GpuBackend):
         backend.ctx.trim_ingest()
 
@@ -583,6 +633,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         for name in doomed:
             if os.path.exists(name):
                 os.remove(name)
+        if rank != 0:
+            import shutil
+            shutil.rmtree(scratch, ignore_errors=True)
         raise
     if rank != 0:
         eng.outputs = {os.path.basename(n): t for n, t in eng.outputs.items()}
@@ -595,8 +648,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         f.result()                      # re-raises a writer's exception
     writers.shutdown()
     st.stop()
+    memory = st.memory()
     if benchmark and rank == 0:
-        st.write(f"{prefix}.stage_times.tsv")
+        st.write(f"{prefix}.stage_times.tsv", memory)
     if getattr(backend, "_batch", None) is not None:
         backend._batch[1].free()
         backend._batch = None
@@ -610,4 +664,5 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     st.mark("end")
     eng.stage_times = st.rows
     eng.stage_marks = st.marks
+    eng.memory = memory
     return eng

@@ -83,6 +83,41 @@ def test_select_hi_pipeline_has_only_its_own_vector_memory_operations(code_objec
         assert any(i == "s_waitcnt vmcnt(0)" for i in after)
 
 
+@pytest.mark.parametrize("has_bf,per", [(True, 2), (True, 4), (False, 2), (False, 4)])
+def test_select_hi_m0_is_only_ever_used_next_to_its_own_write(code_object, has_bf, per):
+    """The LDS-DMA loads take their LDS address from m0, which the kernel's inline asm writes itself (`s_mov_b32 m0, sN;
+    s_nop 0; global_load_lds_*` in ONE asm statement each, csrc/nts_pruned.inc stage_dma / issue_probes).  m0 is a reserved
+    register: the compiler ignores the clobber (it warns about it) and uses m0 as a scratch scalar of its own -- today for the lane
+    index of `v_writelane_b32 v, s, m0`, written by an `s_mov_b32 m0` right in front.  Both uses are safe only while every reader
+    of m0 sits directly behind the write that serves it, with nothing of the other party in between.  This walks the ISA of the
+    four instantiations and checks exactly that."""
+    co, notes = code_object
+    symbol = f"_ZN12_GLOBAL__N_116k_hash_select_hiILb{int(has_bf)}ELj{per}EEEvNS_9SelParamsEjjm"
+    ins = _disassemble(co, symbol)
+    writes = [n for n, i in enumerate(ins) if re.match(r"s_\w+ m0\b", i)]
+    assert all(ins[n].startswith("s_mov_b32 m0, s") for n in writes), [ins[n] for n in writes]
+    dma = [n for n, i in enumerate(ins) if i.startswith("global_load_lds_")]
+    assert len(dma) == 4 + (2 * per if has_bf else 0)
+    ours = set()
+    for n in dma:            # every LDS-DMA load: its own write of m0 two instructions ahead, the s_nop between them, nothing else
+        assert ins[n - 1] == "s_nop 0" and ins[n - 2].startswith("s_mov_b32 m0, s"), ins[n - 3:n + 1]
+        ours.add(n - 2)
+    readers = [n for n, i in enumerate(ins) if re.search(r"\bm0\b", i) and n not in writes]
+    for n in readers:        # every other reader of m0 (the compiler's): served by a write of the compiler's own, straight behind it
+        back = n - 1
+        while back not in writes:
+            # between the write and its reader: straight-line scalar / vector ALU work, none of our asm, no branch
+            assert not ins[back].startswith(("global_load_lds_", "s_cbranch", "s_branch", "s_setpc", "s_swappc", "s_endpgm")), \
+                (ins[back], "between a write of m0 and", ins[n])
+            back -= 1
+        assert back not in ours, ("a compiler-made reader of m0 behind the kernel's own write", ins[back:n + 1])
+        assert n - back <= 8, ins[back:n + 1]
+    # and the compiler's writes are all consumed where they stand (no value of m0 is expected to survive one of our asm blocks)
+    for n in writes:
+        if n not in ours:
+            assert any(m in readers for m in range(n + 1, n + 4)), ins[n:n + 4]
+
+
 def test_bloom_build_kernels_keep_their_occupancy_and_batched_loads(code_object):
     """k_bin1 (persistent, two workgroups of 1024 lanes per CU) and k_bin2 (four of 512) are tuned to 64 registers; what made
     them fast was found in the ISA (csrc/nts_bloom_bin.inc): no scratch traffic on the tile paths -- in k_bin1 a
