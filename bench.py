@@ -269,21 +269,43 @@ def family_bases(args, n_fam, total_bp, contigs):
     return [int(synth.structural_plan(contigs, int(total_bp) // contigs, j, ANCESTOR_SEED)[0].sum()) for j in range(n_fam)]
 
 
-def write_fasta_from_device(g, path, chunk=1 << 28, soft_mask_seed=None):
-    """resident genome -> single-line FASTA file (inputs of the e2e leg; not timed).  soft_mask_seed: lower-case stretches
-    (10-20,000 bases, about one per 250 kbp) as in SURVEY.md 8(d)'s soft-masked variant -- the parse has to fold them"""
+def write_fasta_from_device(g, path, chunk=1 << 28, soft_mask_seed=None, half_lower=False, line_width=0):
+    """resident genome -> FASTA file (inputs of the e2e leg; not timed), single-line unless line_width.  soft_mask_seed: lower-case
+    stretches (10-20,000 bases, about one per 250 kbp) as in SURVEY.md 8(d)'s soft-masked variant -- the parse has to fold them;
+    half_lower: stretches of 50-3,000 bases alternately lower and upper case, about half of the bases each (a RepeatMasker-style
+    soft-masked assembly; needs soft_mask_seed)."""
     rng = np.random.default_rng(soft_mask_seed) if soft_mask_seed is not None else None
     with open(path, "wb") as fh:
         for r, name in enumerate(g.names):
             fh.write(b">" + name.encode() + b"\n")
             off, ln = int(g.rec_off[r]), int(g.rec_len[r])
+            col = 0
             for s in range(0, ln, chunk):
                 part = g.download(off + s, min(chunk, ln - s))
-                if rng is not None and part.size > 40000:
+                if rng is not None and half_lower:
+                    ends = np.cumsum(rng.integers(50, 3001, size=part.size // 1500 + 2))
+                    ends = ends[ends < part.size]
+                    flips = np.zeros(part.size + 1, dtype=np.int8)
+                    flips[ends] = 1
+                    lower = (np.cumsum(flips[:-1]) + int(rng.integers(0, 2))) & 1
+                    part[lower.astype(bool)] |= 0x20                            # ('N' becomes 'n': still invalid)
+                elif rng is not None and part.size > 40000:
                     for st in rng.integers(0, part.size - 20000, size=max(1, part.size // 250000)):
                         part[st:st + int(rng.integers(10, 20000))] |= 0x20      # ('N' would become 'n': still invalid)
-                fh.write(part.tobytes())
-            fh.write(b"\n")
+                if line_width:
+                    at = 0
+                    while at < part.size:
+                        take = min(line_width - col, part.size - at)
+                        fh.write(part[at:at + take].tobytes())
+                        at += take
+                        col += take
+                        if col == line_width:
+                            fh.write(b"\n")
+                            col = 0
+                else:
+                    fh.write(part.tobytes())
+            if not line_width or col:
+                fh.write(b"\n")
 
 
 ORACLE_RECORD = os.path.join(ROOT, "profiles", "r03_e2e_oracle.json")       # written by scripts/e2e_oracle_check.py
@@ -454,13 +476,8 @@ def main():
         common = BloomFilter(ctx, nbytes, k, world=world if comm is not None else 1)
     common.insert(genomes[0])
     occ_single = common.get_fpr()
-    if len(genomes) > 1:
-        tmp = BloomFilter(ctx, nbytes, k)
-        for g in genomes[1:]:
-            tmp.clear()
-            tmp.insert(g)
-            common.and_(tmp)
-        tmp.free()
+    for g in genomes[1:]:
+        common.insert_and(g)                     # one cascade level inside the build's last pass (nts_bf_insert_and), as pipeline.run does
     ctx.sync()
     t_build = time.time() - t0
     t_allreduce = 0.0
@@ -477,6 +494,7 @@ def main():
         ctx.sync()
         t_allreduce = time.time() - t1
     ins_ms, ins_n = ctx.timing("bf_insert")
+    insa_ms, insa_n = ctx.timing("bf_insert_and")
     occ_common = common.get_fpr()
 
     # ---- cold leg: the first sketch of a genome nothing has been derived from yet ---------------------------------
@@ -645,13 +663,13 @@ def main():
             g.free()
         fam = [family_genome(ctx, args, total_bp, contigs, g, 0.10 / 2.0) for g in range(8)]
         c4 = BloomFilter(ctx, nbytes, k)
+        t1 = time.time()
         c4.insert(fam[0])
-        tmp = BloomFilter(ctx, nbytes, k)
         for g in fam[1:]:
-            tmp.clear()
-            tmp.insert(g)
-            c4.and_(tmp)
-        tmp.free()
+            c4.insert_and(g)
+            c4.get_fpr()                         # (the pipeline prints the occupancy after every level; the library then knows when the filter is sparse)
+        ctx.sync()
+        t_c4_build = time.time() - t1
         for g in fam:
             sketch(ctx, g, k, w, c4).free()
         ctx.sync()
@@ -667,7 +685,7 @@ def main():
         d4 = time.time() - t1
         c4_n1 = {"workload": "8 synthetic 3000 Mbp genomes at 10% divergence on one GPU (bench.py --workload c4 --gpus 1)",
                  "value_Gbases_s": round(sum(g.total_bp for g in fam) * 2 / d4 / 1e9, 3), "ms_per_step": round(d4 / 2 * 1e3, 2),
-                 "common_filter_occupancy": c4.get_fpr(), "minimizers_per_step": n4}
+                 "common_filter_occupancy": c4.get_fpr(), "minimizers_per_step": n4, "common_filter_build_s": round(t_c4_build, 4)}
         c4.free()
         for g in fam:
             g.free()
@@ -766,6 +784,9 @@ def main():
             "bloom": {"bytes": nbytes, "build_s": round(t_build, 4), "allreduce_and_s": round(t_allreduce, 4),
                       "bf_insert_avg_ms": round(ins_ms / max(ins_n, 1), 4),
                       "bf_insert_Gbases_s": round(total_bp / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 3) if ins_ms > 0 else None,
+                      # a cascade level = the same build with the running filter AND-ed in its last pass (nts_bf_insert_and)
+                      "bf_insert_and_avg_ms": round(insa_ms / max(insa_n, 1), 4) if insa_n else None,
+                      "bf_insert_and_Gbases_s": round(total_bp / (insa_ms / max(insa_n, 1) * 1e-3) / 1e9, 3) if insa_ms > 0 else None,
                       # SURVEY.md 8(d) prices the build at 129 B/base (sector read + write-back per k-mer)
                       "bf_insert_GBs_at_129B_per_base": round(129.0 * total_bp / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 1)
                       if ins_ms > 0 else None,

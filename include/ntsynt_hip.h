@@ -125,6 +125,28 @@ typedef struct
 } nts_synth_piece;
 int nts_genome_synth_plan(nts_ctx* ctx, uint32_t n_rec, const uint64_t* rec_len, uint32_t n_pieces, const nts_synth_piece* pieces,
                           uint64_t seed_ancestor, uint64_t seed_genome, double substitution_rate, nts_genome** out);
+/* The assembly-like family (BASELINE config 5 stands on real mammalian assemblies, /root/reference README.md:157; they are not in
+ * the container): the same tiling, over an ancestor that is not i.i.d.  `rep` describes interspersed repeat families as a function
+ * of the ancestor coordinate s -- every cell of 2^cell_log2 bases holds, with probability prob_256/256, one copy of one of
+ * `families` consensus elements (SINE-like: sine_len bases; LINE-like: the last line_min_len..line_len bases of a line_len
+ * consensus, i.e. 5'-truncated), forwards or reverse-complemented, each copy diverged from its consensus by one of sixteen levels
+ * between div_min_1024/1024 and div_max_1024/1024 (young copies share k-mers: within-assembly duplicate minimizers, Bloom buckets
+ * that overflow); SINE copies overwrite LINE copies.  Pieces flagged NTS_SYNTH_TANDEM are satellite arrays: `reserved` = the array
+ * family, base = that family's sat_unit-base unit at (source coordinate mod sat_unit), diverged at sat_div_1024/1024 per base
+ * (keyed by the source coordinate, so that the copies of an array in the genomes of a family agree).  rep == NULL: an i.i.d.
+ * ancestor, tandem pieces rejected.  ntsynt_amd/synth.py (realistic_plan, plan_bases) holds the plan and the numpy statement of
+ * the same generator that the tests compare with. */
+#define NTS_SYNTH_TANDEM 8u
+typedef struct
+{
+  uint32_t sine_cell_log2, sine_len, sine_prob_256, sine_families;
+  uint32_t line_cell_log2, line_len, line_min_len, line_prob_256, line_families;
+  uint32_t div_min_1024, div_max_1024;
+  uint32_t sat_unit, sat_div_1024;
+} nts_synth_repeats;
+int nts_genome_synth_plan_ex(nts_ctx* ctx, uint32_t n_rec, const uint64_t* rec_len, uint32_t n_pieces, const nts_synth_piece* pieces,
+                             uint64_t seed_ancestor, uint64_t seed_genome, double substitution_rate, const nts_synth_repeats* rep,
+                             nts_genome** out);
 int nts_genome_download(nts_ctx* ctx, const nts_genome* g, uint64_t offset, uint64_t len, uint8_t* ascii);
 /* total bases (sum of record lengths, what approximate_bf_size() counts) */
 uint64_t nts_genome_bases(const nts_genome* g);
@@ -137,6 +159,9 @@ int nts_genome_valid_kmers(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64
  * nts_bf_cascade    : `if (bf->contains(h)) new_bf->insert(h)`, cpp:145-153 (literal cascade level)
  * nts_bf_and        : acc &= other -- with one hash function the cascade equals the AND of the
  *                     per-genome filters; this is the form the multi-GPU path reduces
+ * nts_bf_insert_and : one whole cascade level, cpp:134-160, as acc &= (filter of genome g) inside the partitioned build's
+ *                     last pass -- no second filter, no clearing, no AND pass; bit for bit what nts_bf_insert into a
+ *                     cleared filter followed by nts_bf_and gives (and what nts_bf_cascade gives)
  * nts_bf_popcount   : numerator of bf->get_fpr(), cpp:132,154,162
  * nts_bf_download / nts_bf_upload : raw bit array for bf->save()/load (cpp:164; smk:76).  The download sees
  *                     everything queued before the call and runs on the context's copy stream: it is the one
@@ -146,6 +171,7 @@ void nts_bf_free(nts_ctx* ctx, nts_bf* bf);
 uint64_t nts_bf_bytes(const nts_bf* bf);
 void* nts_bf_device_ptr(nts_bf* bf);
 int nts_bf_clear(nts_ctx* ctx, nts_bf* bf);
+int nts_bf_insert_and(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, uint32_t k);
 int nts_bf_insert(nts_ctx* ctx, nts_bf* bf, const nts_genome* g, uint32_t k);
 /* How nts_bf_insert sets the bits (same filter either way): 0 = auto (large genomes: hash, partition the bit
  * indices by filter segment in two streaming passes, set them in LDS bitmaps and OR whole segments into the
@@ -265,6 +291,14 @@ int nts_sketch_select(nts_ctx* ctx, int impl);
 /* of the last nts_sketch call: accepted candidates, uncovered ranges handed to the dense kernels, the number of
  * k-mers in them, and the c that was used (all 0 for a dense-mode call) */
 int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers, uint32_t* prune_c_used);
+/* Which of the paths for repeat-rich or fragmented input the last calls took (tests assert that an assembly-like family reaches
+ * them): of the last nts_sketch call, the candidates of k_hash_select_hi tiles that listed more k-mers than their slots hold (the
+ * two-sweep path: copies of a repeat, tiles in pieces); of the last partitioned Bloom build (nts_bf_insert / nts_bf_insert_and), the
+ * indices that bypassed the buckets (a full bucket: the copies of a repeat family; lanes whose k-mers span a run boundary), and
+ * whether its list of such indices ran full (store-only build: fell back to read-and-OR on the device; fused AND build: redone
+ * with a filter of the genome's own).  The Bloom figures are read at the next synchronising call on the filter
+ * (nts_bf_popcount, nts_bf_download, nts_sync). */
+int nts_path_stats(nts_ctx* ctx, uint64_t* sketch_many_listed, uint64_t* bf_direct_indices, uint32_t* bf_list_fallback);
 uint64_t nts_mx_count(const nts_mx* mx);
 void nts_mx_free(nts_ctx* ctx, nts_mx* mx);
 /* copy a minimizer list to caller-provided host arrays of nts_mx_count() elements */

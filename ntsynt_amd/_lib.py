@@ -31,6 +31,12 @@ class Fasta(ctypes.Structure):
                 ("fai_linebases", c_u32p), ("fai_linewidth", c_u32p)]
 
 
+class SynthRepeats(ctypes.Structure):
+    "nts_synth_repeats (include/ntsynt_hip.h): the repeat families of the assembly-like ancestor"
+    _fields_ = [(n, u32) for n in ("sine_cell_log2", "sine_len", "sine_prob_256", "sine_families", "line_cell_log2", "line_len", "line_min_len",
+                                   "line_prob_256", "line_families", "div_min_1024", "div_max_1024", "sat_unit", "sat_div_1024")]
+
+
 class Graph(ctypes.Structure):
     _fields_ = [("nv", u64), ("v_hash", c_u64p), ("occ_rec", c_u32p), ("occ_pos", c_u64p),
                 ("ne", u64), ("e_u", c_u32p), ("e_v", c_u32p), ("e_w", c_u32p), ("e_first", c_u64p)]
@@ -67,6 +73,7 @@ SYMBOLS = [
     ("nts_genome_upload", ctypes.c_int, [c_vp, c_vp, u64, c_u64p, c_u64p, u32, ctypes.POINTER(c_vp)]),
     ("nts_genome_synth", ctypes.c_int, [c_vp, u64, u32, u64, u64, ctypes.c_double, ctypes.POINTER(c_vp)]),
     ("nts_genome_synth_plan", ctypes.c_int, [c_vp, u32, c_vp, u32, c_vp, u64, u64, ctypes.c_double, ctypes.POINTER(c_vp)]),
+    ("nts_genome_synth_plan_ex", ctypes.c_int, [c_vp, u32, c_vp, u32, c_vp, u64, u64, ctypes.c_double, c_vp, ctypes.POINTER(c_vp)]),
     ("nts_genome_download", ctypes.c_int, [c_vp, c_vp, u64, u64, c_vp]),
     ("nts_genome_concat", ctypes.c_int, [c_vp, u32, c_vp, ctypes.POINTER(c_vp)]),
     ("nts_genome_free", None, [c_vp, c_vp]),
@@ -78,6 +85,7 @@ SYMBOLS = [
     ("nts_bf_device_ptr", c_vp, [c_vp]),
     ("nts_bf_clear", ctypes.c_int, [c_vp, c_vp]),
     ("nts_bf_insert", ctypes.c_int, [c_vp, c_vp, c_vp, u32]),
+    ("nts_bf_insert_and", ctypes.c_int, [c_vp, c_vp, c_vp, u32]),
     ("nts_bf_build_mode", ctypes.c_int, [c_vp, ctypes.c_int]),
     ("nts_bf_cascade", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, u32]),
     ("nts_bf_insert_repeats", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, u32]),
@@ -114,6 +122,7 @@ SYMBOLS = [
     ("nts_sketch_summary", ctypes.c_int, [c_vp, ctypes.c_int, c_u32p]),
     ("nts_sketch_select", ctypes.c_int, [c_vp, ctypes.c_int]),
     ("nts_sketch_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u64p, c_u32p]),
+    ("nts_path_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u32p]),
     ("nts_mx_count", u64, [c_vp]),
     ("nts_mx_free", None, [c_vp, c_vp]),
     ("nts_mx_download", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),

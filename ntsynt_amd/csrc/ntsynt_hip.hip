@@ -140,6 +140,9 @@ struct nts_ctx
   uint32_t prune_c = 0; // 0 = adaptive (from the filter's occupancy), else fixed
   uint32_t last_c = 0;
   uint64_t last_candidates = 0, last_gaps = 0, last_gap_kmers = 0;
+  uint64_t last_many_listed = 0; // candidates of k_hash_select_hi tiles that listed more than their slots hold (repeats, pieces)
+  uint64_t last_bf_direct = 0;   // indices of the last partitioned Bloom build that bypassed the buckets (full bucket, lanes in pieces)
+  uint32_t last_bf_fallback = 0; // 1: its late list ran full (store-only build fell back to read-and-OR / fused AND build was redone unfused)
   // dense sketch over a sparse filter: summary consulted before the filter, key tiles without an accepted k-mer skipped
   const uint32_t* cur_summary = nullptr;
   const uint32_t* cur_fold = nullptr; // folded copy of the filter for the LDS first look (k_hash_accept4), or null
@@ -1127,11 +1130,67 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ code, uint6
   }
 }
 
+// The assembly-like ancestor (nts_synth_repeats, include/ntsynt_hip.h): interspersed repeat copies as a function of the ancestor
+// coordinate.  ntsynt_amd/synth.py `_anc_bases` is the numpy statement of the same arithmetic.
+struct SynthRep
+{
+  uint32_t on;
+  nts_synth_repeats r;
+};
+
+__device__ __forceinline__ bool synth_layer(uint64_t s, uint64_t seed, uint64_t salt, uint32_t cell_log2, uint32_t len_full, uint32_t len_min,
+                                            uint32_t prob, uint32_t nfam, uint32_t div_min, uint32_t div_max, uint32_t& base)
+{
+  if (prob == 0) return false;
+  const uint64_t cell = s >> cell_log2;
+  const uint32_t o = (uint32_t)(s & ((1ull << cell_log2) - 1ull));
+  const uint64_t h = mix64((seed ^ salt) + cell * 0xA24BAED4963EE407ULL);
+  if ((uint32_t)(h & 255u) >= prob) return false;
+  const uint32_t len = len_min + (uint32_t)((h >> 8) & 0xFFFFu) % (len_full - len_min + 1u);
+  const uint32_t off = (uint32_t)((h >> 24) & 0xFFFFFu) % ((1u << cell_log2) - len + 1u);
+  if (o < off || o >= off + len) return false;
+  const uint32_t idx = o - off;
+  const uint32_t fam = (uint32_t)((h >> 44) & 0xFFu) % nfam;
+  const bool rev = (h >> 52) & 1u;
+  const uint32_t lvl = (uint32_t)(h >> 53) & 15u;
+  const uint32_t div = div_min + lvl * (div_max - div_min) / 15u;
+  const uint32_t ci = rev ? len_full - 1u - idx : len_full - len + idx;
+  uint32_t cb = (uint32_t)(mix64((seed ^ salt ^ 0x5555555555555555ULL) + (((uint64_t)fam << 32) + ci) * 0x9E3779B97F4A7C15ULL) & 3u);
+  if (rev) cb = 3u - cb;
+  const uint64_t y = mix64((seed ^ salt ^ 0xAAAAAAAAAAAAAAAAULL) + s * 0xD1B54A32D192ED03ULL);
+  if ((uint32_t)(y & 1023u) < div) cb = (cb + 1u + (uint32_t)((y >> 32) % 3u)) & 3u;
+  base = cb;
+  return true;
+}
+
+constexpr uint64_t SYNTH_SALT_LINE = 0x4C494E454C494E45ULL, SYNTH_SALT_SINE = 0x53494E4553494E45ULL, SYNTH_SALT_SAT = 0x5341544553415445ULL;
+
+__device__ __forceinline__ uint32_t synth_ancestor_base(uint64_t s, uint64_t seed_anc, const SynthRep& R)
+{
+  uint32_t base = (uint32_t)(mix64(seed_anc + s * 0x9E3779B97F4A7C15ULL) & 3u);
+  if (R.on) {
+    synth_layer(s, seed_anc, SYNTH_SALT_LINE, R.r.line_cell_log2, R.r.line_len, R.r.line_min_len, R.r.line_prob_256, R.r.line_families, R.r.div_min_1024,
+                R.r.div_max_1024, base);
+    synth_layer(s, seed_anc, SYNTH_SALT_SINE, R.r.sine_cell_log2, R.r.sine_len, R.r.sine_len, R.r.sine_prob_256, R.r.sine_families, R.r.div_min_1024,
+                R.r.div_max_1024, base);
+  }
+  return base;
+}
+
+__device__ __forceinline__ uint32_t synth_tandem_base(uint64_t s, uint32_t fam, uint64_t seed_anc, const SynthRep& R)
+{
+  const uint32_t u = (uint32_t)(s % R.r.sat_unit);
+  uint32_t b = (uint32_t)(mix64((seed_anc ^ SYNTH_SALT_SAT) + (((uint64_t)fam << 32) + u) * 0x9E3779B97F4A7C15ULL) & 3u);
+  const uint64_t y = mix64((seed_anc ^ SYNTH_SALT_SAT ^ 0xAAAAAAAAAAAAAAAAULL) + (((uint64_t)fam << 40) ^ s) * 0xD1B54A32D192ED03ULL);
+  if ((uint32_t)(y & 1023u) < R.r.sat_div_1024) b = (b + 1u + (uint32_t)((y >> 32) % 3u)) & 3u;
+  return b;
+}
+
 // The same family with structural events: the genome is a tiling of pieces (ascending dst), each a stretch of the ancestor
-// read forwards or as its reverse complement, a stretch of sequence of the genome's own (an insertion), or a run of N.
-// Substitutions are keyed by the genome coordinate, as in k_synth.
+// read forwards or as its reverse complement, a stretch of sequence of the genome's own (an insertion), a satellite array, or a
+// run of N.  Substitutions are keyed by the genome coordinate, as in k_synth.
 __global__ __launch_bounds__(256) void k_synth_plan(uint8_t* __restrict__ code, uint64_t n, const nts_synth_piece* __restrict__ pieces, uint32_t n_pieces,
-                                                    uint64_t seed_anc, uint64_t seed_gen, uint32_t thr)
+                                                    uint64_t seed_anc, uint64_t seed_gen, uint32_t thr, SynthRep R)
 {
   const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
   if (i0 >= n) return;
@@ -1157,8 +1216,10 @@ __global__ __launch_bounds__(256) void k_synth_plan(uint8_t* __restrict__ code, 
     else {
       if (pc.flags & NTS_SYNTH_NOVEL)
         base = (uint32_t)(mix64((seed_gen ^ 0x5bd1e995a7c3f1d7ULL) + sidx * 0x9E3779B97F4A7C15ULL) & 3u);
+      else if (pc.flags & NTS_SYNTH_TANDEM)
+        base = synth_tandem_base(sidx, pc.reserved, seed_anc, R);
       else
-        base = (uint32_t)(mix64(seed_anc + sidx * 0x9E3779B97F4A7C15ULL) & 3u);
+        base = synth_ancestor_base(sidx, seed_anc, R);
       if (rev) base = 3u - base;
       const uint64_t y = mix64(seed_gen ^ (i * 0xD1B54A32D192ED03ULL));
       if ((uint32_t)y < thr) base = (base + 1u + (uint32_t)((y >> 32) % 3u)) & 3u;
@@ -2062,8 +2123,30 @@ int nts_genome_synth(nts_ctx* ctx, uint64_t total_bp, uint32_t n_contigs, uint64
 int nts_genome_synth_plan(nts_ctx* ctx, uint32_t n_rec, const uint64_t* rec_len, uint32_t n_pieces, const nts_synth_piece* pieces,
                           uint64_t seed_ancestor, uint64_t seed_genome, double substitution_rate, nts_genome** out)
 {
+  return nts_genome_synth_plan_ex(ctx, n_rec, rec_len, n_pieces, pieces, seed_ancestor, seed_genome, substitution_rate, nullptr, out);
+}
+
+int nts_genome_synth_plan_ex(nts_ctx* ctx, uint32_t n_rec, const uint64_t* rec_len, uint32_t n_pieces, const nts_synth_piece* pieces,
+                             uint64_t seed_ancestor, uint64_t seed_genome, double substitution_rate, const nts_synth_repeats* rep, nts_genome** out)
+{
   if (!ctx || !out || !rec_len || !pieces || n_rec == 0 || n_pieces == 0 || substitution_rate < 0 || substitution_rate >= 1)
     return fail(ctx, NTS_EINVAL, "nts_genome_synth_plan: bad arguments");
+  SynthRep R;
+  memset(&R, 0, sizeof(R));
+  if (rep) {
+    R.on = 1;
+    R.r = *rep;
+    const nts_synth_repeats& r = R.r;
+    const bool sine_ok = r.sine_prob_256 == 0 || (r.sine_cell_log2 >= 4 && r.sine_cell_log2 <= 20 && r.sine_len >= 1 && r.sine_len <= (1u << r.sine_cell_log2) &&
+                                                  r.sine_families >= 1 && r.sine_prob_256 <= 256);
+    const bool line_ok = r.line_prob_256 == 0 || (r.line_cell_log2 >= 4 && r.line_cell_log2 <= 20 && r.line_min_len >= 1 && r.line_min_len <= r.line_len &&
+                                                  r.line_len <= (1u << r.line_cell_log2) && r.line_families >= 1 && r.line_prob_256 <= 256);
+    if (!sine_ok || !line_ok || r.div_min_1024 > r.div_max_1024 || r.div_max_1024 > 1024 || r.sat_div_1024 > 1024)
+      return fail(ctx, NTS_EINVAL, "nts_genome_synth_plan_ex: repeat parameters out of range");
+  }
+  for (uint32_t p = 0; p < n_pieces; ++p)
+    if ((pieces[p].flags & NTS_SYNTH_TANDEM) && (!rep || rep->sat_unit == 0))
+      return fail(ctx, NTS_EINVAL, "nts_genome_synth_plan_ex: a tandem piece needs rep->sat_unit");
   uint64_t n = 0;
   for (uint32_t r = 0; r < n_rec; ++r) {
     if (rec_len[r] == 0) return fail(ctx, NTS_EINVAL, "nts_genome_synth_plan: empty record");
@@ -2121,7 +2204,7 @@ int nts_genome_synth_plan(nts_ctx* ctx, uint32_t n_rec, const uint64_t* rec_len,
   hipMemcpyAsync(d_pieces, pieces, (size_t)n_pieces * sizeof(nts_synth_piece), hipMemcpyHostToDevice, ctx->stream);
   const uint32_t thr = (uint32_t)(substitution_rate * 4294967296.0);
   hipLaunchKernelGGL(k_synth_plan, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_pieces, n_pieces, seed_ancestor,
-                     seed_genome, thr);
+                     seed_genome, thr, R);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   dev_free(d_pieces);
   if (e != hipSuccess) {
@@ -2279,14 +2362,68 @@ static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nt
   const GenomeTables* T = nullptr;
   int rc = get_tables(ctx, g, k, nullptr, 0, scratch, &T);
   if (rc) return rc;
+  uint32_t* late_ctl = (uint32_t*)(ctx->mail + MAIL_WORDS - 8); // (pinned; the mailbox proper ends below: its users wait for their own flag)
+  late_ctl[0] = late_ctl[2] = late_ctl[3] = 0;
   if (prev) {
     rc = launch_hash<MODE_CASCADE>(ctx, "bf_cascade", g, *T, k, prev, next, nullptr);
   } else {
-    rc = ctx->bf_build_mode == 1 ? 1 : bf_insert_binned(ctx, next, g, *T, k, ctx->bf_build_mode == 2, was_empty);
+    rc = ctx->bf_build_mode == 1 ? 1 : bf_insert_binned(ctx, next, g, *T, k, ctx->bf_build_mode == 2, was_empty, 0, late_ctl);
     if (rc == 1) rc = launch_hash<MODE_INSERT>(ctx, "bf_insert", g, *T, k, nullptr, next, nullptr);
   }
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // run table buffers are released on return
+  if (!prev) {
+    ctx->last_bf_direct = (uint64_t)late_ctl[2] | ((uint64_t)late_ctl[3] << 32);
+    ctx->last_bf_fallback = late_ctl[0];
+  }
+  return NTS_OK;
+}
+
+// acc &= the filter of genome g: one level of the reference's cascade (src/ntsynt_make_common_bf.cpp:134-160; with one hash
+// function `new_bf[h] |= bf.contains(h)` over a genome's k-mers is the AND of the running filter with the genome's own filter,
+// SURVEY.md F8) inside the partitioned build's last pass: no second filter, no clearing of it, no separate AND pass -- per level
+// 14.8 GB read + <= 14.8 GB written at 3 Gbp instead of 14.8 (memset) + 14.8 (store) + 44.4 (k_bf_and).  Where the partitioned
+// build does not apply (small inputs, k > 128, forced atomic mode) or its list of bucket-bypassing indices ran full, the level is
+// done the plain way: the genome's filter in a temporary allocation, then k_bf_and.
+int nts_bf_insert_and(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, uint32_t k)
+{
+  if (!ctx || !acc || !g || k == 0) return fail(ctx, NTS_EINVAL, "nts_bf_insert_and: bad arguments");
+  const int64_t pop_before = acc->owned ? acc->popcnt : -1;
+  acc->popcnt = -1;
+  ++acc->version;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  GenomeTables scratch;
+  const GenomeTables* T = nullptr;
+  int rc = get_tables(ctx, g, k, nullptr, 0, scratch, &T);
+  if (rc) return rc;
+  uint32_t* late_ctl = (uint32_t*)(ctx->mail + MAIL_WORDS - 8);
+  late_ctl[0] = late_ctl[2] = late_ctl[3] = 0;
+  // (a running filter known to hold fewer than one bit per 2^12: most 64 KiB slices are empty, k_bin3 looks before it reads residues)
+  const bool sparse = pop_before >= 0 && (uint64_t)pop_before < ((acc->bytes * 8) >> 12);
+  const bool fused_ok = ctx->bf_build_mode != 1 && !(getenv("NTS_BIN_FUSED_AND") && atoi(getenv("NTS_BIN_FUSED_AND")) == 0);
+  rc = fused_ok ? bf_insert_binned(ctx, acc, g, *T, k, ctx->bf_build_mode == 2, false, sparse ? 2 : 1, late_ctl) : 1;
+  if (rc != 0 && rc != 1) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->last_bf_direct = (uint64_t)late_ctl[2] | ((uint64_t)late_ctl[3] << 32);
+  ctx->last_bf_fallback = 0;
+  if (rc == 0 && late_ctl[0] == 0) return NTS_OK;
+  // the plain way (acc is untouched: the fused build did not apply, or it gave up and put its parked bits back)
+  ctx->last_bf_fallback = rc == 0 ? 1u : 0u;
+  nts_bf* own = nullptr;
+  if (int rc2 = bf_create_alloc(ctx, acc->bytes, (acc->bytes + 15) / 16 * 16, &own)) return rc2;
+  rc = bf_hash_pass(ctx, nullptr, own, g, k);
+  if (rc == NTS_OK) {
+    const uint64_t n16 = (acc->bytes + 15) / 16;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
+    ScopedTimer t(ctx, "bf_and");
+    hipLaunchKernelGGL(k_bf_and, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)acc->d_words, (const uint4*)own->d_words, n16);
+  }
+  const uint32_t fb = ctx->last_bf_fallback;
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  nts_bf_free(ctx, own);
+  ctx->last_bf_fallback = fb;
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(ctx, NTS_EHIP, std::string("nts_bf_insert_and: ") + hipGetErrorString(e));
   return NTS_OK;
 }
 
@@ -3213,6 +3350,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     }
     n_gap = ctl[N_SEG];
     n_sparse = last_scan + last_cnt;
+    ctx->last_many_listed = sel_hi ? m : 0;
     if (sel_hi) { // the tiles' own slots are not counted by the segment counters: the directory's total is
       m = listed;
       if (listed > m_max) worst = std::max<uint64_t>(worst, listed / N_SEG + 1); // the compacted array was cut short
@@ -3341,6 +3479,15 @@ extern "C" int nts_sketch_select(nts_ctx* ctx, int impl)
   return NTS_OK;
 }
 
+extern "C" int nts_path_stats(nts_ctx* ctx, uint64_t* sketch_many_listed, uint64_t* bf_direct_indices, uint32_t* bf_list_fallback)
+{
+  if (!ctx) return NTS_EINVAL;
+  if (sketch_many_listed) *sketch_many_listed = ctx->last_many_listed;
+  if (bf_direct_indices) *bf_direct_indices = ctx->last_bf_direct;
+  if (bf_list_fallback) *bf_list_fallback = ctx->last_bf_fallback;
+  return NTS_OK;
+}
+
 extern "C" int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers, uint32_t* prune_c_used)
 {
   if (!ctx) return NTS_EINVAL;
@@ -3375,7 +3522,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   if (rc) return rc;
   const RunTable& rt = T->rt;
   nts_mx* mx = new nts_mx();
-  ctx->last_candidates = ctx->last_gaps = ctx->last_gap_kmers = 0;
+  ctx->last_candidates = ctx->last_gaps = ctx->last_gap_kmers = ctx->last_many_listed = 0;
   ctx->small_gap_path = true;
   if (rt.n_valid == 0 || T->n_win_tiles(w) == 0) {
     *out = mx;

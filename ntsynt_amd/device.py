@@ -81,6 +81,13 @@ class Context:
         self.last_prune_c = d.value
         return a.value, b.value, c.value
 
+    def path_stats(self):
+        """dict(sketch_many_listed, bf_direct_indices, bf_list_fallback): the repeat / fragmentation paths the last sketch and the
+        last partitioned Bloom build took (nts_path_stats)"""
+        a, b, c = u64(), u64(), ctypes.c_uint32()
+        self.check(self.lib.nts_path_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "nts_path_stats")
+        return {"sketch_many_listed": a.value, "bf_direct_indices": b.value, "bf_list_fallback": c.value}
+
     VALU_KINDS = ["v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64", "v_lshlrev_b64", "v_mul_lo_u32", "v_mad_u64_u32",
                   "v_add_co_u32+v_addc_co_u32", "v_xor_b32 (dependent chain)", "v_add3_u32", "v_cmp_ge_u32+v_addc_co_u32",
                   "roll31 step (9 instructions)"]
@@ -172,22 +179,28 @@ class Genome:
         return g
 
     @classmethod
-    def synth_plan(cls, ctx, plan, seed_ancestor, seed_genome, substitution_rate):
-        """Synthetic genome with structural events generated in HBM (nts_genome_synth_plan): `plan` = (record lengths,
-        pieces) from ntsynt_amd.synth.structural_plan; relatives share seed_ancestor and the ancestor's layout."""
-        rec_len, pieces = plan
+    def synth_plan(cls, ctx, plan, seed_ancestor, seed_genome, substitution_rate, rep=None, names=None):
+        """Synthetic genome with structural events generated in HBM (nts_genome_synth_plan[_ex]): `plan` = (record lengths,
+        pieces) from ntsynt_amd.synth.structural_plan / realistic_plan; relatives share seed_ancestor and the ancestor's layout.
+        rep: dict of nts_synth_repeats fields (synth.REPEATS) -- the assembly-like ancestor with interspersed repeats and
+        satellite arrays."""
+        rec_len, pieces = plan[0], plan[1]
         g = cls.__new__(cls)
         g.ctx = ctx
         rec_len = np.ascontiguousarray(rec_len, dtype=np.uint64)
         pieces = np.ascontiguousarray(pieces)
         assert pieces.dtype.itemsize == 32
-        g.names = [f"chr{i + 1}" for i in range(rec_len.size)]
+        g.names = list(names) if names is not None else [f"chr{i + 1}" for i in range(rec_len.size)]
         g.rec_len = rec_len
         g.rec_off = np.concatenate(([0], np.cumsum(rec_len[:-1]))).astype(np.uint64)
         g.n_bytes = int(rec_len.sum())
         h = c_vp()
-        ctx.check(ctx.lib.nts_genome_synth_plan(ctx.h, rec_len.size, rec_len.ctypes.data, pieces.size, pieces.ctypes.data,
-                                                int(seed_ancestor), int(seed_genome), float(substitution_rate), ctypes.byref(h)),
+        rp = None
+        if rep is not None:
+            rp = _lib.SynthRepeats(**{k_: int(v) for k_, v in rep.items()})
+        ctx.check(ctx.lib.nts_genome_synth_plan_ex(ctx.h, rec_len.size, rec_len.ctypes.data, pieces.size, pieces.ctypes.data,
+                                                   int(seed_ancestor), int(seed_genome), float(substitution_rate),
+                                                   ctypes.byref(rp) if rp is not None else None, ctypes.byref(h)),
                   "nts_genome_synth_plan")
         g.h = h
         return g
@@ -275,6 +288,11 @@ class BloomFilter:
     def insert(self, genome):
         "bf->insert(record.seq) for every record (cpp:128-131)"
         self.ctx.check(self.ctx.lib.nts_bf_insert(self.ctx.h, self.h, genome.h, self.k), "nts_bf_insert")
+
+    def insert_and(self, genome):
+        """one cascade level (cpp:134-160) in place: self &= the filter of `genome`, fused into the build's last pass
+        (nts_bf_insert_and) -- what clear + insert into a second filter + and_ give, without the second filter"""
+        self.ctx.check(self.ctx.lib.nts_bf_insert_and(self.ctx.h, self.h, genome.h, self.k), "nts_bf_insert_and")
 
     def cascade_from(self, prev, genome):
         "`if prev.contains(h): self.insert(h)` over every k-mer of genome (cpp:145-153)"

@@ -163,6 +163,9 @@ class GpuBackend:
     def bf_and(self, acc, other):
         acc.and_(other)
 
+    def bf_insert_and(self, acc, genome):
+        acc.insert_and(genome)
+
     def bf_clear(self, bf):
         bf.clear()
 
@@ -452,11 +455,16 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
             st.mark("bf_first_insert")
             if world == 1:
                 log(f"Bloom filter FPR: {backend.bf_fpr(bf)}")
-            if len(my_sorted) > 1:
+            if len(my_sorted) > 1 and hasattr(backend, "bf_insert_and"):
+                for p in my_sorted[1:]:
+                    backend.bf_insert_and(bf, genomes[p])       # bf &= G_i inside the build's last pass: AND == cascade level
+                    if world == 1:
+                        log(f"Bloom filter FPR: {backend.bf_fpr(bf)}")
+            elif len(my_sorted) > 1:                            # (test doubles)
                 tmp = backend.bf_new(nbytes, k)
                 for p in my_sorted[1:]:
                     backend.bf_clear(tmp)
-                    backend.bf_insert(tmp, genomes[p])          # G_i; AND == cascade level
+                    backend.bf_insert(tmp, genomes[p])
                     backend.bf_and(bf, tmp)
                     if world == 1:
                         log(f"Bloom filter FPR: {backend.bf_fpr(bf)}")

@@ -167,10 +167,10 @@ REVCOMP, NOVEL, NRUN = 1, 2, 4
 
 
 class _PieceTable:
-    "one contig as a list of [src, len, flags]"
+    "one contig as a list of [src, len, flags, family]"
 
     def __init__(self, src, length):
-        self.p = [[int(src), int(length), 0]]
+        self.p = [[int(src), int(length), 0, 0]]
 
     def size(self):
         return sum(x[1] for x in self.p)
@@ -178,15 +178,15 @@ class _PieceTable:
     def split(self, pos):
         "piece boundary at contig coordinate pos; returns the index of the piece that starts there"
         at = 0
-        for i, (src, ln, fl) in enumerate(self.p):
+        for i, (src, ln, fl, fam) in enumerate(self.p):
             if pos == at:
                 return i
             if pos < at + ln:
                 cut = pos - at
                 if fl & REVCOMP:        # a reversed piece reads its source backwards: the head of the piece is the tail of the source
-                    first, second = [src + ln - cut, cut, fl], [src, ln - cut, fl]
+                    first, second = [src + ln - cut, cut, fl, fam], [src, ln - cut, fl, fam]
                 else:
-                    first, second = [src, cut, fl], [src + cut, ln - cut, fl]
+                    first, second = [src, cut, fl, fam], [src + cut, ln - cut, fl, fam]
                 self.p[i:i + 1] = [first, second]
                 return i + 1
             at += ln
@@ -200,27 +200,27 @@ class _PieceTable:
         del self.p[i0:i1]
         return out
 
+    def copy(self, a, ln):
+        i0 = self.split(a)
+        i1 = self.split(a + ln)
+        return [list(x) for x in self.p[i0:i1]]
+
     def insert(self, a, pieces):
         i = self.split(a)
         self.p[i:i] = pieces
 
     def invert(self, a, ln):
         seg = self.cut(a, ln)
-        self.insert(a, [[s, n, f ^ REVCOMP] for s, n, f in reversed(seg)])
+        self.insert(a, _reversed_pieces(seg))
 
 
-def structural_plan(n_contigs, contig_bp, j, seed=BASE_SEED, inversions=5, translocations=2, indels=20, n_runs=False,
-                    indel_bp=None, micro=60, micro_bp=None, micro_shift=None, small_indels=200):
-    """(record lengths, pieces) of genome j of a family whose ancestor is n_contigs x contig_bp.  Sizes follow SURVEY.md 8(d) at
-    human scale (contigs of 125 Mbp) and shrink with the contigs below that; deterministic in (seed, j).
+def _reversed_pieces(seg):
+    return [[s_, n, f ^ REVCOMP, fam] for s_, n, f, fam in reversed(seg)]
 
-    On top of SURVEY's list: `micro` small rearrangements (a segment of micro_bp bases moved or copied up to micro_shift bases
-    away, or inverted in place -- bubbles, short blocks, and neighbouring collinear blocks for the merge rule) and
-    `small_indels` of 1-50 bases (neighbouring minimizers that are adjacent in some assemblies only: light edges for the last
-    round's erosion)."""
-    rng = np.random.Generator(np.random.PCG64(seed + 7919 * (j + 1)))
-    scale = min(1.0, contig_bp / 125e6)
-    tabs = [_PieceTable(c * contig_bp, contig_bp) for c in range(n_contigs)]
+
+def _structural_events_on_tables(tabs, rng, scale, inversions, translocations, indels, indel_bp, micro, micro_bp, micro_shift, small_indels):
+    "genome j's own events on its piece tables; returns the length of the genome's novel stream used"
+    n_contigs = len(tabs)
     novel = 0
     lo_i, hi_i = indel_bp or (max(30, int(1000 * scale)), max(120, int(60000 * scale)))
     for _ in range(inversions):
@@ -245,7 +245,7 @@ def structural_plan(n_contigs, contig_bp, j, seed=BASE_SEED, inversions=5, trans
         if rng.random() < 0.5:
             t.cut(at, ln)
         else:
-            t.insert(at, [[novel, ln, NOVEL]])
+            t.insert(at, [[novel, ln, NOVEL, 0]])
             novel += ln
     lo_m, hi_m = micro_bp or (max(40, int(2000 * scale)), max(80, int(20000 * scale)))
     shift = micro_shift or max(200, int(80000 * scale))
@@ -260,8 +260,7 @@ def structural_plan(n_contigs, contig_bp, j, seed=BASE_SEED, inversions=5, trans
             seg = t.cut(st, ln)
             t.insert(st + int(rng.integers(-shift, shift + 1)), seg)
         elif kind < 0.7:                        # copy
-            i0, i1 = t.split(st), t.split(st + ln)
-            seg = [list(x) for x in t.p[i0:i1]]
+            seg = t.copy(st, ln)
             t.insert(st + int(rng.integers(-shift, shift + 1)), seg)
         else:                                   # invert in place
             t.invert(st, ln)
@@ -274,8 +273,34 @@ def structural_plan(n_contigs, contig_bp, j, seed=BASE_SEED, inversions=5, trans
         if rng.random() < 0.5:
             t.cut(at, ln)
         else:
-            t.insert(at, [[novel, ln, NOVEL]])
+            t.insert(at, [[novel, ln, NOVEL, 0]])
             novel += ln
+    return novel
+
+
+def _pieces_array(rows):
+    pieces = np.zeros(len(rows), dtype=PIECE_DTYPE)
+    pieces["src"] = [r[0] for r in rows]
+    pieces["len"] = [r[1] for r in rows]
+    pieces["flags"] = [r[2] for r in rows]
+    pieces["reserved"] = [r[3] for r in rows]
+    pieces["dst"] = np.concatenate(([0], np.cumsum(pieces["len"][:-1]))).astype(np.uint64)
+    return pieces
+
+
+def structural_plan(n_contigs, contig_bp, j, seed=BASE_SEED, inversions=5, translocations=2, indels=20, n_runs=False,
+                    indel_bp=None, micro=60, micro_bp=None, micro_shift=None, small_indels=200):
+    """(record lengths, pieces) of genome j of a family whose ancestor is n_contigs x contig_bp.  Sizes follow SURVEY.md 8(d) at
+    human scale (contigs of 125 Mbp) and shrink with the contigs below that; deterministic in (seed, j).
+
+    On top of SURVEY's list: `micro` small rearrangements (a segment of micro_bp bases moved or copied up to micro_shift bases
+    away, or inverted in place -- bubbles, short blocks, and neighbouring collinear blocks for the merge rule) and
+    `small_indels` of 1-50 bases (neighbouring minimizers that are adjacent in some assemblies only: light edges for the last
+    round's erosion)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919 * (j + 1)))
+    scale = min(1.0, contig_bp / 125e6)
+    tabs = [_PieceTable(c * contig_bp, contig_bp) for c in range(n_contigs)]
+    _structural_events_on_tables(tabs, rng, scale, inversions, translocations, indels, indel_bp, micro, micro_bp, micro_shift, small_indels)
     if n_runs:                                  # 0.5 % of the bases in runs of 100-50,000 (scaled)
         for t in tabs:
             budget = int(0.005 * t.size())
@@ -285,16 +310,142 @@ def structural_plan(n_contigs, contig_bp, j, seed=BASE_SEED, inversions=5, trans
                     break
                 at = int(rng.integers(0, t.size() - ln))
                 t.cut(at, ln)
-                t.insert(at, [[0, ln, NRUN]])
+                t.insert(at, [[0, ln, NRUN, 0]])
                 budget -= ln
     rec_len = np.array([t.size() for t in tabs], dtype=np.uint64)
-    rows = [x for t in tabs for x in t.p]
-    pieces = np.zeros(len(rows), dtype=PIECE_DTYPE)
-    pieces["src"] = [r[0] for r in rows]
-    pieces["len"] = [r[1] for r in rows]
-    pieces["flags"] = [r[2] for r in rows]
-    pieces["dst"] = np.concatenate(([0], np.cumsum(pieces["len"][:-1]))).astype(np.uint64)
-    return rec_len, pieces
+    return rec_len, _pieces_array([x for t in tabs for x in t.p])
+
+
+# ---- the assembly-like family (BASELINE config 5 is quoted on human / chimp / bonobo assemblies, reference README.md:157; they are not
+# in the container) -------------------------------------------------------------------------------------------------------------------
+# What an i.i.d. ancestor lacks and a mammalian assembly has: interspersed repeat families in 10^5-10^6 copies (young copies share
+# k-mers: minimizers that occur twice within an assembly and are dropped by row C1, Bloom buckets that overflow, tiles that list
+# many equal candidates), satellite arrays, segmental duplications, thousands of scaffolds with a long tail shorter than a window,
+# N gaps at the joins, soft-masked (lower-case) repeats.  The repeat families are a function of the ancestor coordinate evaluated on
+# the device (include/ntsynt_hip.h nts_synth_repeats); satellite arrays, duplications, scaffolds and gaps are pieces of the plan.
+REPEATS = {
+    # SINE-like: 300-base elements, one per 1024-base cell in a third of the cells (~10 % of the sequence), four families
+    "sine_cell_log2": 10, "sine_len": 300, "sine_prob_256": 85, "sine_families": 4,
+    # LINE-like: the last 900-6000 bases of a 6 kbp consensus per 16384-base cell in 3/4 of the cells (~16 %), two families
+    "line_cell_log2": 14, "line_len": 6000, "line_min_len": 900, "line_prob_256": 192, "line_families": 2,
+    # a copy's divergence from its consensus: sixteen levels from 1 % to 20 %
+    "div_min_1024": 10, "div_max_1024": 205,
+    # satellites: 171-base unit, 2 % between units
+    "sat_unit": 171, "sat_div_1024": 20,
+}
+TANDEM = 8
+
+
+def _slice_rows(rows, starts, a, b):
+    "the rows (pieces) of a contig that cover [a, b) of its coordinates; starts = cumulative starts of rows (+ total at the end)"
+    import bisect
+    out = []
+    i = bisect.bisect_right(starts, a) - 1
+    while i < len(rows) and starts[i] < b:
+        src, ln, fl, fam = rows[i]
+        lo, hi = max(a, starts[i]), min(b, starts[i] + ln)
+        if hi > lo:
+            head, n = lo - starts[i], hi - lo
+            if fl & (NRUN | NOVEL) == NRUN:
+                out.append([0, n, fl, fam])
+            elif fl & REVCOMP:
+                out.append([src + ln - head - n, n, fl, fam])
+            else:
+                out.append([src + head, n, fl, fam])
+        i += 1
+    return out
+
+
+def realistic_plan(n_chrom, chrom_bp, j, seed=BASE_SEED, n_scaffolds=None, n_tail=None, n_gaps=None, segdups=None, sat_families=3,
+                   tail_bp=(200, 1500), **events):
+    """(record lengths, pieces, record names) of genome j of an assembly-like family: ancestor = n_chrom chromosomes of chrom_bp bases
+    with satellite arrays and segmental duplications (the same in every genome: seeded by `seed` alone), genome j = the ancestor with
+    structural_plan's events of its own, cut into n_scaffolds scaffolds plus n_tail short ones (tail_bp bases: most below w + k, so
+    they give no minimizer -- the long tail of unplaced scaffolds), with n_gaps N gaps inside the scaffolds.  Use with
+    Genome.synth_plan(..., rep=REPEATS)."""
+    total = n_chrom * chrom_bp
+    scale = min(1.0, chrom_bp / 125e6)
+    rng_a = np.random.Generator(np.random.PCG64(seed + 104729))           # the ancestor's events: shared by the family
+    tabs = [_PieceTable(c * chrom_bp, chrom_bp) for c in range(n_chrom)]
+    sat_cursor = [0] * sat_families
+    for t in tabs:                                                       # a centromere-like array + a few small ones per chromosome
+        sizes = [int(rng_a.uniform(0.5e6, 3e6) * scale)] + [int(rng_a.uniform(5e3, 5e4) * max(scale, 0.2)) for _ in range(3)]
+        for ln in sizes:
+            ln = max(ln, 20 * REPEATS["sat_unit"])
+            fam = int(rng_a.integers(0, sat_families))
+            at = int(rng_a.integers(1000, t.size() - 1000))
+            t.insert(at, [[sat_cursor[fam], ln, TANDEM, fam]])
+            sat_cursor[fam] += ln
+    n_sd = segdups if segdups is not None else max(12, int(round(300 * total / 3e9)))
+    sd_scale = max(scale, 0.1)
+    for _ in range(n_sd):                                                # segmental duplications: 10-100 kbp, a third inverted
+        a = int(rng_a.integers(0, n_chrom))
+        ln = int(rng_a.uniform(1e4, 1e5) * sd_scale)
+        if tabs[a].size() < 8 * ln:
+            continue
+        st = int(rng_a.integers(ln, tabs[a].size() - 2 * ln))
+        seg = tabs[a].copy(st, ln)
+        if rng_a.random() < 0.33:
+            seg = _reversed_pieces(seg)
+        if rng_a.random() < 0.7:                                         # nearby on the same chromosome
+            b = a
+            dst = int(np.clip(st + rng_a.integers(-int(5e6 * sd_scale), int(5e6 * sd_scale) + 1), ln, tabs[b].size() - ln))
+        else:
+            b = int(rng_a.integers(0, n_chrom))
+            dst = int(rng_a.integers(ln, tabs[b].size() - ln))
+        tabs[b].insert(dst, seg)
+    # genome j's own events
+    rng = np.random.Generator(np.random.PCG64(seed + 7919 * (j + 1)))
+    ev = dict(inversions=5, translocations=2, indels=20, indel_bp=None, micro=60, micro_bp=None, micro_shift=None, small_indels=200)
+    ev.update(events)
+    _structural_events_on_tables(tabs, rng, scale, **ev)
+    # scaffolds, the tail of short ones, N gaps: positions in the chromosomes as they stand now, one pass per chromosome
+    n_scaffolds = n_scaffolds if n_scaffolds is not None else [600, 1500, 4000][j % 3]
+    n_tail = n_tail if n_tail is not None else n_scaffolds
+    n_gaps = n_gaps if n_gaps is not None else 2 * n_scaffolds
+    sizes = np.array([t.size() for t in tabs], dtype=np.int64)
+    csum = np.concatenate(([0], np.cumsum(sizes)))
+
+    def draw(n):
+        g = np.sort(rng.integers(0, int(csum[-1]), size=int(n)))
+        c = np.searchsorted(csum, g, side="right") - 1
+        return c, g - csum[c]
+    events_by_chrom = [[] for _ in range(n_chrom)]
+    for c, x in zip(*draw(max(0, n_scaffolds - n_chrom))):
+        events_by_chrom[int(c)].append((int(x), 0, "cut"))
+    lo_t, hi_t = tail_bp
+    for (c, x), ln in zip(zip(*draw(n_tail)), rng.integers(lo_t, hi_t + 1, size=n_tail)):
+        events_by_chrom[int(c)].append((int(x), int(ln), "tail"))
+    gap_len = np.where(rng.random(n_gaps) < 0.6, 100, rng.integers(10, 5001, size=n_gaps))
+    gap_del = rng.integers(0, 2001, size=n_gaps)
+    for (c, x), gl, gd in zip(zip(*draw(n_gaps)), gap_len, gap_del):
+        events_by_chrom[int(c)].append((int(x), int(gd), ("gap", int(gl))))
+    records, tails = [], []
+    for c, t in enumerate(tabs):
+        rows = t.p
+        starts = [0]
+        for r in rows:
+            starts.append(starts[-1] + r[1])
+        size = starts[-1]
+        cur, at = [], 0
+        for x, ln, kind in sorted(events_by_chrom[c], key=lambda e: e[0]):
+            if x < at + 50 or x + ln + 50 > size:                        # overlaps the event before, or the chromosome's end: dropped
+                continue
+            cur += _slice_rows(rows, starts, at, x)
+            if kind == "cut":
+                records.append(cur)
+                cur = []
+            elif kind == "tail":
+                tails.append(_slice_rows(rows, starts, x, x + ln))
+            else:
+                cur.append([0, kind[1], NRUN, 0])
+            at = x + ln
+        cur += _slice_rows(rows, starts, at, size)
+        records.append(cur)
+    records = [r for r in records if sum(x[1] for x in r) > 0] + tails
+    rec_len = np.array([sum(x[1] for x in r) for r in records], dtype=np.uint64)
+    names = [f"scaffold_{i + 1}" for i in range(len(records))]
+    return rec_len, _pieces_array([x for r in records for x in r]), names
 
 
 def _mix64(x):
@@ -309,9 +460,61 @@ def _mix64(x):
     return x
 
 
-def plan_bases(plan, seed_ancestor, seed_genome, substitution_rate):
-    """What nts_genome_synth_plan generates, evaluated with numpy (tests only: small plans): codes 0..3 = A, C, G, T, 4 = N."""
-    rec_len, pieces = plan
+_PHI, _C2, _CELL = np.uint64(0x9E3779B97F4A7C15), np.uint64(0xD1B54A32D192ED03), np.uint64(0xA24BAED4963EE407)
+_SALT_LINE, _SALT_SINE, _SALT_SAT = 0x4C494E454C494E45, 0x53494E4553494E45, 0x5341544553415445
+
+
+def _layer(base, s, seed, salt, cell_log2, len_full, len_min, prob, nfam, div_min, div_max):
+    "csrc/ntsynt_hip.hip synth_layer on arrays: overwrite `base` where ancestor coordinate s lies in a repeat copy of this layer"
+    if prob == 0:
+        return
+    u = np.uint64
+    cell = s >> u(cell_log2)
+    o = (s & u((1 << cell_log2) - 1)).astype(np.int64)
+    h = _mix64(u(seed ^ salt) + cell * _CELL)
+    ln = len_min + (((h >> u(8)) & u(0xFFFF)) % u(len_full - len_min + 1)).astype(np.int64)
+    off = (((h >> u(24)) & u(0xFFFFF)).astype(np.int64)) % ((1 << cell_log2) - ln + 1)
+    hit = ((h & u(255)) < u(prob)) & (o >= off) & (o < off + ln)
+    if not hit.any():
+        return
+    idx = (o - off)[hit]
+    hh, ss, ll = h[hit], s[hit], ln[hit]
+    fam = ((hh >> u(44)) & u(0xFF)) % u(nfam)
+    rev = ((hh >> u(52)) & u(1)).astype(bool)
+    lvl = ((hh >> u(53)) & u(15)).astype(np.int64)
+    div = div_min + lvl * (div_max - div_min) // 15
+    ci = np.where(rev, len_full - 1 - idx, len_full - ll + idx).astype(np.uint64)
+    cb = _mix64(u(seed ^ salt ^ 0x5555555555555555) + ((fam << u(32)) + ci) * _PHI) & u(3)
+    cb = np.where(rev, u(3) - cb, cb)
+    y = _mix64(u(seed ^ salt ^ 0xAAAAAAAAAAAAAAAA) + ss * _C2)
+    sub = (cb + u(1) + (y >> u(32)) % u(3)) & u(3)
+    base[hit] = np.where((y & u(1023)).astype(np.int64) < div, sub, cb)
+
+
+def _anc_bases(s, seed_anc, rep):
+    "ancestor base at coordinates s (uint64 array): synth_ancestor_base"
+    with np.errstate(over="ignore"):
+        base = _mix64(np.uint64(seed_anc) + s * _PHI) & np.uint64(3)
+        if rep:
+            _layer(base, s, seed_anc, _SALT_LINE, rep["line_cell_log2"], rep["line_len"], rep["line_min_len"], rep["line_prob_256"], rep["line_families"],
+                   rep["div_min_1024"], rep["div_max_1024"])
+            _layer(base, s, seed_anc, _SALT_SINE, rep["sine_cell_log2"], rep["sine_len"], rep["sine_len"], rep["sine_prob_256"], rep["sine_families"],
+                   rep["div_min_1024"], rep["div_max_1024"])
+    return base
+
+
+def _tandem_bases(s, fam, seed_anc, rep):
+    u = np.uint64
+    with np.errstate(over="ignore"):
+        b = _mix64(u(seed_anc ^ _SALT_SAT) + (u(fam << 32) + s % u(rep["sat_unit"])) * _PHI) & u(3)
+        y = _mix64(u(seed_anc ^ _SALT_SAT ^ 0xAAAAAAAAAAAAAAAA) + (u(fam << 40) ^ s) * _C2)
+        sub = (b + u(1) + (y >> u(32)) % u(3)) & u(3)
+    return np.where((y & u(1023)) < u(rep["sat_div_1024"]), sub, b)
+
+
+def plan_bases(plan, seed_ancestor, seed_genome, substitution_rate, rep=None):
+    """What nts_genome_synth_plan[_ex] generates, evaluated with numpy (tests only: small plans): codes 0..3 = A, C, G, T, 4 = N."""
+    rec_len, pieces = plan[0], plan[1]
     n = int(rec_len.sum())
     out = np.empty(n, dtype=np.uint8)
     thr = np.uint64(int(substitution_rate * 4294967296.0))
@@ -325,8 +528,10 @@ def plan_bases(plan, seed_ancestor, seed_genome, substitution_rate):
             sidx = (np.uint64(src + ln - 1) - off) if fl & REVCOMP else (np.uint64(src) + off)
             if fl & NOVEL:
                 base = _mix64(np.uint64(seed_genome ^ 0x5bd1e995a7c3f1d7) + sidx * np.uint64(0x9E3779B97F4A7C15)) & np.uint64(3)
+            elif fl & TANDEM:
+                base = _tandem_bases(sidx, int(pc["reserved"]), seed_ancestor, rep)
             else:
-                base = _mix64(np.uint64(seed_ancestor) + sidx * np.uint64(0x9E3779B97F4A7C15)) & np.uint64(3)
+                base = _anc_bases(sidx, seed_ancestor, rep)
             if fl & REVCOMP:
                 base = np.uint64(3) - base
             i = np.uint64(d) + off

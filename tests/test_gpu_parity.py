@@ -140,6 +140,73 @@ def test_bloom_binned_build_equals_atomic_and_oracle(ctx, nbytes, monkeypatch):
 
 
 
+@pytest.mark.parametrize("nbytes", [3 << 20, 100 << 20])   # 24 final buckets (one partition level) / 800 (two levels)
+def test_bloom_fused_and_equals_insert_then_and_and_the_oracle_cascade(ctx, nbytes, monkeypatch):
+    """nts_bf_insert_and (the cascade level of cpp:134-160 as acc &= G inside the partitioned build's last pass) against insert
+    into a second filter + nts_bf_and, against the literal cascade kernel and against the oracle's cascade -- on records whose
+    repeats overflow their buckets (the copies of a k-mer park ONE index and the bit comes back after the AND), with tiles in
+    pieces, with the parking list cut short (the device gives up, restores the running filter, the level is redone the plain
+    way), on a running filter so sparse that slices are skipped, and on all-ones / all-zero running filters."""
+    from ntsynt_amd.device import BloomFilter
+    k = 24
+    rng = np.random.default_rng(2024)
+    names, seqs = _family(81, lengths=[400000, 0, 30, 250000, 12000, 90001], n_frac=0.0002)
+    rep = [b"ACGTTGCA" * 40000, b"A" * 300000]
+    seqs_a = list(seqs) + rep
+    # a relative: the same records at 2 % divergence (+ the same repeats, so that overflowing bits ARE in the running filter)
+    seqs_b = []
+    for s_ in seqs:
+        a = np.frombuffer(s_, dtype=np.uint8).copy()
+        hit = (rng.random(a.size) < 0.02) & (a != ord("N"))
+        a[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+        seqs_b.append(a.tobytes())
+    seqs_b += rep
+    seqs_c = [seqs_b[0][:200000], b"ACGTTGCA" * 20000]        # a third genome: little in common, the repeat again
+    fam = []
+    for sq in (seqs_a, seqs_b, seqs_c):
+        nm = [f"r{i}" for i in range(len(sq))]
+        fam.append((to_oracle(nm, sq), to_device(ctx, nm, sq)))
+    o = O.bf_build(fam[0][0], k, nbytes)
+    levels = [o]
+    for og, _ in fam[1:]:
+        o = O.bf_build(og, k, nbytes, prev=o)
+        levels.append(o)
+    assert 0 < int(np.unpackbits(levels[2]).sum()) < int(np.unpackbits(levels[1]).sum()) < int(np.unpackbits(levels[0]).sum())
+    try:
+        for mode in ("binned", "binned list full", "binned unfused", "atomic", "auto"):
+            ctx.bf_build_mode(mode.split()[0])
+            monkeypatch.delenv("NTS_BIN_LATE_CAP", raising=False)
+            monkeypatch.delenv("NTS_BIN_FUSED_AND", raising=False)
+            if mode == "binned list full":
+                monkeypatch.setenv("NTS_BIN_LATE_CAP", "3")
+            if mode == "binned unfused":
+                monkeypatch.setenv("NTS_BIN_FUSED_AND", "0")
+            acc = BloomFilter(ctx, nbytes, k)
+            acc.insert(fam[0][1])
+            for lvl, (_, dg) in enumerate(fam[1:], start=1):
+                if lvl == 2:
+                    acc.popcount()               # the library now knows how sparse the running filter is (slice-skipping path)
+                acc.insert_and(dg)
+                assert np.array_equal(acc.to_numpy(), levels[lvl]), (mode, lvl)
+                st = ctx.path_stats()
+                if mode == "binned":
+                    assert st["bf_direct_indices"] > 0 and st["bf_list_fallback"] == 0, st
+                if mode == "binned list full" and lvl == 1:
+                    assert st["bf_list_fallback"] == 1, st
+            assert acc.popcount() == int(np.unpackbits(levels[2]).sum())
+            # identities of AND: all ones -> the genome's own filter; all zeros stay zeros
+            ones = BloomFilter(ctx, nbytes, k, ones=True)
+            ones.insert_and(fam[1][1])
+            assert np.array_equal(ones.to_numpy(), O.bf_build(fam[1][0], k, nbytes)), mode
+            zero = BloomFilter(ctx, nbytes, k)
+            zero.insert_and(fam[1][1])
+            assert zero.popcount() == 0, mode
+            for f in (acc, ones, zero):
+                f.free()
+    finally:
+        ctx.bf_build_mode("auto")
+
+
 @pytest.mark.parametrize("k,w", [(24, 1000), (24, 100), (20, 10), (24, 1), (32, 17), (24, 16), (24, 15),
                                  (24, 4097), (20, 250)])
 def test_sketch_no_filter(ctx, k, w):

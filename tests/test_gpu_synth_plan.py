@@ -96,3 +96,103 @@ def test_pipeline_on_a_structural_family_matches_the_oracle(ctx, tmp_path, monke
     print(eng.stats)
     assert eng.stats["indel_cuts"] > 0 and eng.stats["merged"] > 0 and eng.stats["eroded_edges"] > 0 and eng.stats["bubbles"] > 0, eng.stats
     assert len(text.splitlines()) // 3 >= 10
+
+
+# ---- the assembly-like family (BASELINE config 5 stands on mammalian assemblies, which are not in the container) -----------------
+def test_assembly_like_family_equals_its_plan(ctx):
+    """nts_genome_synth_plan_ex (interspersed repeat families as a function of the ancestor coordinate, satellite arrays, segmental
+    duplications, scaffolds with a tail of short ones, N gaps) against synth.plan_bases, the numpy statement of the same generator"""
+    from ntsynt_amd.device import Genome
+    for j in range(3):
+        plan = synth.realistic_plan(3, 700_000, j, seed=17, n_scaffolds=12 + 9 * j, n_tail=15, n_gaps=20)
+        rec_len, pieces, names = plan
+        assert (pieces["flags"] & synth.TANDEM).any() and (pieces["flags"] & synth.NRUN).any() and (pieces["flags"] & synth.REVCOMP).any()
+        g = Genome.synth_plan(ctx, plan, 17, 1000 + j, 0.0065, rep=synth.REPEATS, names=names)
+        assert g.total_bp == int(rec_len.sum()) and len(g.names) == rec_len.size
+        got = g.download(0, g.total_bp)
+        exp = CODES[synth.plan_bases(plan, 17, 1000 + j, 0.0065, rep=synth.REPEATS)]
+        assert np.array_equal(got, exp), j
+        g.free()
+    # the ancestor really is repetitive: a 24-mer drawn from a young SINE copy occurs many times
+    anc = synth.plan_bases((np.array([400_000], dtype=np.uint64), synth._pieces_array([[0, 400_000, 0, 0]])), 17, 1, 0.0, rep=synth.REPEATS)
+    kmers = np.lib.stride_tricks.sliding_window_view(anc, 24)[::7]
+    packed = (kmers.astype(np.uint64) << (2 * np.arange(24, dtype=np.uint64))).sum(axis=1)
+    _, counts = np.unique(packed, return_counts=True)
+    assert counts.max() >= 3, counts.max()
+
+
+_ORACLE_RUNS = {}
+
+
+def _assembly_like_files(ctx, tmp_path, n_chrom, chrom_bp, seed, scaffolds):
+    import bench
+    from ntsynt_amd.device import Genome
+    paths, dup = [], []
+    for j in range(3):
+        plan = synth.realistic_plan(n_chrom, chrom_bp, j, seed=seed, n_scaffolds=scaffolds[j], n_tail=scaffolds[j], n_gaps=2 * scaffolds[j])
+        g = Genome.synth_plan(ctx, plan, seed, 1000 + j, 0.0065, rep=synth.REPEATS, names=plan[2])        # 1.3 % pairwise
+        p = str(tmp_path / f"asm{j}.fa")
+        bench.write_fasta_from_device(g, p, soft_mask_seed=4000 + j, half_lower=True, line_width=(0, 80, 61)[j])
+        g.free()
+        paths.append(p)
+    return paths
+
+
+@pytest.mark.parametrize("batch", [True, False])
+def test_pipeline_on_an_assembly_like_family_matches_the_oracle(ctx, tmp_path, monkeypatch, batch):
+    """BASELINE config 5's parameter set (ntSynt -d 1.3: w 1000, --w_rounds 250 100, indel 50000, merge 100000, block 1000;
+    /root/reference bin/ntSynt:92-94, README.md:157) on three assembly-like genomes of ~56 Mbp: FASTA files (half the bases lower
+    case, one single-line, two wrapped) -> minimizer TSVs and both synteny TSVs byte-identical to the oracle pipeline's, through the
+    one-batch sketch and through one launch sequence per genome; and the run went where an i.i.d. family never goes: minimizers
+    that occur twice within an assembly (row C1's drop), Bloom buckets that overflow, select tiles that list more than their
+    slots hold."""
+    from ntsynt_amd import pipeline
+    monkeypatch.setenv("NTS_BATCH_BELOW_BP", str(1 << 30) if batch else "0")
+    monkeypatch.setattr(pipeline.GpuBackend, "BATCH_BELOW_BP", (1 << 30) if batch else 0)
+    paths = _assembly_like_files(ctx, tmp_path, 6, 9_000_000, 23, (40, 150, 400))
+    kw = dict(k=24, w=1000, w_rounds=[250, 100], indel=50000, merge=100000, block_size=1000, prefix="c5")
+    seen = {"direct": 0, "many": 0}
+    real_insert_and, real_sketch_dev = pipeline.GpuBackend.bf_insert_and, pipeline.GpuBackend.sketch_dev
+
+    def spy_insert_and(self, acc, genome):
+        real_insert_and(self, acc, genome)
+        seen["direct"] += self.ctx.path_stats()["bf_direct_indices"]
+
+    def spy_sketch_dev(self, *a, **k_):
+        out = real_sketch_dev(self, *a, **k_)
+        seen["many"] += self.ctx.path_stats()["sketch_many_listed"]
+        return out
+    monkeypatch.setattr(pipeline.GpuBackend, "bf_insert_and", spy_insert_and)
+    monkeypatch.setattr(pipeline.GpuBackend, "sketch_dev", spy_sketch_dev)
+    cwd = os.getcwd()
+    try:
+        os.makedirs(tmp_path / "hip")
+        os.makedirs(tmp_path / "ora")
+        os.chdir(tmp_path / "hip")
+        eng = pipeline.run(paths, log=lambda *a: None, ctx=ctx, **kw)
+        hip_files = {n: open(n, "rb").read() for n in os.listdir(".") if n.endswith(".tsv") or n.endswith(".fai")}
+        os.chdir(tmp_path / "ora")
+        if "c5" not in _ORACLE_RUNS:              # (the family is deterministic: the oracle runs once for both parametrisations)
+            ora = SO.run_pipeline(paths, threads=8, **kw)
+            _ORACLE_RUNS["c5"] = (dict(ora.outputs), {n: open(n, "rb").read() for n in os.listdir(".") if n.endswith(".tsv")})
+        ora_outputs, ora_files = _ORACLE_RUNS["c5"]
+    finally:
+        os.chdir(cwd)
+    for name in ("c5.synteny_blocks.tsv", "c5.pre-collinear-merge.synteny_blocks.tsv"):
+        assert eng.outputs[name] == ora_outputs[name], name
+    mx = sorted(n for n in ora_files if ".k24.w1000.tsv" in n)
+    assert len(mx) == 3
+    for n in mx:
+        assert hip_files[n] == ora_files[n], n
+    # what the uniform family never reaches
+    dups = 0
+    for n in mx:
+        hashes = np.array([int(tok.split(":")[0]) for line in ora_files[n].decode().splitlines() for tok in line.split("\t")[1].split(" ") if tok],
+                          dtype=np.uint64)
+        _, cnt = np.unique(hashes, return_counts=True)
+        dups += int((cnt > 1).sum())
+    print("assembly-like family:", eng.stats, "duplicated minimizer hashes within an assembly:", dups, seen)
+    assert dups > 0, "no minimizer occurs twice within an assembly"
+    assert seen["direct"] > 0, "no Bloom bucket overflowed / no lane in pieces"
+    assert len(eng.outputs["c5.synteny_blocks.tsv"].splitlines()) // 3 >= 20
+    assert eng.stats["small_blocks"] > 0 and eng.stats["merged"] > 0, eng.stats
