@@ -357,7 +357,7 @@ def _slice_rows(rows, starts, a, b):
 
 
 def realistic_plan(n_chrom, chrom_bp, j, seed=BASE_SEED, n_scaffolds=None, n_tail=None, n_gaps=None, segdups=None, sat_families=3,
-                   tail_bp=(200, 1500), **events):
+                   tail_bp=(200, 1500), sat_scale=None, **events):
     """(record lengths, pieces, record names) of genome j of an assembly-like family: ancestor = n_chrom chromosomes of chrom_bp bases
     with satellite arrays and segmental duplications (the same in every genome: seeded by `seed` alone), genome j = the ancestor with
     structural_plan's events of its own, cut into n_scaffolds scaffolds plus n_tail short ones (tail_bp bases: most below w + k, so
@@ -369,7 +369,9 @@ def realistic_plan(n_chrom, chrom_bp, j, seed=BASE_SEED, n_scaffolds=None, n_tai
     tabs = [_PieceTable(c * chrom_bp, chrom_bp) for c in range(n_chrom)]
     sat_cursor = [0] * sat_families
     for t in tabs:                                                       # a centromere-like array + a few small ones per chromosome
-        sizes = [int(rng_a.uniform(0.5e6, 3e6) * scale)] + [int(rng_a.uniform(5e3, 5e4) * max(scale, 0.2)) for _ in range(3)]
+        # (sat_scale: tests keep the arrays near their human size in a small genome, so that the copies of a unit overflow a bucket)
+        sizes = [int(rng_a.uniform(0.5e6, 3e6) * (scale if sat_scale is None else sat_scale))] + \
+                [int(rng_a.uniform(5e3, 5e4) * max(scale, 0.2)) for _ in range(3)]
         for ln in sizes:
             ln = max(ln, 20 * REPEATS["sat_unit"])
             fam = int(rng_a.integers(0, sat_families))

@@ -129,7 +129,7 @@ def _assembly_like_files(ctx, tmp_path, n_chrom, chrom_bp, seed, scaffolds):
     from ntsynt_amd.device import Genome
     paths, dup = [], []
     for j in range(3):
-        plan = synth.realistic_plan(n_chrom, chrom_bp, j, seed=seed, n_scaffolds=scaffolds[j], n_tail=scaffolds[j], n_gaps=2 * scaffolds[j])
+        plan = synth.realistic_plan(n_chrom, chrom_bp, j, seed=seed, n_scaffolds=scaffolds[j], n_tail=scaffolds[j], n_gaps=2 * scaffolds[j], sat_scale=0.4, indel_bp=(1000, 90000))
         g = Genome.synth_plan(ctx, plan, seed, 1000 + j, 0.0065, rep=synth.REPEATS, names=plan[2])        # 1.3 % pairwise
         p = str(tmp_path / f"asm{j}.fa")
         bench.write_fasta_from_device(g, p, soft_mask_seed=4000 + j, half_lower=True, line_width=(0, 80, 61)[j])
@@ -195,4 +195,5 @@ def test_pipeline_on_an_assembly_like_family_matches_the_oracle(ctx, tmp_path, m
     assert dups > 0, "no minimizer occurs twice within an assembly"
     assert seen["direct"] > 0, "no Bloom bucket overflowed / no lane in pieces"
     assert len(eng.outputs["c5.synteny_blocks.tsv"].splitlines()) // 3 >= 20
-    assert eng.stats["small_blocks"] > 0 and eng.stats["merged"] > 0, eng.stats
+    assert seen["many"] > 0, "no select tile listed more candidates than its slots hold"
+    assert eng.stats["small_blocks"] > 0 and eng.stats["merged"] > 0 and eng.stats["bubbles"] > 0 and eng.stats["indel_cuts"] > 0, eng.stats
