@@ -79,6 +79,10 @@ def parse():
     ap.add_argument("--at-once", action="store_true", help="the timed steps sketch the genomes of a GPU at once (device.SketchPool) "
                                                            "instead of one after the other (an experiment: DESIGN.md section 8)")
     ap.add_argument("--substitutions-only", action="store_true", help="genomes differ by substitutions only (round 2's family)")
+    ap.add_argument("--family", choices=["structural", "assembly-like"], default="structural",
+                    help="assembly-like: ntsynt_amd.synth.realistic_plan + REPEATS (interspersed repeat families, satellite arrays, segmental "
+                         "duplications, thousands of scaffolds with a tail of short ones, N gaps) -- the family of the c5_like leg, for every leg")
+    ap.add_argument("--no-c5-leg", action="store_true")
     ap.add_argument("--e2e-dir", default=None, help="where the e2e leg writes its FASTA files [a temp dir]")
     return ap.parse_args()
 
@@ -234,12 +238,14 @@ def cpu_baseline(k, w, fpr, sample, bf_np, budget_s=20.0, e2e_slices=None, e2e_p
         }
     if e2e_slices:
         stages["end_to_end_sample"] = cpu_e2e_sample(k, w, fpr, e2e_slices, e2e_par, cores)
-        try:                                   # and the one full-size run on record (scripts/e2e_oracle_check.py)
-            rec = json.load(open(ORACLE_RECORD))
-            stages["end_to_end_full_size_on_record"] = {"seconds": rec["oracle_seconds"], "threads": rec["oracle_threads"], "key": rec["key"],
-                                                        "source": "profiles/r03_e2e_oracle.json"}
-        except (OSError, ValueError, KeyError):
-            pass
+        for path in ORACLE_RECORDS:            # and the full-size runs on record (scripts/e2e_oracle_check.py)
+            try:
+                rec = json.load(open(path))
+                stages.setdefault("end_to_end_full_size_on_record", []).append(
+                    {"seconds": rec["oracle_seconds"], "threads": rec["oracle_threads"], "key": rec["key"], "peak_host_rss_bytes": rec.get("oracle_peak_rss_bytes"),
+                     "source": os.path.relpath(path, ROOT)})
+            except (OSError, ValueError, KeyError):
+                pass
     return {"value": stages["all_cores"]["sketch_Gbases_s"], "unit": "Gbases/s", "cores": cores, "kind": "port",
             "cpu_model": cpu_model(), "logical_cpus_visible": os.cpu_count(), "stages": stages,
             "sample": f"first {sample.size / 1e6:.0f} Mbp of genome 0 read back from HBM, cut into 4 records per thread "
@@ -253,6 +259,9 @@ def family_genome(ctx, args, total_bp, contigs, j, rate, n_runs=False):
     "genome j of the bench family, generated in HBM"
     from ntsynt_amd import synth
     from ntsynt_amd.device import Genome
+    if getattr(args, "family", "structural") == "assembly-like":
+        plan = synth.realistic_plan(contigs, int(total_bp) // contigs, j, ANCESTOR_SEED)
+        return Genome.synth_plan(ctx, plan, ANCESTOR_SEED, 1000 + j, rate, rep=synth.REPEATS, names=plan[2])
     if args.substitutions_only and not n_runs:
         return Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + j, rate)
     plan = synth.structural_plan(contigs, int(total_bp) // contigs, j, ANCESTOR_SEED, n_runs=n_runs,
@@ -264,6 +273,8 @@ def family_genome(ctx, args, total_bp, contigs, j, rate, n_runs=False):
 def family_bases(args, n_fam, total_bp, contigs):
     "bases of every genome of the family (the plans are cheap: no device work)"
     from ntsynt_amd import synth
+    if getattr(args, "family", "structural") == "assembly-like":
+        return [int(synth.realistic_plan(contigs, int(total_bp) // contigs, j, ANCESTOR_SEED)[0].sum()) for j in range(n_fam)]
     if args.substitutions_only:
         return [int(total_bp) // contigs * contigs] * n_fam
     return [int(synth.structural_plan(contigs, int(total_bp) // contigs, j, ANCESTOR_SEED)[0].sum()) for j in range(n_fam)]
@@ -308,13 +319,27 @@ def write_fasta_from_device(g, path, chunk=1 << 28, soft_mask_seed=None, half_lo
                 fh.write(b"\n")
 
 
-ORACLE_RECORD = os.path.join(ROOT, "profiles", "r03_e2e_oracle.json")       # written by scripts/e2e_oracle_check.py
+ORACLE_RECORDS = [os.path.join(ROOT, "profiles", n) for n in ("r04_e2e_oracle_c5_like.json", "r03_e2e_oracle.json")]   # scripts/e2e_oracle_check.py
+
+
+def oracle_record(key):
+    "the full-size oracle run on record for this family + parameter set (None: none)"
+    for path in ORACLE_RECORDS:
+        try:
+            rec = json.load(open(path))
+            if rec.get("key") == key:
+                return rec, os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def e2e_key(args, n_fam, total_bp, contigs, div):
     "identity of an e2e family + parameter set (the oracle's recorded md5 applies to exactly this)"
-    return (f"{n_fam}x{total_bp}bp/{contigs}contigs/div{div:g}/k{args.k}/w{args.w}/fpr{args.fpr}/seed{ANCESTOR_SEED}/"
-            f"{'substitutions-only' if args.substitutions_only else 'structural+softmask'}")
+    fam = "substitutions-only" if args.substitutions_only else "structural+softmask"
+    if getattr(args, "family", "structural") == "assembly-like":
+        fam = "assembly-like(repeat families+satellites+segdups+scaffold tail+N gaps)+half-lower"
+    return f"{n_fam}x{total_bp}bp/{contigs}contigs/div{div:g}/k{args.k}/w{args.w}/fpr{args.fpr}/seed{ANCESTOR_SEED}/{fam}"
 
 
 def e2e_inputs(args, device, n_fam, total_bp, contigs, div, workdir):
@@ -325,7 +350,10 @@ def e2e_inputs(args, device, n_fam, total_bp, contigs, div, workdir):
     for j in range(n_fam):
         g = family_genome(ctx, args, total_bp, contigs, j, div / 2.0)
         p = os.path.join(workdir, f"syn{j}.fa")
-        write_fasta_from_device(g, p, soft_mask_seed=None if args.substitutions_only else 4000 + j)
+        if getattr(args, "family", "structural") == "assembly-like":
+            write_fasta_from_device(g, p, soft_mask_seed=4000 + j, half_lower=True)
+        else:
+            write_fasta_from_device(g, p, soft_mask_seed=None if args.substitutions_only else 4000 + j)
         g.free()
         paths.append(p)
     ctx.close()
@@ -372,13 +400,10 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
     # the oracle pipeline's output for this very family, recorded once on the GPU box's host cores (tens of minutes of CPU):
     # scripts/e2e_oracle_check.py -> profiles/r03_e2e_oracle.json
     oracle = {"oracle_md5": None, "oracle_checked": "no record for this family (scripts/e2e_oracle_check.py makes one)"}
-    try:
-        rec = json.load(open(ORACLE_RECORD))
-        if rec.get("key") == e2e_key(args, n_fam, total_bp, contigs, div):
-            oracle = {"oracle_md5": rec["oracle_md5"], "oracle_checked": "identical" if rec["oracle_md5"] == md5 else "DIFFERENT",
-                      "oracle_record": "profiles/r03_e2e_oracle.json"}
-    except (OSError, ValueError, KeyError):
-        pass
+    rec, rec_path = oracle_record(e2e_key(args, n_fam, total_bp, contigs, div))
+    if rec is not None:
+        oracle = {"oracle_md5": rec["oracle_md5"], "oracle_checked": "identical" if rec["oracle_md5"] == md5 else "DIFFERENT",
+                  "oracle_record": rec_path, "oracle_seconds_on_record": rec.get("oracle_seconds"), "oracle_threads_on_record": rec.get("oracle_threads")}
     return {**extra, "graph_stage": type(eng).__name__, "engine_stats": eng.stats,
             "what": f"{len(paths)} FASTA files on disk -> final synteny TSV (ntSynt -d {divergence_pct:g}: w_rounds {a.w_rounds}, "
                     f"indel {a.indel}, merge {a.merge}, block {a.block_size}), one GPU, files in the page cache",
@@ -392,6 +417,86 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
             "peak_hbm_bytes": (eng.memory or {}).get("peak_hbm_bytes"), "peak_host_rss_bytes": (eng.memory or {}).get("peak_host_rss_bytes"),
             "hbm_live_at_marks_GB": {n: round(v / 1e9, 2) for n, v in ((eng.memory or {}).get("hbm_live_at_marks") or {}).items()},
             "write_inputs_s": round(t_write, 1)}
+
+
+def c5_like_leg(args, ctx, device, total_bp, contigs, workdir):
+    """BASELINE configs[4] stands on three real mammalian assemblies (human / chimp / bonobo, -d 1.3; reference README.md:157), which are
+    not in the container.  This leg runs its parameter set on the assembly-like synthetic family instead (ntsynt_amd/synth.py
+    realistic_plan + REPEATS: interspersed repeat families in ~10^6 copies at 1-20 % from their consensus, satellite arrays, segmental
+    duplications, 600 / 1500 / 4000 scaffolds per genome + as many short ones, N gaps, half of the bases lower case in the files):
+    Bloom build, sketch, and FASTA files -> final TSV, with the paths an i.i.d. family never takes counted."""
+    import copy
+    from ntsynt_amd.device import BloomFilter, bf_size_bytes, sketch
+    a5 = copy.copy(args)
+    a5.family, a5.substitutions_only = "assembly-like", False
+    div, k, w = 0.013, args.k, args.w
+    t0 = time.time()
+    gens = [family_genome(ctx, a5, total_bp, contigs, j, div / 2.0) for j in range(3)]
+    t_synth = time.time() - t0
+    bases = sum(g.total_bp for g in gens)
+    _, nbytes = bf_size_bytes(gens[0].total_bp, args.fpr)
+    ctx.profile(True)
+    ctx.sync()
+    t0 = time.time()
+    common = BloomFilter(ctx, nbytes, k)
+    common.insert(gens[0])
+    direct = [ctx.path_stats()["bf_direct_indices"]]
+    fallback = 0
+    for g in gens[1:]:
+        common.insert_and(g)
+        st = ctx.path_stats()
+        direct.append(st["bf_direct_indices"])
+        fallback += st["bf_list_fallback"]
+    ctx.sync()
+    t_build = time.time() - t0
+    ins = ctx.timing("bf_insert"), ctx.timing("bf_insert_and")
+    occ = common.get_fpr()
+    ctx.profile(2)
+    for g in gens:
+        sketch(ctx, g, k, w, common).free()
+    ctx.sync()
+    t0 = time.time()
+    n_steps, n_mx, many, dup = 3, 0, 0, 0
+    for it in range(n_steps):
+        n_mx = many = 0
+        for g in gens:
+            mx = sketch(ctx, g, k, w, common)
+            n_mx += len(mx)
+            many += ctx.path_stats()["sketch_many_listed"]
+            mx.free()
+    ctx.sync()
+    dt = time.time() - t0
+    sel_ms, sel_n = ctx.timing("hash_select")
+    cand, gaps, gap_kmers = ctx.sketch_stats()
+    mx = sketch(ctx, gens[0], k, w, common)
+    h1 = mx.to_numpy()[0]
+    mx.free()
+    _, cnt = np.unique(h1, return_counts=True)
+    dup = int((cnt > 1).sum())
+    out = {"what": "BASELINE configs[4]'s parameter set (-d 1.3, k=24 w=1000 + --w_rounds 250 100) on 3 assembly-like synthetic genomes "
+                   f"({total_bp / 1e6:g} Mbp, {contigs} chromosomes; the real assemblies are not in the container)",
+           "records_per_genome": [len(g.names) for g in gens], "bases": bases, "synth_s": round(t_synth, 2),
+           "sketch_Gbases_s": round(bases * n_steps / dt / 1e9, 3), "ms_per_step": round(dt / n_steps * 1e3, 3), "minimizers_per_step": n_mx,
+           "select_kernel_avg_ms": round(sel_ms / max(sel_n, 1), 4), "prune_c": getattr(ctx, "last_prune_c", 0),
+           "candidates_last_launch": cand, "uncovered_ranges_last_launch": gaps, "uncovered_kmers_last_launch": gap_kmers,
+           "bloom": {"build_s": round(t_build, 4), "bf_insert_ms": round(ins[0][0] / max(ins[0][1], 1), 3),
+                     "bf_insert_and_avg_ms": round(ins[1][0] / max(ins[1][1], 1), 3) if ins[1][1] else None,
+                     "build_Gbases_s": round(bases / t_build / 1e9, 2), "occupancy_common": occ},
+           # where an i.i.d. family never goes
+           "paths_reached": {"bloom_indices_bypassing_full_buckets_per_genome": direct, "bloom_list_fallbacks": fallback,
+                             "select_candidates_from_tiles_listing_more_than_their_slots_per_step": many,
+                             "minimizer_hashes_occurring_twice_within_genome_0": dup}}
+    common.free()
+    for g in gens:
+        g.free()
+    if not args.no_e2e:
+        sub = os.path.join(workdir, "c5_like")
+        os.makedirs(sub, exist_ok=True)
+        try:
+            out["e2e"] = e2e_leg(a5, device, 3, total_bp, contigs, div, sub)
+        finally:
+            shutil.rmtree(sub, ignore_errors=True)
+    return out
 
 
 def main():
@@ -817,18 +922,25 @@ def main():
             e2e_slices = [g.download(0, min(int(g.rec_len[0]), 30_000_000)) for g in genomes]
             pa, _ = e2e_params(args, [f"syn{j}.fa" for j in range(len(genomes))], div)
             e2e_par = {"w_rounds": pa.w_rounds, "indel": pa.indel, "merge": pa.merge, "block_size": pa.block_size}
-        if not args.no_e2e:
-            for g in genomes:                                        # everything of the sketch legs goes, the pipeline
-                g.free()                                             # starts from files like a user's run
-            common.free()
-            ctx.close()
-            workdir = args.e2e_dir or tempfile.mkdtemp(prefix="nts_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
-            os.makedirs(workdir, exist_ok=True)
-            try:
+        workdir = args.e2e_dir or tempfile.mkdtemp(prefix="nts_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+        os.makedirs(workdir, exist_ok=True)
+        try:
+            if name == "c3" and not args.no_c5_leg and args.family == "structural":
+                for g in genomes:
+                    g.free()
+                common.free()
+                genomes, common = [], None
+                out["c5_like"] = c5_like_leg(args, ctx, local_rank, total_bp, contigs, workdir)
+            if not args.no_e2e:
+                for g in genomes:                                    # everything of the sketch legs goes, the pipeline
+                    g.free()                                         # starts from files like a user's run
+                if common is not None:
+                    common.free()
+                ctx.close()
                 out["e2e"] = e2e_leg(args, local_rank, n_fam, total_bp, contigs, div, workdir)
-            finally:
-                if not args.e2e_dir:
-                    shutil.rmtree(workdir, ignore_errors=True)
+        finally:
+            if not args.e2e_dir:
+                shutil.rmtree(workdir, ignore_errors=True)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, w, args.fpr, sample, bf_np, e2e_slices=e2e_slices, e2e_par=e2e_par)
     if rank == 0:

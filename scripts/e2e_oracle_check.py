@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--fpr", type=float, default=0.025)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--substitutions-only", action="store_true")
+    ap.add_argument("--family", choices=["structural", "assembly-like"], default="structural")
     ap.add_argument("--out", default="gpurun_out/r03_e2e_oracle.json")
     args = ap.parse_args()
     import bench
@@ -58,6 +59,8 @@ def main():
             ora = SO.run_pipeline(paths, k=a.k, w=a.w, fpr=a.fpr, prefix=a.prefix, w_rounds=a.w_rounds, indel=a.indel, merge=a.merge,
                                   block_size=a.block_size, threads=args.threads)
             ora_s = time.time() - t
+            import resource
+            ora_rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024
         finally:
             os.chdir(cwd)
         names = ["e2e.synteny_blocks.tsv", "e2e.pre-collinear-merge.synteny_blocks.tsv"]
@@ -77,6 +80,7 @@ def main():
                "oracle_md5": hashlib.md5(tsv.encode()).hexdigest(), "product_md5": product["tsv_md5"],
                "identical": same, "all_identical": all(same.values()),
                "oracle_seconds": round(ora_s, 1), "oracle_threads": args.threads, "product_seconds": product["seconds"],
+               "oracle_peak_rss_bytes": ora_rss, "product_peak_hbm_bytes": product.get("peak_hbm_bytes"),
                "blocks": product["blocks"], "engine_stats": product["engine_stats"],
                "what": product["what"] + "; oracle = oracle/synteny_oracle.py run_pipeline on the same files, host cores of the GPU box"}
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
