@@ -260,8 +260,25 @@ def family_genome(ctx, args, total_bp, contigs, j, rate, n_runs=False):
     from ntsynt_amd import synth
     from ntsynt_amd.device import Genome
     if getattr(args, "family", "structural") == "assembly-like":
-        plan = synth.realistic_plan(contigs, int(total_bp) // contigs, j, ANCESTOR_SEED)
-        return Genome.synth_plan(ctx, plan, ANCESTOR_SEED, 1000 + j, rate, rep=synth.REPEATS, names=plan[2])
+        # NTS_FAM_VARIANT (experiments: which trait of the family costs what): "nosat" satellite arrays of 3 kbp, "noscaf" chromosomes
+        # in one piece without gaps, "norep" no interspersed repeat families
+        var = os.environ.get("NTS_FAM_VARIANT", "").split(",")
+        kw = {}
+        if "nosat" in var:
+            kw["sat_scale"] = 1e-9
+        if "noscaf" in var:
+            kw.update(n_scaffolds=contigs, n_tail=0, n_gaps=0)
+        if "notail" in var:
+            kw.update(n_tail=0)
+        if "nogaps" in var:
+            kw.update(n_gaps=0)
+        if "nocuts" in var:
+            kw.update(n_scaffolds=contigs)
+        plan = synth.realistic_plan(contigs, int(total_bp) // contigs, j, ANCESTOR_SEED, **kw)
+        rep = dict(synth.REPEATS)
+        if "norep" in var:
+            rep["sine_prob_256"] = rep["line_prob_256"] = 0
+        return Genome.synth_plan(ctx, plan, ANCESTOR_SEED, 1000 + j, rate, rep=rep, names=plan[2])
     if args.substitutions_only and not n_runs:
         return Genome.synth(ctx, total_bp, contigs, ANCESTOR_SEED, 1000 + j, rate)
     plan = synth.structural_plan(contigs, int(total_bp) // contigs, j, ANCESTOR_SEED, n_runs=n_runs,
