@@ -531,6 +531,22 @@ int nts_ingest_trim(nts_ctx* ctx);
 int nts_write_indexlr_tsv_kmers(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,
                                 uint64_t n, uint32_t k, const uint8_t* kmers);
 void nts_fasta_free(nts_fasta* f);
+/* nts_read_indexlr_tsv: ntJoin's read_minimizers on an `indexlr --long --pos [--seq]` file -- the input of the reference's stage 3
+ * (bin/ntsynt_run.py:12 FILES, bin/ntsynt_synteny.py:607-609; file format: rule indexlr, smk:74-85): per line the record id and its
+ * tokens "hash:pos[:KMER]".  Out: the ids of all lines (NUL-separated, in file order), and per token the printed hash, the position
+ * and the number of its line, in file order.  NTS_EFORMAT for a token without a position.  Released with nts_mx_tsv_free. */
+typedef struct
+{
+  uint64_t n_lines;
+  char* names;
+  uint64_t names_bytes;
+  uint64_t n;
+  uint64_t* h1;
+  uint64_t* pos;
+  uint32_t* line;
+} nts_mx_tsv;
+int nts_read_indexlr_tsv(const char* path, nts_mx_tsv* out);
+void nts_mx_tsv_free(nts_mx_tsv* t);
 int nts_write_indexlr_tsv(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,
                           uint64_t n, uint32_t k, int with_seq);
 

@@ -37,6 +37,11 @@ class SynthRepeats(ctypes.Structure):
                                    "line_prob_256", "line_families", "div_min_1024", "div_max_1024", "sat_unit", "sat_div_1024")]
 
 
+class MxTsv(ctypes.Structure):
+    _fields_ = [("n_lines", u64), ("names", ctypes.POINTER(ctypes.c_char)), ("names_bytes", u64), ("n", u64), ("h1", c_u64p), ("pos", c_u64p),
+                ("line", c_u32p)]
+
+
 class Graph(ctypes.Structure):
     _fields_ = [("nv", u64), ("v_hash", c_u64p), ("occ_rec", c_u32p), ("occ_pos", c_u64p),
                 ("ne", u64), ("e_u", c_u32p), ("e_v", c_u32p), ("e_w", c_u32p), ("e_first", c_u64p)]
@@ -158,6 +163,8 @@ SYMBOLS = [
     ("nts_graph_free", None, [ctypes.POINTER(Graph)]),
     ("nts_fasta_read", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Fasta)]),
     ("nts_fasta_free", None, [ctypes.POINTER(Fasta)]),
+    ("nts_read_indexlr_tsv", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(MxTsv)]),
+    ("nts_mx_tsv_free", None, [ctypes.POINTER(MxTsv)]),
     ("nts_genome_from_fasta", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(c_vp), ctypes.POINTER(Fasta)]),
     ("nts_ingest_trim", ctypes.c_int, [c_vp]),
     ("nts_mx_kmers", ctypes.c_int, [c_vp, c_vp, c_vp, u32, c_vp]),

@@ -283,6 +283,123 @@ static int write_indexlr_tsv_impl(const char* path, const nts_fasta* fa, const u
                                   uint64_t n, uint32_t k, int with_seq, const uint8_t* kmers);
 
 // `indexlr --long --pos [--seq]`: one line per record, "id \t hash:pos[:KMER] hash:pos[:KMER] ...\n"
+// ntJoin's read_minimizers on an `indexlr --long --pos [--seq]` file (the stage-3 input of the reference: bin/ntsynt_run.py FILES,
+// bin/ntsynt_synteny.py:607-609): one line per record, "id\thash:pos[:KMER] hash:pos[:KMER] ...".  Parsed on host threads
+// (a 3 Gbp genome's file: ~6 M tokens, 300 MB with --seq).
+extern "C" int nts_read_indexlr_tsv(const char* path, nts_mx_tsv* out)
+{
+  if (!path || !out) return NTS_EINVAL;
+  memset(out, 0, sizeof(*out));
+  FileBytes f;
+  if (!f.open(path)) return NTS_EINVAL;
+  const uint8_t* p = f.p;
+  const uint64_t n = f.n;
+  // lines
+  std::vector<uint64_t> ls;
+  for (uint64_t at = 0; at < n;) {
+    ls.push_back(at);
+    const void* nl = memchr(p + at, '\n', n - at);
+    at = nl ? (uint64_t)((const uint8_t*)nl - p) + 1 : n;
+  }
+  ls.push_back(n);
+  const uint64_t n_lines = ls.size() - 1;
+  const unsigned n_thr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, n / (8u << 20) + 1));
+  std::vector<std::vector<uint64_t>> th1(n_thr), tpos(n_thr);
+  std::vector<std::vector<uint32_t>> tline(n_thr);
+  std::vector<int> bad(n_thr, 0);
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < n_thr; ++t)
+    pool.emplace_back([&, t] {
+      const uint64_t l0 = n_lines * t / n_thr, l1 = n_lines * (t + 1) / n_thr;
+      for (uint64_t l = l0; l < l1; ++l) {
+        const uint8_t* q = p + ls[l];
+        const uint8_t* e = p + ls[l + 1];
+        while (e > q && (e[-1] == '\n' || e[-1] == '\r')) --e;
+        const uint8_t* tab = (const uint8_t*)memchr(q, '\t', (size_t)(e - q));
+        if (!tab) continue; // a record id alone: no minimizers
+        q = tab + 1;
+        while (q < e) {
+          while (q < e && *q == ' ') ++q;
+          if (q >= e) break;
+          uint64_t h = 0, ps = 0;
+          const uint8_t* d0 = q;
+          while (q < e && *q >= '0' && *q <= '9') h = h * 10 + (uint64_t)(*q++ - '0');
+          if (q == d0 || q >= e || *q != ':') { // ntJoin needs hash:pos
+            bad[t] = 1;
+            return;
+          }
+          ++q;
+          d0 = q;
+          while (q < e && *q >= '0' && *q <= '9') ps = ps * 10 + (uint64_t)(*q++ - '0');
+          if (q == d0) {
+            bad[t] = 1;
+            return;
+          }
+          while (q < e && *q != ' ') ++q; // (:KMER)
+          th1[t].push_back(h);
+          tpos[t].push_back(ps);
+          tline[t].push_back((uint32_t)l);
+        }
+      }
+    });
+  for (auto& th : pool) th.join();
+  for (int b : bad)
+    if (b) return NTS_EFORMAT;
+  uint64_t tot = 0, name_bytes = 0;
+  for (unsigned t = 0; t < n_thr; ++t) tot += th1[t].size();
+  for (uint64_t l = 0; l < n_lines; ++l) {
+    const uint8_t* q = p + ls[l];
+    const uint8_t* e = p + ls[l + 1];
+    const uint8_t* tab = (const uint8_t*)memchr(q, '\t', (size_t)(e - q));
+    const uint8_t* ne = tab ? tab : e;
+    while (ne > q && (ne[-1] == '\n' || ne[-1] == '\r')) --ne;
+    name_bytes += (uint64_t)(ne - q) + 1;
+  }
+  out->n_lines = n_lines;
+  out->n = tot;
+  out->names = (char*)malloc(std::max<uint64_t>(name_bytes, 1));
+  out->h1 = (uint64_t*)malloc(std::max<uint64_t>(tot, 1) * 8);
+  out->pos = (uint64_t*)malloc(std::max<uint64_t>(tot, 1) * 8);
+  out->line = (uint32_t*)malloc(std::max<uint64_t>(tot, 1) * 4);
+  if (!out->names || !out->h1 || !out->pos || !out->line) {
+    nts_mx_tsv_free(out);
+    return NTS_ENOMEM;
+  }
+  out->names_bytes = name_bytes;
+  char* w = out->names;
+  for (uint64_t l = 0; l < n_lines; ++l) {
+    const uint8_t* q = p + ls[l];
+    const uint8_t* e = p + ls[l + 1];
+    const uint8_t* tab = (const uint8_t*)memchr(q, '\t', (size_t)(e - q));
+    const uint8_t* ne = tab ? tab : e;
+    while (ne > q && (ne[-1] == '\n' || ne[-1] == '\r')) --ne;
+    memcpy(w, q, (size_t)(ne - q));
+    w += ne - q;
+    *w++ = 0;
+  }
+  uint64_t at = 0;
+  for (unsigned t = 0; t < n_thr; ++t) {
+    const size_t m = th1[t].size();
+    if (m) {
+      memcpy(out->h1 + at, th1[t].data(), m * 8);
+      memcpy(out->pos + at, tpos[t].data(), m * 8);
+      memcpy(out->line + at, tline[t].data(), m * 4);
+    }
+    at += m;
+  }
+  return NTS_OK;
+}
+
+extern "C" void nts_mx_tsv_free(nts_mx_tsv* t)
+{
+  if (!t) return;
+  free(t->names);
+  free(t->h1);
+  free(t->pos);
+  free(t->line);
+  memset(t, 0, sizeof(*t));
+}
+
 extern "C" int nts_write_indexlr_tsv(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,
                                      uint64_t n, uint32_t k, int with_seq)
 {

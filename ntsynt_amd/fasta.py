@@ -199,3 +199,24 @@ def write_fai(path, recs):
 def basename(path):
     "genome identity everywhere = basename of the FASTA (smk:42; bin/ntsynt_synteny.py:137)"
     return os.path.basename(path)
+
+
+def read_indexlr_tsv(path):
+    """ntJoin's read_minimizers on an `indexlr --long --pos [--seq]` file (stage-3 input of the reference, bin/ntsynt_run.py:12):
+    (record ids of all lines, h1, pos, line number of every token), arrays in file order.  Native parser (nts_read_indexlr_tsv)."""
+    lib = _lib.load()
+    t = _lib.MxTsv()
+    rc = lib.nts_read_indexlr_tsv(os.fsencode(path), ctypes.byref(t))
+    if rc == -74:
+        raise ValueError(f"{path!r}: a minimizer token without a position (indexlr must run with --pos)")
+    if rc != 0:
+        raise OSError(f"cannot read minimizer TSV {path!r} (code {rc})")
+    try:
+        n, nl = int(t.n), int(t.n_lines)
+        names = [x.decode() for x in ctypes.string_at(t.names, int(t.names_bytes)).split(b"\0")[:nl]]
+        h1 = np.ctypeslib.as_array(t.h1, shape=(max(n, 1),))[:n].copy()
+        pos = np.ctypeslib.as_array(t.pos, shape=(max(n, 1),))[:n].copy()
+        line = np.ctypeslib.as_array(t.line, shape=(max(n, 1),))[:n].copy()
+    finally:
+        lib.nts_mx_tsv_free(ctypes.byref(t))
+    return names, h1, pos, line

@@ -43,15 +43,23 @@ def write_bf(path, bits, k, hash_num=1, signature=BF_SIGNATURE):
 
 
 def read_bf(path):
+    "(bit array, k) of a filter file in write_bf's layout (the bits are read straight into one array: a 3 Gbp filter is 14.8 GB)"
     with open(path, "rb") as fh:
-        data = fh.read()
-    end = data.index(b"[HeaderEnd]\n") + len(b"[HeaderEnd]\n")
+        head = fh.read(4096)
+    if b"[HeaderEnd]\n" not in head:
+        raise ValueError(f"{path}: no [HeaderEnd] line -- not a Bloom filter file in btllib's layout")
+    end = head.index(b"[HeaderEnd]\n") + len(b"[HeaderEnd]\n")
     meta = {}
-    for line in data[:end].decode().splitlines():
+    for line in head[:end].decode().splitlines():
         if "=" in line:
             key, val = [x.strip() for x in line.split("=", 1)]
             meta[key] = val.strip('"')
-    return np.frombuffer(data[end:], dtype=np.uint8).copy(), int(meta["k"])
+    bits = np.fromfile(path, dtype=np.uint8, offset=end)
+    if "bytes" in meta and int(meta["bytes"]) != bits.size:
+        raise ValueError(f"{path}: header says {meta['bytes']} bytes, the file holds {bits.size}")
+    if int(meta.get("hash_num", 1)) != 1:
+        raise ValueError(f"{path}: {meta['hash_num']} hash functions; ntSynt's common filter has one (src/ntsynt_make_common_bf.cpp:18-19)")
+    return bits, int(meta["k"])
 
 
 write_indexlr_tsv = fa.write_indexlr_tsv      # native writer (csrc/nts_hostio.cpp)
@@ -359,11 +367,19 @@ def _exchange_lists(backend, local, n_total):
 
 def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000, merge=10000,
         block_size=500, common=True, simplify=True, device=0, write_mx_tsv=True, mx_with_seq=True,
-        benchmark=False, log=print, ctx=None, backend=None, bf_rounding="up", bf_signature=BF_SIGNATURE, dev=False, interarrivals=False, repeat=False):
+        benchmark=False, log=print, ctx=None, backend=None, bf_rounding="up", bf_signature=BF_SIGNATURE, dev=False, interarrivals=False, repeat=False,
+        mx_tsvs=None, common_file=None, m=90, n=0, initial_only=False, write_fai=True):
     """FASTA paths -> engine (outputs in .outputs and in the CWD).  Mirrors oracle.synteny_oracle.run_pipeline's
     signature so the parity tests read alike.  Under torch.distributed (WORLD_SIZE > 1, process group already
-    initialised by the caller) genomes are sharded over the ranks."""
+    initialised by the caller) genomes are sharded over the ranks.
+
+    The reference's stage 3 on its own (bin/ntsynt_run.py, rule ntsynt_synteny smk:87-103): mx_tsvs = the minimizer TSV of
+    every assembly (aligned with `fastas`: read instead of sketched, ntJoin's read_minimizers) and common_file = the
+    `--common` filter file (uploaded instead of built; None with common=False: the refinement rounds sketch unfiltered);
+    m / n: ntsynt_run.py's -m / -n."""
     prefix = prefix or f"ntSynt.k{k}.w{w}"
+    if mx_tsvs is not None and len(mx_tsvs) != len(fastas):
+        raise ValueError("one minimizer TSV per FASTA file")
     world, rank = 1, 0
     dist = None
     import sys
@@ -403,11 +419,18 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         if len(g.names) >= MAX_RECORDS or (rl is not None and len(rl) and int(np.max(rl)) >= MAX_RECORD_BP):
             raise ValueError(f"{p}: more than 2^22 records or a record of 2^40 bases or more "
                              "(limits of the refinement rounds' composite interval keys)")
-        fa.write_fai(f"{fa.basename(p)}.fai", g.recs)
+        if write_fai:
+            fa.write_fai(f"{fa.basename(p)}.fai", g.recs)
 
-    overlap_load = (world == 1 and common and len(mine) > 1 and isinstance(backend, GpuBackend)
+    # stage 3's initial round alone needs no sequence: record ids come from the minimizer files
+    tsv_data = [fa.read_indexlr_tsv(t) for t in mx_tsvs] if mx_tsvs is not None else None
+    skip_genomes = mx_tsvs is not None and initial_only
+    overlap_load = (world == 1 and common and common_file is None and len(mine) > 1 and isinstance(backend, GpuBackend) and not skip_genomes
                     and os.environ.get("NTS_FASTA", "device") != "host" and os.environ.get("NTS_LOAD_OVERLAP", "1") != "0")
-    if overlap_load:
+    if skip_genomes:
+        genomes = {}
+        common, common_file = False, None
+    elif overlap_load:
         # files in the order the filter takes them (sorted: src/ntsynt_make_common_bf.cpp:105-107), on a context of their own
         from .device import Context
         n_loaders = max(1, min(int(os.environ.get("NTS_LOADERS", "1")), len(mine)))
@@ -427,7 +450,10 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
             arrived(p, genomes[p])
     st.mark("first_genome_resident" if overlap_load else "genomes_resident")
     # record names and sizes are needed everywhere (output text, filter sizing)
-    meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine} if not overlap_load else None
+    if skip_genomes:
+        meta = {p: (tsv_data[i][0], 0) for i, p in enumerate(fastas)}
+    else:
+        meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine} if not overlap_load else None
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, meta)
@@ -439,6 +465,19 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     from concurrent.futures import ThreadPoolExecutor
     writers = ThreadPoolExecutor(max_workers=4)
     pending_files = []
+    if common_file is not None:
+        # stage 3 on its own: `--common <file>` (ntsynt_run.py:23; consumed by the refinement rounds' indexlr -s, S:175-177)
+        if world > 1 or not isinstance(backend, GpuBackend):
+            raise ValueError("a filter file is read on one GPU")
+        st.start("load_common_bf")
+        bits, k_file = read_bf(common_file)
+        if k_file != k:
+            raise ValueError(f"{common_file}: built for k = {k_file}, this run uses k = {k}")
+        bf = backend.bf_new(bits.size, k)
+        bf.from_numpy(bits)
+        del bits
+        st.stop()
+        common = False
     if common:
         st.start("make_common_bf")
         ordered = sorted(fastas)                               # src/ntsynt_make_common_bf.cpp:105-107
@@ -495,7 +534,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 c.close()
         meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine}
         st.mark("genomes_resident")
-    elif isinstance(backend, GpuBackend):
+    elif isinstance(backend, GpuBackend) and not skip_genomes:
         backend.ctx.trim_ingest()
 
     # The reference's experimental repeat filter (config "repeat": rules make_repeat_bf and indexlr -r, smk:65-85): k-mers seen
@@ -529,7 +568,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     else:
         out_prefix = prefix
 
-    if bf is not None and rank == 0:
+    if bf is not None and rank == 0 and common_file is None:
         # filter file, behind everything that follows: straight out of HBM on the library's own copy threads where the filter
         # has a save() (the GPU backend), else device -> host copy + write
         if hasattr(bf, "save"):
@@ -560,8 +599,28 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 m.free()
             return dict(enumerate(everything))
 
-        st.start("indexlr")
-        initial_dev = sketch_dev_round(None, w)
+        st.start("indexlr" if mx_tsvs is None else "read_minimizers")
+        if mx_tsvs is not None:
+            # ntJoin's read_minimizers (S:607-609): the lists come from the files; records are matched to the FASTA's by id
+            from .device import Minimizers
+            if world > 1:
+                raise ValueError("minimizer TSVs are read on one GPU")
+            initial_dev = {}
+            for i, (p, tsv) in enumerate(zip(fastas, mx_tsvs)):
+                ids, h1, pos, line = tsv_data[i]
+                index = {name: r for r, name in enumerate(meta[p][0])}
+                try:
+                    rec_of_line = np.array([index[x] for x in ids], dtype=np.uint32)
+                except KeyError as exc:
+                    raise ValueError(f"{tsv}: record {exc.args[0]!r} is not in {p}") from None
+                rec = rec_of_line[line] if line.size else np.zeros(0, dtype=np.uint32)
+                if rec.size and np.any(rec[1:] < rec[:-1]):              # (lines in another order than the FASTA's records)
+                    order = np.lexsort((pos, rec))
+                    h1, rec, pos = h1[order], rec[order], pos[order]
+                initial_dev[i] = Minimizers.from_numpy(backend.ctx, h1, rec, pos)
+            write_mx_tsv = False
+        else:
+            initial_dev = sketch_dev_round(None, w)
         if write_mx_tsv:
             for i in mine_idx:
                 out = initial_dev[i].to_numpy()
@@ -575,7 +634,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         st.mark("sketches_done")
         st.start("ntsynt_synteny")
         eng = DeviceSyntenyEngine(backend.ctx, tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size,
-                                  out_prefix, sketch_dev_round, simplify=simplify, log=log, dev=dev, interarrivals=interarrivals)
+                                  out_prefix, sketch_dev_round, simplify=simplify, log=log, dev=dev, interarrivals=interarrivals, m=m, n=n)
+        if initial_only:
+            eng.initial_only = True
         first = [initial_dev[i] for i in range(len(fastas))]
     else:
         st.start("indexlr")

@@ -335,6 +335,8 @@ class DeviceSyntenyEngine(SyntenyEngine):
             print("Error - no paths found. Try adjusting the specified k/w parameters.")
             sys.exit(1)
         self._emit(f"{self.prefix}.synteny_blocks.tsv", ordered)
+        if getattr(self, "initial_only", False):               # (ntsynt_run.py --initial-only of this build: the initial round's table,
+            return                                              # which the reference overwrites at S:516-523 -- no FASTA needed)
         prev_w = self.w
         for new_w in self.w_rounds:
             self.log(f"Extending synteny blocks with w = {new_w}")

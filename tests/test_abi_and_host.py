@@ -189,3 +189,67 @@ def test_batch_list_splits_at_record_boundaries():
     assert all(p[1].dtype == np.uint32 for p in parts)
     empty = g.split_minimizers(h1[:0], rec[:0], pos[:0])
     assert [p[0].size for p in empty] == [0, 0, 0, 0]
+
+
+# ---- the stage executables of the reference's workflow (ntsynt_amd/stage_cli.py) ---------------------------------------------
+def test_stage3_command_line_is_the_reference_s():
+    "bin/ntsynt_run.py:10-44: every flag, its default and its type"
+    from ntsynt_amd import stage_cli
+    a = stage_cli.run_parser().parse_args(["b.fa.k24.w1000.tsv", "a.fa.k24.w1000.tsv", "--fastas", "x/a.fa", "b.fa", "-k", "24", "-w", "1000"])
+    assert (a.n, a.p, a.z, a.common, a.repeat, a.btllib_t, a.w_rounds, a.bp, a.collinear_merge, a.simplify_graph, a.m, a.dev, a.interarrivals) == \
+        (0, "out", 500, None, None, 4, [100, 10], 500, "1w", False, 90, False, False)
+    b = stage_cli.run_parser().parse_args("t1.tsv t2.tsv -k 20 -w 500 --w-rounds 250 100 -p pre --bp 50000 --collinear-merge 100000 -z 1000 "
+                                          "--common pre.common.bf --simplify-graph --btllib_t 12 --fastas a.fa b.fa --dev -n 2 -m 80".split())
+    assert (b.FILES, b.fastas, b.k, b.w, b.w_rounds, b.p, b.bp, b.collinear_merge, b.z, b.common, b.simplify_graph, b.btllib_t, b.dev, b.n, b.m) == \
+        (["t1.tsv", "t2.tsv"], ["a.fa", "b.fa"], 20, 500, [250, 100], "pre", 50000, "100000", 1000, "pre.common.bf", True, 12, True, 2, 80)
+    for argv in (["t.tsv", "-k", "24", "-w", "10"], ["t.tsv", "--fastas", "a.fa", "-w", "10"], ["--fastas", "a.fa", "-k", "2", "-w", "10"]):
+        with pytest.raises(SystemExit):                                      # --fastas, -k, -w and FILES are required
+            stage_cli.run_parser().parse_args(argv)
+    assert stage_cli.collinear_merge_bp("3w", 1000) == 3000 and stage_cli.collinear_merge_bp("12345", 1000) == 12345
+    with pytest.raises(ValueError):                                          # bin/ntsynt_synteny.py:42
+        stage_cli.collinear_merge_bp("3x", 1000)
+    assert stage_cli.pair_files(["d/b.fa.k24.w1000.tsv", "a.fa.gz.k20.w100.tsv"], ["x/a.fa.gz", "y/b.fa"]) == ["y/b.fa", "x/a.fa.gz"]
+    with pytest.raises(ValueError):
+        stage_cli.pair_files(["c.fa.k24.w1000.tsv"], ["a.fa"])
+
+
+def test_make_common_bf_and_indexlr_command_lines():
+    "src/ntsynt_make_common_bf.cpp:46-81; the indexlr options of rule indexlr (smk:81-85) and ntJoin's run_indexlr (S:173-182)"
+    from ntsynt_amd import stage_cli
+    a = stage_cli.make_common_bf_parser().parse_args(["--genome", "b.fa", "a.fa", "-k", "24"])
+    assert (a.genome, a.k, a.fpr, a.p, a.bf, a.t) == (["b.fa", "a.fa"], 24, 0.025, "common_bf", None, 12)
+    b = stage_cli.make_common_bf_parser().parse_args("--genome a.fa b.fa c.fa -p pre.common --fpr 0.01 -k 20 -t 48 --bf 1000000".split())
+    assert (b.p, b.fpr, b.k, b.t, b.bf) == ("pre.common", 0.01, 20, 48, 1000000)
+    with pytest.raises(SystemExit):
+        stage_cli.make_common_bf_parser().parse_args(["-k", "24"])            # --genome is required
+    c = stage_cli.indexlr_parser().parse_args("-k 24 -w 1000 --long --seq --pos -t 5 -s pre.common.bf -r pre.repeat.bf a.fa".split())
+    assert (c.k, c.w, c.long, c.seq, c.pos, c.t, c.s, c.r, c.fasta, c.o) == (24, 1000, True, True, True, 5, "pre.common.bf", "pre.repeat.bf", "a.fa", "/dev/stdout")
+
+
+def test_minimizer_tsv_reader(tmp_path):
+    "ntJoin's read_minimizers on indexlr's text: ids of all lines, tokens hash:pos[:KMER], lines without tokens"
+    from ntsynt_amd import fasta as fa
+    p = tmp_path / "x.fa.k4.w2.tsv"
+    p.write_text("chr1\t18446744073709551615:0:ACGT 456:10:TTTT\nchr2\t\nchr3 desc\t9:5\nchr4\n\n")
+    ids, h1, pos, line = fa.read_indexlr_tsv(str(p))
+    assert ids == ["chr1", "chr2", "chr3 desc", "chr4", ""]
+    assert h1.tolist() == [18446744073709551615, 456, 9] and pos.tolist() == [0, 10, 5] and line.tolist() == [0, 0, 2]
+    assert h1.dtype == np.uint64 and line.dtype == np.uint32
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("chr1\t123 456\n")                                       # indexlr without --pos: ntJoin cannot use it
+    with pytest.raises(ValueError):
+        fa.read_indexlr_tsv(str(bad))
+    with pytest.raises(OSError):
+        fa.read_indexlr_tsv(str(tmp_path / "missing.tsv"))
+    # a large file goes through several parser threads: same arrays as a line-by-line parse
+    rng = np.random.default_rng(1)
+    rows = []
+    with open(tmp_path / "big.tsv", "w") as fh:
+        for r in range(3000):
+            n = int(rng.integers(0, 400))
+            toks = [(int(rng.integers(0, 2**63)), int(i * 7)) for i in range(n)]
+            rows += [(h, ps, r) for h, ps in toks]
+            fh.write(f"ctg{r}\t" + " ".join(f"{h}:{ps}:ACGTACGTACGTACGTACGTACGT" for h, ps in toks) + "\n")
+    assert os.path.getsize(tmp_path / "big.tsv") > (8 << 20)
+    ids, h1, pos, line = fa.read_indexlr_tsv(str(tmp_path / "big.tsv"))
+    assert len(ids) == 3000 and h1.tolist() == [r[0] for r in rows] and pos.tolist() == [r[1] for r in rows] and line.tolist() == [r[2] for r in rows]

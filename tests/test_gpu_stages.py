@@ -1,0 +1,109 @@
+"""The stage executables of the reference's workflow (bin/ntsynt_make_common_bf, bin/indexlr, bin/ntsynt_run.py: the command
+lines of rules make_common_bf / indexlr / ntsynt_synteny, bin/ntsynt_run_pipeline.smk:55-103) chained through files like the
+Snakefile chains them, against `ntSynt` in one go -- and the reference's own minimizer files through the stage-3 command line."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from ntsynt_amd import synth
+from oracle import synteny_oracle as SO
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin")
+
+
+def _run(cmd, cwd, stdout=None):
+    r = subprocess.run([sys.executable] + cmd, cwd=cwd, stdout=stdout or subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, (cmd, r.stderr.decode()[-2000:])
+    return r
+
+
+def test_stages_chained_through_files_equal_ntsynt_in_one_go(tmp_path):
+    """make_common_bf -> indexlr x 3 -> ntsynt_run.py with the argument strings of smk:62,85,102-103, each a process of its own,
+    data crossing as files in the CWD -- every artefact byte-identical to bin/ntSynt's (filter file, minimizer TSVs, both synteny
+    TSVs), and both equal to the oracle pipeline's."""
+    src = tmp_path / "in"
+    src.mkdir()
+    paths = synth.make_family(str(src), 3, 900_000, 3, 0.01, seed=41, micro=8, soft_mask=True, n_runs=True, line_width=70)
+    one, chain = tmp_path / "one", tmp_path / "chain"
+    one.mkdir()
+    chain.mkdir()
+    k, w = 24, 400
+    opts = ["-k", str(k), "-w", str(w), "--w_rounds", "100", "20", "--indel", "600", "--merge", "3000", "-b", "300"]
+    _run([os.path.join(BIN, "ntSynt")] + paths + ["-d", "1", "-p", "run"] + opts, str(one))
+    # rule make_common_bf (smk:62): {script} --genome {refs} -p {prefix}.common --fpr {fpr} -k {k} -t {threads}
+    out = _run([os.path.join(BIN, "ntsynt_make_common_bf"), "--genome"] + paths + ["-p", "run.common", "--fpr", "0.025", "-k", str(k), "-t", "12"], str(chain))
+    text = out.stdout.decode()
+    assert "BF size (bytes):" in text and text.count("Bloom filter FPR:") == 4          # three levels + the final line (cpp:132,154,162)
+    # rule indexlr (smk:85): indexlr -k -w --long --seq --pos -t 5 -s {common} {fa} > {fa}.k{k}.w{w}.tsv
+    tsvs = []
+    for p in paths:
+        t = f"{os.path.basename(p)}.k{k}.w{w}.tsv"
+        with open(chain / t, "wb") as fh:
+            _run([os.path.join(BIN, "indexlr"), "-k", str(k), "-w", str(w), "--long", "--seq", "--pos", "-t", "5", "-s", "run.common.bf", p], str(chain), stdout=fh)
+        tsvs.append(t)
+    # rule ntsynt_synteny (smk:102-103)
+    out = _run([os.path.join(BIN, "ntsynt_run.py")] + tsvs + ["-k", str(k), "-w", str(w), "--w-rounds", "100", "20", "-p", "run", "--bp", "600",
+                                                             "--collinear-merge", "3000", "-z", "300", "--common", "run.common.bf", "--simplify-graph",
+                                                             "--btllib_t", "12", "--fastas"] + paths, str(chain))
+    assert "Running ntSynt v1.0.4" in out.stdout.decode()
+    names = ["run.common.bf", "run.synteny_blocks.tsv", "run.pre-collinear-merge.synteny_blocks.tsv"] + tsvs
+    for n in names:
+        a, b = open(one / n, "rb").read(), open(chain / n, "rb").read()
+        assert a == b and len(a) > 0, n
+    assert not [n for n in os.listdir(chain) if n.endswith(".fai")]                  # stage 3 writes no index (rule faidx is its own)
+    cwd = os.getcwd()
+    os.makedirs(tmp_path / "ora")
+    os.chdir(tmp_path / "ora")
+    try:
+        ora = SO.run_pipeline(paths, k=k, w=w, w_rounds=[100, 20], indel=600, merge=3000, block_size=300, prefix="run", threads=4)
+    finally:
+        os.chdir(cwd)
+    for n in ("run.synteny_blocks.tsv", "run.pre-collinear-merge.synteny_blocks.tsv"):
+        assert open(chain / n).read() == ora.outputs[n], n
+    assert len(ora.outputs["run.synteny_blocks.tsv"].splitlines()) >= 9
+
+
+MX = {("ref", 24): "mx_celegans-chrII-III.fa.k24.w1000.npz", ("A", 24): "mx_celegans-chrII-III.A.fa.k24.w1000.npz",
+      ("ref", 20): "mx_celegans-chrII-III.fa.k20.w1000.npz", ("A", 20): "mx_celegans-chrII-III.A.fa.k20.w1000.npz",
+      ("B", 20): "mx_celegans-chrII-III.B.fa.k20.w1000.npz"}
+FASTA = {"ref": "celegans-chrII-III.fa", "A": "celegans-chrII-III.A.fa", "B": "celegans-chrII-III.B.fa"}
+
+
+@pytest.mark.parametrize("keys,k,n_blocks", [([("ref", 24), ("A", 24)], 24, 15), ([("ref", 20), ("A", 20), ("B", 20)], 20, 16)])
+def test_reference_minimizer_files_through_the_stage3_command_line(tmp_path, golden_dir, keys, k, n_blocks):
+    """The reference's own indexlr output (tests/expected_result/*.k{20,24}.w1000.tsv, committed as arrays) written back as
+    minimizer TSVs and given to bin/ntsynt_run.py: the initial round's table (the one the reference overwrites at S:516-523,
+    so the FASTA files -- absent from the reference tree -- are not needed) equals the oracle's on the same lists, with the
+    block counts of SURVEY.md 8(c) P4 (15 and 16 with bubble removal, the workflow's default)."""
+    tsvs, tables = [], {}
+    for key in keys:
+        z = np.load(os.path.join(golden_dir, MX[key]))
+        names = [str(c) for c in z["contigs"]]
+        name = f"{FASTA[key[0]]}.k{k}.w1000.tsv"
+        recs = [(c, []) for c in names]
+        for ci, h, p in zip(z["contig_idx"].tolist(), z["h1"].tolist(), z["pos"].tolist()):
+            recs[ci][1].append((str(h), p))
+        with open(tmp_path / name, "w") as fh:
+            for c, toks in recs:
+                fh.write(c + "\t" + " ".join(f"{h}:{p}" for h, p in toks) + "\n")
+        tsvs.append(name)
+        tables[name] = SO.mx_tables_from_tokens(recs)
+    fastas = [FASTA[key[0]] for key in keys]                                     # (names only: --initial-only reads no sequence)
+    _run([os.path.join(BIN, "ntsynt_run.py")] + tsvs + ["-k", str(k), "-w", "1000", "--w-rounds", "100", "10", "-p", "c1", "--bp", "500",
+                                                       "--collinear-merge", "3000", "-z", "500", "--simplify-graph", "--initial-only", "--fastas"] + fastas,
+         str(tmp_path))
+    got = open(tmp_path / "c1.synteny_blocks.tsv").read()
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        ora = SO.SyntenyOracle(list(tables), {}, k, 1000, [], 500, 3000, 500, "ora", simplify=True)
+        ora.load(tables)
+        want = ora.main()["ora.synteny_blocks.tsv"]
+    finally:
+        os.chdir(cwd)
+    assert got == want and len(got.splitlines()) == n_blocks * len(keys)
