@@ -336,7 +336,7 @@ def write_fasta_from_device(g, path, chunk=1 << 28, soft_mask_seed=None, half_lo
                 fh.write(b"\n")
 
 
-ORACLE_RECORDS = [os.path.join(ROOT, "profiles", n) for n in ("r04_e2e_oracle_c5_like.json", "r03_e2e_oracle.json")]   # scripts/e2e_oracle_check.py
+ORACLE_RECORDS = [os.path.join(ROOT, "profiles", n) for n in ("r04_e2e_oracle_c3.json", "r04_e2e_oracle_c5_like.json", "r03_e2e_oracle.json")]   # scripts/e2e_oracle_check.py
 
 
 def oracle_record(key):
@@ -349,6 +349,16 @@ def oracle_record(key):
         except (OSError, ValueError):
             continue
     return None, None
+
+
+def mx_digest(h1, rec, pos):
+    """Order-independent digest of a minimizer list (count, XOR of the printed hashes, a multiply-mixed sum of hash, position and
+    record modulo 2^64): what the full-size oracle runs leave on record (scripts/e2e_oracle_check.py) and tests/test_gpu_scale.py
+    recomputes from the HIP path's lists -- the whole output at headline size, not slices of it."""
+    h1 = np.ascontiguousarray(h1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        mix = h1 * (np.asarray(pos, dtype=np.uint64) * np.uint64(2) + np.uint64(1)) + np.asarray(rec, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        return {"n": int(h1.size), "xor_h1": int(np.bitwise_xor.reduce(h1)) if h1.size else 0, "sum_mix": int(mix.sum(dtype=np.uint64)) if h1.size else 0}
 
 
 def e2e_key(args, n_fam, total_bp, contigs, div):
@@ -527,8 +537,7 @@ def main():
     mbp = args.mbp or mbp
     contigs = args.contigs or contigs
     div = args.divergence if args.divergence is not None else div
-    if n_fam < world:
-        raise SystemExit(f"workload {name}: {n_fam} genomes cannot occupy {world} GPUs")
+    shard_records = n_fam < world         # fewer genomes than GPUs: a genome's records are shared out over the ranks of its group
     import torch
     import torch.distributed as dist
     from ntsynt_amd.device import BloomFilter, Comm, Context, Genome, SketchPool, allgather_minimizers, bf_size_bytes, sketch
@@ -577,7 +586,29 @@ def main():
     # ---- the family: genome g lives on rank g mod world ------------------------------------------------------
     mine = [g for g in range(n_fam) if g % world == rank]
     t0 = time.time()
-    genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in mine]
+    shard = None
+    if shard_records:
+        # SURVEY.md 8(e), last paragraph: genome g is worked on by the ranks r with r mod G == g, each taking a range of its records
+        # (ntsynt_amd.pipeline.shard_plan); the shards' filters are OR-ed inside the group and AND-ed across groups in exchange 1
+        # (nts_bf_allreduce_groups), the shards' lists strung together per genome behind exchange 2 (nts_mx_concat)
+        from ntsynt_amd import pipeline, synth
+        if comm is None:
+            raise SystemExit("record sharding (fewer genomes than GPUs) needs the library's communicator")
+        if args.substitutions_only:
+            rec_lens = [[total_bp // contigs] * contigs] * n_fam
+        elif args.family == "assembly-like":
+            rec_lens = [synth.realistic_plan(contigs, total_bp // contigs, j, ANCESTOR_SEED)[0] for j in range(n_fam)]
+        else:
+            rec_lens = [synth.structural_plan(contigs, total_bp // contigs, j, ANCESTOR_SEED)[0] for j in range(n_fam)]
+        group_of, ranges = pipeline.shard_plan(rec_lens, world)
+        gi, si, rec0, rec1 = ranges[rank]
+        whole = family_genome(ctx, args, total_bp, contigs, gi, div / 2.0)
+        shard = {"genome": gi, "rec0": rec0, "rec1": rec1, "group_of": group_of, "ranges": ranges}
+        genomes = [whole.slice(rec0, rec1)]
+        whole.free()
+        mine = [rank]                                                 # (exchange 2 numbers the shards by rank)
+    else:
+        genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in mine]
     t_synth = time.time() - t0
     bases = sum(g.total_bp for g in genomes)
     fam_bases = family_bases(args, n_fam, total_bp, contigs)
@@ -605,7 +636,9 @@ def main():
     t_allreduce = 0.0
     if world > 1:
         t1 = time.time()
-        if comm is not None:
+        if shard is not None:
+            comm.allreduce_groups(common, shard["group_of"])
+        elif comm is not None:
             comm.allreduce_and(common)
         elif torch_comm:
             def and_into(a, b):
@@ -658,7 +691,19 @@ def main():
                 n += len(mx)
                 held.append(mx)
         if world > 1:                                               # exchange 2: every rank receives every list
-            if comm is not None:
+            if shard is not None:
+                from ntsynt_amd.device import Minimizers
+                parts = comm.allgather_minimizers(held, mine, world)
+                n_all = 0
+                for g_ in range(n_fam):                                 # the genome's list: its shards in record order
+                    rs = [r for r in range(world) if shard["ranges"][r][0] == g_]
+                    whole_list = Minimizers.concat(ctx, [parts[r] for r in rs], [shard["ranges"][r][2] for r in rs])
+                    n_all += len(whole_list)
+                    whole_list.free()
+                shard["n_all"] = n_all
+                for mx in parts:
+                    mx.free()
+            elif comm is not None:
                 everything = comm.allgather_minimizers(held, mine, n_fam)
                 for mx in everything:
                     mx.free()
@@ -884,7 +929,11 @@ def main():
                        "family": "substitutions only" if args.substitutions_only else
                                  "substitutions + per genome 5 inversions (1-5 Mbp), 2 inter-contig translocations, 20 indels (1-60 kbp), "
                                  "60 small rearrangements (2-20 kbp moved / copied / inverted within 80 kbp), 200 indels of 1-50 bp",
-                       "minimizers_per_step_rank0": n_mx, "parallelism": f"genomes sharded over {world} GPU(s)" + (f"; the {n_at_once} genomes of a GPU sketched at once, a stream each" if n_at_once > 1 else ""),
+                       "all_reduce_gathered_set_bit_indices": bool(comm.last_sparse()) if comm is not None else None,
+                       "minimizers_per_step_rank0": n_mx, "minimizers_per_step_all_genomes": shard["n_all"] if shard is not None else None,
+                       "parallelism": (f"{n_fam} genomes over {world} GPUs: the records of genome g shared out over the ranks r with r mod {n_fam} == g "
+                                       f"(rank 0: records {shard['rec0']}..{shard['rec1']} of genome 0)" if shard is not None else
+                                       f"genomes sharded over {world} GPU(s)") + (f"; the {n_at_once} genomes of a GPU sketched at once, a stream each" if n_at_once > 1 else ""),
                        "synth_s": round(t_synth, 3)},
             "roofline": {"bound": "hbm", "kernel": kern,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -922,7 +971,22 @@ def main():
             out["roofline"]["achieved_at_128B_per_probe"] = {
                 "GBs": round(pm["bytes_per_launch"] / (a_ms * 1e-3) / 1e9, 1) if a_ms > 0 else None,
                 "frac": round(pm["bytes_per_launch"] / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if a_ms > 0 else None,
-                "what": "corrected PMC bytes per launch / this run's average launch duration"}
+                "what": "corrected PMC bytes per launch (from the committed counter pass) / this run's average launch duration"}
+        # Which figures of the block were measured by THIS run (HIP events, wall clock, the library's counters) and which are
+        # constants read from the committed counter passes (rocprofv3 --pmc runs of this same command on the builder's box; they
+        # cannot be collected inside a timed run)
+        rf = out["roofline"]
+        rf["provenance"] = {
+            "measured_this_run": ["achieved", "frac", "avg_launch_ms", "launches", "other_kernels_avg_ms", "candidates_per_launch", "uncovered_ranges",
+                                  "uncovered_kmers", "one_probe_per_kmer_equivalent", "unpruned", "valu.wave_instr_per_s_per_cu", "valu.achieved (its time)",
+                                  "achieved_at_128B_per_probe (its time)"],
+            "from_committed_profiles": {
+                "traffic": (pm or {}).get("source"),
+                "achieved_at_128B_per_probe (its bytes)": (pm or {}).get("source"),
+                "valu.valu_wave_instr_per_64_kmers": "profiles/r03_sq_counters.json (SQ_INSTS_VALU pass)" if valu and "kernel" in valu else None,
+                "valu.mix, valu.peak": "profiles/r03_valu_mix.json (instruction classes counted from the ISA) priced at this run's measured issue rates"
+                if valu and "kernel" in valu else None},
+            "constants": {"peak": "MI355X_MICROARCH.md: HBM3E 8 TB/s", "algorithmic_bytes_per_base": "SURVEY.md 8(d): 64 B per probe; DESIGN.md 4.1"}}
         if cold:
             out["cold"] = cold
         if nruns:

@@ -102,6 +102,10 @@ int nts_genome_upload(nts_ctx* ctx,
  * the reference's "indexlr per assembly" (bin/ntsynt_run_pipeline.smk:74-85) for all assemblies with one sequence of launches --
  * records never share k-mers, so the minimizers of a record are those of the same record sketched alone. */
 int nts_genome_concat(nts_ctx* ctx, uint32_t n_parts, const nts_genome* const* parts, nts_genome** out);
+/* Records [rec0, rec1) of a resident genome as a resident genome of their own (device-to-device copy): the shard one rank of a
+ * genome's group works on when genomes < GPUs.  Windows never cross records (Indexlr minimizes per record), so the shards'
+ * minimizer lists concatenate to the genome's (nts_mx_concat) and their filters OR to the genome's (nts_bf_allreduce_groups). */
+int nts_genome_slice(nts_ctx* ctx, const nts_genome* g, uint32_t rec0, uint32_t rec1, nts_genome** out);
 void nts_genome_free(nts_ctx* ctx, nts_genome* g);
 /* Bench / scale-test utilities (no counterpart in the reference): a synthetic genome generated directly in
  * HBM -- `n_contigs` equal records of i.i.d. bases drawn from `seed_ancestor`, with independent substitutions
@@ -247,6 +251,14 @@ const char* nts_comm_library(void);
 int nts_bf_create_sharded(nts_ctx* ctx, uint64_t bytes, int world, nts_bf** out);
 int nts_bf_fill_ones(nts_ctx* ctx, nts_bf* bf);
 int nts_bf_allreduce_and(nts_ctx* ctx, nts_bf* bf, nts_comm* comm);
+/* Exchange 1 when there are fewer genomes than GPUs (last paragraph; what the reference parallelises over is
+ * records, src/ntsynt_make_common_bf.cpp:128-131,145-153): the ranks of group g hold the filters of the shards (record ranges,
+ * nts_genome_slice) of genome g.  In place, every rank ends with AND over groups of (OR over the group's ranks); group_of[r] in
+ * [0, n_groups) for each of the communicator's ranks, every group with at least one rank.  group_of == NULL: nts_bf_allreduce_and.
+ * nts_comm_last_sparse: 1 if the context's last all-reduce gathered the set bits' indices instead of the reduced chunks (a
+ * reduced filter that is all but empty -- BASELINE config 4 -- moves megabytes instead of the filter's size). */
+int nts_bf_allreduce_groups(nts_ctx* ctx, nts_bf* bf, nts_comm* comm, const int32_t* group_of, uint32_t n_groups);
+int nts_comm_last_sparse(const nts_ctx* ctx);
 int nts_mx_allgather(nts_ctx* ctx, nts_comm* comm, uint32_t n_local, const nts_mx* const* local, const uint32_t* local_ids,
                      uint32_t n_total, nts_mx** out);
 
@@ -316,6 +328,9 @@ int nts_mx_kmers(nts_ctx* ctx, const nts_genome* g, const nts_mx* mx, uint32_t k
 /* the list of a batch genome (nts_genome_concat) taken apart on the device: out[p] = the minimizers of records
  * [rec_base[p], rec_base[p+1]) with record ids rebased to the part (rec_base has n_parts + 1 entries) */
 int nts_mx_split(nts_ctx* ctx, const nts_mx* mx, uint32_t n_parts, const uint32_t* rec_base, nts_mx** out);
+/* the inverse: the lists of a genome's shards (nts_genome_slice), in record order, as the genome's list -- part p's record
+ * numbers raised by rec_offset[p] */
+int nts_mx_concat(nts_ctx* ctx, uint32_t n_parts, const nts_mx* const* parts, const uint32_t* rec_offset, nts_mx** out);
 /* build a device list from host arrays (receiving side of the all-gather, tests) */
 int nts_mx_upload(nts_ctx* ctx,
                   const uint64_t* h1,

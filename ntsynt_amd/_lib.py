@@ -81,6 +81,7 @@ SYMBOLS = [
     ("nts_genome_synth_plan_ex", ctypes.c_int, [c_vp, u32, c_vp, u32, c_vp, u64, u64, ctypes.c_double, c_vp, ctypes.POINTER(c_vp)]),
     ("nts_genome_download", ctypes.c_int, [c_vp, c_vp, u64, u64, c_vp]),
     ("nts_genome_concat", ctypes.c_int, [c_vp, u32, c_vp, ctypes.POINTER(c_vp)]),
+    ("nts_genome_slice", ctypes.c_int, [c_vp, c_vp, u32, u32, ctypes.POINTER(c_vp)]),
     ("nts_genome_free", None, [c_vp, c_vp]),
     ("nts_genome_bases", u64, [c_vp]),
     ("nts_genome_valid_kmers", ctypes.c_int, [c_vp, c_vp, u32, c_u64p]),
@@ -116,6 +117,8 @@ SYMBOLS = [
     ("nts_bf_create_sharded", ctypes.c_int, [c_vp, u64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     ("nts_bf_fill_ones", ctypes.c_int, [c_vp, c_vp]),
     ("nts_bf_allreduce_and", ctypes.c_int, [c_vp, c_vp, c_vp]),
+    ("nts_bf_allreduce_groups", ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_int32), u32]),
+    ("nts_comm_last_sparse", ctypes.c_int, [c_vp]),
     ("nts_mx_allgather", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_vp), c_u32p, u32, ctypes.POINTER(c_vp)]),
     ("nts_mx_export", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("nts_mx_export_async", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -134,6 +137,7 @@ SYMBOLS = [
     ("nts_mx_device_ptrs", ctypes.c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                                           ctypes.POINTER(c_vp)]),
     ("nts_mx_split", ctypes.c_int, [c_vp, c_vp, u32, c_u32p, ctypes.POINTER(c_vp)]),
+    ("nts_mx_concat", ctypes.c_int, [c_vp, u32, ctypes.POINTER(c_vp), c_u32p, ctypes.POINTER(c_vp)]),
     ("nts_mx_upload", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, u64, ctypes.POINTER(c_vp)]),
     ("nts_hash_all", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_u64p), c_u64p]),
     ("nts_graph_build", ctypes.c_int, [c_vp, u32, ctypes.POINTER(MxList), ctypes.POINTER(Graph)]),

@@ -71,6 +71,23 @@ inline hipError_t dev_malloc(T** p, size_t n)
   return dev_malloc((void**)p, n);
 }
 
+// the same with allocation flags (hipDeviceMallocUncached / hipDeviceMallocFinegrained: how the L2 treats the memory)
+inline hipError_t dev_malloc_flags(void** p, size_t n, unsigned flags)
+{
+  const hipError_t e = ::hipExtMallocWithFlags(p, n, flags);
+  if (e == hipSuccess && *p) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      sizes[*p] = n;
+    }
+    const uint64_t now = live.fetch_add(n) + n;
+    uint64_t seen = peak.load();
+    while (now > seen && !peak.compare_exchange_weak(seen, now)) {
+    }
+  }
+  return e;
+}
+
 inline hipError_t dev_free(void* p)
 {
   if (p) {
@@ -86,6 +103,7 @@ inline hipError_t dev_free(void* p)
 } // namespace nts_mem
 using nts_mem::dev_free;
 using nts_mem::dev_malloc;
+using nts_mem::dev_malloc_flags;
 
 namespace {
 
@@ -142,6 +160,7 @@ struct nts_ctx
   uint64_t last_candidates = 0, last_gaps = 0, last_gap_kmers = 0;
   uint64_t last_many_listed = 0; // candidates of k_hash_select_hi tiles that listed more than their slots hold (repeats, pieces)
   uint64_t last_bf_direct = 0;   // indices of the last partitioned Bloom build that bypassed the buckets (full bucket, lanes in pieces)
+  uint32_t last_comm_sparse = 0; // the last all-reduce of a filter gathered set-bit indices instead of chunks
   uint32_t last_bf_fallback = 0; // 1: its late list ran full (store-only build fell back to read-and-OR / fused AND build was redone unfused)
   // dense sketch over a sparse filter: summary consulted before the filter, key tiles without an accepted k-mer skipped
   const uint32_t* cur_summary = nullptr;
@@ -2058,6 +2077,52 @@ int nts_genome_concat(nts_ctx* ctx, uint32_t n_parts, const nts_genome* const* p
   return NTS_OK;
 }
 
+// Records [rec0, rec1) of a resident genome as a resident genome of their own (a device-to-device copy): the shard of a genome
+// that one rank of its group works on when there are fewer genomes than GPUs (SURVEY.md 8(e) last paragraph: "shard by contig --
+// windows never cross records --, OR the partial filters of a genome, then AND across genomes"; the reference parallelises over
+// records the same way, src/ntsynt_make_common_bf.cpp:128-131,145-153).  Record r of the slice is record rec0 + r of `g`.
+int nts_genome_slice(nts_ctx* ctx, const nts_genome* g, uint32_t rec0, uint32_t rec1, nts_genome** out)
+{
+  if (!ctx || !g || !out || rec0 > rec1 || rec1 > g->n_rec) return fail(ctx, NTS_EINVAL, "nts_genome_slice: record range outside the genome");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t a = rec0 < g->n_rec ? g->rec_off[rec0] : g->n;
+  const uint64_t b = rec1 > rec0 ? g->rec_off[rec1 - 1] + g->rec_len[rec1 - 1] : a;
+  const uint64_t n = b - a;
+  const uint32_t n_rec = rec1 - rec0;
+  nts_genome* q = new nts_genome();
+  q->n = n;
+  q->n_rec = n_rec;
+  if (dev_malloc((void**)&q->d_code, PAD + n + PAD) != hipSuccess || dev_malloc((void**)&q->d_rec_off, std::max<uint64_t>(n_rec, 1) * 8) != hipSuccess) {
+    dev_free(q->d_code);
+    delete q;
+    return fail(ctx, NTS_ENOMEM, "nts_genome_slice: hipMalloc");
+  }
+  for (uint32_t r = rec0; r < rec1; ++r) {
+    q->rec_off.push_back(g->rec_off[r] - a);
+    q->rec_len.push_back(g->rec_len[r]);
+    q->total_bases += g->rec_len[r];
+  }
+  const size_t i0 = (size_t)(std::lower_bound(g->st_a.begin(), g->st_a.end(), a) - g->st_a.begin()); // (stretches are clipped to records)
+  for (size_t i = i0; i < g->st_a.size() && g->st_a[i] < b; ++i) {
+    q->st_a.push_back(g->st_a[i] - a);
+    q->st_b.push_back(g->st_b[i] - a);
+  }
+  bool ok = hipMemsetAsync(q->d_code, CODE_INVALID, PAD, ctx->stream) == hipSuccess &&
+            hipMemsetAsync(q->d_code + PAD + n, CODE_INVALID, PAD, ctx->stream) == hipSuccess;
+  if (ok && n) ok = hipMemcpyAsync(q->d_code + PAD, g->d_code + PAD + a, n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess;
+  if (ok && n_rec) ok = hipMemcpyAsync(q->d_rec_off, q->rec_off.data(), (size_t)n_rec * 8, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+  if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+  if (!ok) {
+    const std::string msg = std::string("nts_genome_slice: ") + hipGetErrorString(hipGetLastError());
+    dev_free(q->d_code);
+    dev_free(q->d_rec_off);
+    delete q;
+    return fail(ctx, NTS_EHIP, msg);
+  }
+  *out = q;
+  return NTS_OK;
+}
+
 void nts_genome_free(nts_ctx* ctx, nts_genome* g)
 {
   if (!g) return;
@@ -2249,7 +2314,16 @@ static int bf_create_alloc(nts_ctx* ctx, uint64_t bytes, uint64_t alloc, nts_bf*
   nts_bf* bf = new nts_bf();
   bf->bytes = bytes;
   bf->alloc_bytes = alloc;
-  hipError_t e = dev_malloc((void**)&bf->d_words, alloc);
+  // NTS_BF_MEM=uncached | finegrained: the filter in memory the L2 does not cache / keeps coherent (an experiment: does a random
+  // 4-byte probe then move less than a 128-byte line?  DESIGN.md 4.2)
+  hipError_t e;
+  const char* kind = getenv("NTS_BF_MEM");
+  if (kind && !strcmp(kind, "uncached"))
+    e = dev_malloc_flags((void**)&bf->d_words, alloc, hipDeviceMallocUncached);
+  else if (kind && !strcmp(kind, "finegrained"))
+    e = dev_malloc_flags((void**)&bf->d_words, alloc, hipDeviceMallocFinegrained);
+  else
+    e = dev_malloc((void**)&bf->d_words, alloc);
   if (e != hipSuccess) {
     delete bf;
     return fail(ctx, NTS_ENOMEM, std::string("hipMalloc bloom: ") + hipGetErrorString(e));
@@ -2363,7 +2437,7 @@ static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nt
   int rc = get_tables(ctx, g, k, nullptr, 0, scratch, &T);
   if (rc) return rc;
   uint32_t* late_ctl = (uint32_t*)(ctx->mail + MAIL_WORDS - 8); // (pinned; the mailbox proper ends below: its users wait for their own flag)
-  late_ctl[0] = late_ctl[2] = late_ctl[3] = 0;
+  for (int i = 0; i < 8; ++i) late_ctl[i] = 0;
   if (prev) {
     rc = launch_hash<MODE_CASCADE>(ctx, "bf_cascade", g, *T, k, prev, next, nullptr);
   } else {
@@ -2375,6 +2449,8 @@ static int bf_hash_pass(nts_ctx* ctx, const nts_bf* prev, nts_bf* next, const nt
   if (!prev) {
     ctx->last_bf_direct = (uint64_t)late_ctl[2] | ((uint64_t)late_ctl[3] << 32);
     ctx->last_bf_fallback = late_ctl[0];
+    // the store-only finish counted the bits it left (k_bin3 + k_bin_late): the filter was empty, so that is its popcount
+    if (was_empty && late_ctl[6] == 1u && late_ctl[0] == 0u && next->owned) next->popcnt = (int64_t)((uint64_t)late_ctl[4] | ((uint64_t)late_ctl[5] << 32));
   }
   return NTS_OK;
 }
@@ -2397,7 +2473,7 @@ int nts_bf_insert_and(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, uint32_t k
   int rc = get_tables(ctx, g, k, nullptr, 0, scratch, &T);
   if (rc) return rc;
   uint32_t* late_ctl = (uint32_t*)(ctx->mail + MAIL_WORDS - 8);
-  late_ctl[0] = late_ctl[2] = late_ctl[3] = 0;
+  for (int i = 0; i < 8; ++i) late_ctl[i] = 0;
   // (a running filter known to hold fewer than one bit per 2^12: most 64 KiB slices are empty, k_bin3 looks before it reads residues)
   const bool sparse = pop_before >= 0 && (uint64_t)pop_before < ((acc->bytes * 8) >> 12);
   const bool fused_ok = ctx->bf_build_mode != 1 && !(getenv("NTS_BIN_FUSED_AND") && atoi(getenv("NTS_BIN_FUSED_AND")) == 0);
@@ -2406,7 +2482,10 @@ int nts_bf_insert_and(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, uint32_t k
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->last_bf_direct = (uint64_t)late_ctl[2] | ((uint64_t)late_ctl[3] << 32);
   ctx->last_bf_fallback = 0;
-  if (rc == 0 && late_ctl[0] == 0) return NTS_OK;
+  if (rc == 0 && late_ctl[0] == 0) {
+    if (late_ctl[6] == 1u && acc->owned) acc->popcnt = (int64_t)((uint64_t)late_ctl[4] | ((uint64_t)late_ctl[5] << 32)); // counted by the AND finish
+    return NTS_OK;
+  }
   // the plain way (acc is untouched: the fused build did not apply, or it gave up and put its parked bits back)
   ctx->last_bf_fallback = rc == 0 ? 1u : 0u;
   nts_bf* own = nullptr;
@@ -3316,7 +3395,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     // one synchronisation: candidate counters, uncovered-range count + a first batch of ranges, winner count
     uint64_t last_scan = 0, last_cnt = 0, listed = 0;
     {
-      static_assert(N_SEG + 5 + 2 * GAP_PEEK < MAIL_WORDS, "mailbox too small (the last word is the arrival flag)");
+      static_assert(N_SEG + 5 + 2 * GAP_PEEK < MAIL_WORDS - 8, "mailbox too small (the last word is the arrival flag)");
       const uint32_t peek = (uint32_t)std::min<uint64_t>(GAP_PEEK, gap_cap);
       Mail mb(ctx);
       const uint32_t a_ctl = mb.add(d_ctl, N_SEG + 1);

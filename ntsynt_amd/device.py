@@ -225,6 +225,22 @@ class Genome:
         g.h = h
         return g
 
+    def slice(self, rec0, rec1, ctx=None):
+        """Records [rec0, rec1) as a resident genome of their own (nts_genome_slice): the shard one rank of this genome's group
+        works on when there are fewer genomes than GPUs; record r of the slice is record rec0 + r here."""
+        ctx = ctx or self.ctx
+        g = Genome.__new__(Genome)
+        g.ctx = ctx
+        g.names = self.names[rec0:rec1]
+        g.rec_len = np.ascontiguousarray(self.rec_len[rec0:rec1], dtype=np.uint64)
+        g.rec_off = (np.concatenate(([0], np.cumsum(g.rec_len[:-1]))) if rec1 > rec0 else np.zeros(0)).astype(np.uint64)
+        g.n_bytes = int(g.rec_len.sum())
+        g.rec0 = int(rec0)
+        h = c_vp()
+        ctx.check(ctx.lib.nts_genome_slice(ctx.h, self.h, int(rec0), int(rec1), ctypes.byref(h)), "nts_genome_slice")
+        g.h = h
+        return g
+
     def split_minimizers(self, h1, rec, pos):
         """(h1, rec, pos) of a sketch of a concat() batch -> one (h1, rec, pos) per part, record ids local to the part
         (the list is in (record, position) order, so each part is a slice)."""
@@ -386,6 +402,16 @@ class Comm:
         "exchange 1: bf &= every other rank's filter, in place (bf from BloomFilter(..., world=N))"
         self.ctx.check(self.ctx.lib.nts_bf_allreduce_and(self.ctx.h, bf.h, self.h), "nts_bf_allreduce_and")
 
+    def allreduce_groups(self, bf, group_of):
+        """exchange 1 with genomes sharded over groups of ranks: bf = AND over groups of (OR over the filters of the group's ranks),
+        in place; group_of[r] = group (genome) of rank r (nts_bf_allreduce_groups)"""
+        arr = (ctypes.c_int32 * self.world)(*[int(g) for g in group_of])
+        self.ctx.check(self.ctx.lib.nts_bf_allreduce_groups(self.ctx.h, bf.h, self.h, arr, max(group_of) + 1), "nts_bf_allreduce_groups")
+
+    def last_sparse(self):
+        "True if the last all-reduce gathered set-bit indices instead of the reduced chunks"
+        return bool(self.ctx.lib.nts_comm_last_sparse(self.ctx.h))
+
     def allgather_minimizers(self, local, local_ids, n_total):
         "exchange 2: the ranks' Minimizers -> [Minimizers of genome g for g in range(n_total)], resident in HBM"
         return allgather_minimizers(self.ctx, self, local, local_ids, n_total)
@@ -457,6 +483,16 @@ class Minimizers:
         out = (c_vp * n)()
         self.ctx.check(self.ctx.lib.nts_mx_split(self.ctx.h, self.h, n, base, out), "nts_mx_split")
         return [Minimizers(self.ctx, c_vp(out[p])) for p in range(n)]
+
+    @classmethod
+    def concat(cls, ctx, parts, rec_offsets):
+        "the lists of a genome's shards, in record order, as the genome's list: part p's record numbers raised by rec_offsets[p] (nts_mx_concat)"
+        n = len(parts)
+        arr = (c_vp * n)(*[m.h for m in parts])
+        off = (ctypes.c_uint32 * n)(*[int(x) for x in rec_offsets])
+        h = c_vp()
+        ctx.check(ctx.lib.nts_mx_concat(ctx.h, n, arr, off, ctypes.byref(h)), "nts_mx_concat")
+        return cls(ctx, h)
 
     def device_ptrs(self):
         a, b, c = c_vp(), c_vp(), c_vp()

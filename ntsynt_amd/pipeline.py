@@ -306,6 +306,41 @@ class GpuBackend:
             self.ctx.close()
 
 
+def shard_plan(rec_lens, world):
+    """Fewer genomes than GPUs (last paragraph): genome g is worked on by the ranks r with r mod G == g (its group),
+    each taking a range of the genome's records -- windows never cross records, and records are what the reference parallelises
+    over (src/ntsynt_make_common_bf.cpp:128-131,145-153) -- balanced by bases.  rec_lens[g]: record lengths of genome g.
+    Returns (group_of[rank], ranges[rank] = (genome, shard number, rec0, rec1)); a genome with fewer records than ranks leaves
+    ranks with an empty range (they contribute nothing to the OR and an empty list)."""
+    G = len(rec_lens)
+    assert 0 < G < world
+    group_of = [r % G for r in range(world)]
+    ranges = [None] * world
+    for g in range(G):
+        ranks = [r for r in range(world) if r % G == g]
+        lens = np.asarray(rec_lens[g], dtype=np.float64)
+        cum = np.concatenate(([0.0], np.cumsum(lens)))
+        cuts = [0]
+        for s_ in range(1, len(ranks)):
+            at = int(np.searchsorted(cum, cum[-1] * s_ / len(ranks), side="left"))
+            cuts.append(min(max(at, cuts[-1]), lens.size))
+        cuts.append(lens.size)
+        for s_, r in enumerate(ranks):
+            ranges[r] = (g, s_, cuts[s_], cuts[s_ + 1])
+    return group_of, ranges
+
+
+def shard_masks(masks, rec0, rec1):
+    "the hard-mask intervals of a genome that fall into records [rec0, rec1), renumbered for the slice (nts_interval arrays or (rec, start, end) tuples)"
+    if masks is None:
+        return None
+    if isinstance(masks, np.ndarray):
+        m = masks[(masks["rec"] >= rec0) & (masks["rec"] < rec1)].copy()
+        m["rec"] -= np.uint32(rec0)
+        return m
+    return [(int(r) - rec0, s_, e) for r, s_, e in masks if rec0 <= int(r) < rec1]
+
+
 def load_genomes(backend, paths, max_threads=8):
     """FASTA files -> resident genomes.  The files are parsed concurrently on host threads (the reference runs one
     indexlr/faidx process per file under Snakemake); uploads happen in order on the caller's thread while later
@@ -405,6 +440,11 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         backend.init_comm()
     owner = {p: i % world for i, p in enumerate(fastas)}
     mine = [p for p in fastas if owner[p] == rank]
+    # fewer genomes than GPUs: every genome is shared out by records over a group of ranks (shard_plan); the device engine only
+    shard_mode = (world > len(fastas) and isinstance(backend, GpuBackend) and os.environ.get("NTS_ENGINE", "device") != "host"
+                  and mx_tsvs is None and not repeat and os.environ.get("NTS_SHARD_RECORDS", "1") != "0")
+    if shard_mode:
+        mine = [fastas[rank % len(fastas)]]                     # the genome of this rank's group (loaded whole, cut below)
 
     # limits of this implementation, checked before anything is written (the reference has none of them)
     for ww in [w] + list(w_rounds):
@@ -419,7 +459,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         if len(g.names) >= MAX_RECORDS or (rl is not None and len(rl) and int(np.max(rl)) >= MAX_RECORD_BP):
             raise ValueError(f"{p}: more than 2^22 records or a record of 2^40 bases or more "
                              "(limits of the refinement rounds' composite interval keys)")
-        if write_fai:
+        if write_fai and (not shard_mode or rank < len(fastas)):            # (shard mode: the first rank of a genome's group writes for it)
             fa.write_fai(f"{fa.basename(p)}.fai", g.recs)
 
     # stage 3's initial round alone needs no sequence: record ids come from the minimizer files
@@ -456,8 +496,18 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine} if not overlap_load else None
     if world > 1:
         gathered = [None] * world
-        dist.all_gather_object(gathered, meta)
+        dist.all_gather_object(gathered, {p: v + (np.asarray(genomes[p].rec_len, dtype=np.uint64),) for p, v in meta.items()} if shard_mode else meta)
         meta = {p: v for part in gathered for p, v in part.items()}
+    shard = None
+    if shard_mode:
+        group_of, ranges = shard_plan([meta[p][2] for p in fastas], world)
+        gi, si, rec0, rec1 = ranges[rank]
+        whole = genomes[fastas[gi]]
+        shard = {"genome": gi, "number": si, "rec0": rec0, "rec1": rec1, "group_of": group_of, "ranges": ranges,
+                 "sub": whole.slice(rec0, rec1, backend.ctx), "leader": si == 0}
+        if not shard["leader"]:                                # only a group's first rank keeps the whole genome (k-mer text of the TSV)
+            whole.free()
+        st.mark("shard_resident")
     st.stop()
 
     bf = None
@@ -486,9 +536,11 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         approx, nbytes = bf_size_bytes(first_bp, fpr, bf_rounding)
         log(f"Genome size (bp): {first_bp}")
         log(f"BF size (bytes): {approx}")
-        my_sorted = [p for p in ordered if owner[p] == rank]
-        bf = backend.bf_new(nbytes, k, world, ones=(world > 1 and not my_sorted))
+        my_sorted = [p for p in ordered if owner[p] == rank] if not shard_mode else []
+        bf = backend.bf_new(nbytes, k, world, ones=(world > 1 and not my_sorted and not shard_mode))
         st.mark("bf_allocated")
+        if shard_mode:
+            backend.bf_insert(bf, shard["sub"])                 # the shard's k-mers: OR-ed with the group's other shards in the exchange
         if my_sorted:
             backend.bf_insert(bf, genomes[my_sorted[0]])
             st.mark("bf_first_insert")
@@ -510,7 +562,10 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 if hasattr(tmp, "free"):
                     tmp.free()
         if world > 1:
-            if hasattr(backend, "allreduce_and"):
+            if shard_mode:
+                backend.ctx.sync()
+                backend.comm.allreduce_groups(bf, shard["group_of"])
+            elif hasattr(backend, "allreduce_and"):
                 backend.allreduce_and(bf)
             else:                                              # test doubles: CPU tensors
                 from .dist import allreduce_and
@@ -583,9 +638,26 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     if device_engine:
         from .synteny_device import DeviceSyntenyEngine
         mine_idx = [i for i, p in enumerate(fastas) if owner[p] == rank]
+        if shard_mode:
+            mine_idx = [shard["genome"]] if shard["leader"] else []          # (the genomes whose minimizer TSV this rank writes)
 
         def sketch_dev_round(masks_by_asm, new_w):
             "device lists of all assemblies: every rank sketches its own genomes (one batch when they are small), one all-gather"
+            if shard_mode:
+                # this rank's records of its genome; the all-gather hands every rank every shard's list (shard = rank number), the
+                # shards of a genome are strung together in record order
+                from .device import Minimizers
+                ms = shard_masks(masks_by_asm[shard["genome"]], shard["rec0"], shard["rec1"]) if masks_by_asm is not None else None
+                part = backend.sketch_dev([shard["sub"]], k, new_w, bf, [ms] if ms is not None else None)[0]
+                parts = backend.exchange_dev({rank: part}, world)
+                part.free()
+                out = {}
+                for g_ in range(len(fastas)):
+                    rs = [r for r in range(world) if shard["ranges"][r][0] == g_]
+                    out[g_] = Minimizers.concat(backend.ctx, [parts[r] for r in rs], [shard["ranges"][r][2] for r in rs])
+                for m_ in parts:
+                    m_.free()
+                return out
             ml = [masks_by_asm[i] for i in mine_idx] if masks_by_asm is not None else None
             if rep_bf is not None and masks_by_asm is None:
                 got = backend.sketch_dev([genomes[fastas[i]] for i in mine_idx], k, new_w, bf, ml, repeat=rep_bf)
@@ -698,7 +770,10 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         doomed = [f"{out_prefix}.synteny_blocks.tsv", f"{out_prefix}.pre-collinear-merge.synteny_blocks.tsv"]
         if rank == 0 and bf is not None:
             doomed.append(f"{prefix}.common.bf")
-        doomed += [tsv_names[i] for i, p in enumerate(fastas) if owner[p] == rank and write_mx_tsv]
+        if shard_mode:
+            doomed += [tsv_names[shard["genome"]]] if shard["leader"] and write_mx_tsv else []
+        else:
+            doomed += [tsv_names[i] for i, p in enumerate(fastas) if owner[p] == rank and write_mx_tsv]
         for name in doomed:
             if os.path.exists(name):
                 os.remove(name)
@@ -726,6 +801,8 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     for g in genomes.values():
         if hasattr(g, "free"):
             g.free()
+    if shard is not None:
+        shard["sub"].free()
     if bf is not None and hasattr(bf, "free"):
         bf.free()
     if own_backend:

@@ -75,10 +75,21 @@ def main():
             hdr_end = blob.index(b"[HeaderEnd]\n") + len(b"[HeaderEnd]\n")
         bits = np.fromfile(os.path.join(hip_dir, "e2e.common.bf"), dtype=np.uint8, offset=hdr_end)
         same["common filter bits"] = bool(bits.size == ora.bf.size and np.array_equal(bits, ora.bf))
+        # the whole minimizer output and the filter as digests, for the suite's full-size identity test (tests/test_gpu_scale.py)
+        from ntsynt_amd import fasta as fa
+        digests = {}
+        for p in paths:
+            n = f"{os.path.basename(p)}.k{a.k}.w{a.w}.tsv"
+            _, h1, pos, line = fa.read_indexlr_tsv(os.path.join(ora_dir, n))     # (lines are the FASTA's records, in order)
+            digests[n] = bench.mx_digest(h1, line, pos)
+        pad = (-ora.bf.size) % 8
+        words = np.concatenate([ora.bf, np.zeros(pad, dtype=np.uint8)]).view(np.uint64) if pad else ora.bf.view(np.uint64)
+        filter_popcount = int(np.bitwise_count(words).sum(dtype=np.uint64))
         tsv = ora.outputs["e2e.synteny_blocks.tsv"]
         rec = {"key": bench.e2e_key(args, args.genomes, total_bp, args.contigs, args.divergence),
                "oracle_md5": hashlib.md5(tsv.encode()).hexdigest(), "product_md5": product["tsv_md5"],
                "identical": same, "all_identical": all(same.values()),
+               "oracle_minimizer_digests": digests, "oracle_filter_bytes": int(ora.bf.size), "oracle_filter_popcount": filter_popcount,
                "oracle_seconds": round(ora_s, 1), "oracle_threads": args.threads, "product_seconds": product["seconds"],
                "oracle_peak_rss_bytes": ora_rss, "product_peak_hbm_bytes": product.get("peak_hbm_bytes"),
                "blocks": product["blocks"], "engine_stats": product["engine_stats"],

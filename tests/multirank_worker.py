@@ -83,6 +83,40 @@ def main():
         assert np.array_equal(bf.to_numpy(), expect), "identity rank"
         bf.free()
         out["sizes"] = checked
+    elif case == "groups":
+        # fewer genomes than ranks: rank r holds the filter of a shard of genome r mod G; the common filter is the AND over genomes of
+        # the OR over each genome's shards.  Dense filters (chunks gathered) and all-but-empty ones (set-bit indices gathered).
+        G = 2
+        group_of = [r % G for r in range(world)]
+        modes = []
+        for nbytes, density in ((1000, 0.5), (123_456 + 8 * world, 0.4), (3_000_008, 0.3), (3_000_008, 0.0008), (64, 0.0)):
+            mine = filter_bytes(rank, nbytes, density)
+            bf = BloomFilter(ctx, nbytes, 24, world=world)
+            bf.from_numpy(mine)
+            comm.allreduce_groups(bf, group_of)
+            expect = np.full(nbytes, 0xFF, dtype=np.uint8)
+            for g in range(G):
+                union = np.zeros(nbytes, dtype=np.uint8)
+                for r in range(world):
+                    if group_of[r] == g:
+                        union |= filter_bytes(r, nbytes, density)
+                expect &= union
+            got = bf.to_numpy()
+            assert got.size == nbytes and np.array_equal(got, expect), f"grouped all-reduce differs at {nbytes} bytes, density {density}"
+            assert bf.popcount() == int(np.unpackbits(expect).sum())
+            modes.append(bool(comm.last_sparse()))
+            bf.free()
+        out["sparse"] = modes
+        # a group without a rank is refused (its OR would clear the filter)
+        bf = BloomFilter(ctx, 1000, 24, world=world)
+        try:
+            comm.allreduce_groups(bf, [0] * (world - 1) + [2])
+            raise AssertionError("a group without a rank was accepted")
+        except Exception as exc:                  # noqa: BLE001
+            if isinstance(exc, AssertionError):
+                raise
+            out["rejects_empty_group"] = True
+        bf.free()
     elif case == "allgather":
         # n_total lists, genome g on rank g mod world: uneven shares, an empty list, a rank that holds fewer than the others
         for n_total, sizes in ((5, [1000, 0, 37, 4099, 1]), (world, [3] * world), (2 * world + 1, [11 * (g + 1) for g in range(2 * world + 1)])):

@@ -253,3 +253,23 @@ def test_minimizer_tsv_reader(tmp_path):
     assert os.path.getsize(tmp_path / "big.tsv") > (8 << 20)
     ids, h1, pos, line = fa.read_indexlr_tsv(str(tmp_path / "big.tsv"))
     assert len(ids) == 3000 and h1.tolist() == [r[0] for r in rows] and pos.tolist() == [r[1] for r in rows] and line.tolist() == [r[2] for r in rows]
+
+
+def test_shard_plan_and_mask_renumbering():
+    "fewer genomes than GPUs: groups of ranks per genome, record ranges balanced by bases, masks renumbered for a slice"
+    from ntsynt_amd.pipeline import shard_masks, shard_plan
+    group_of, ranges = shard_plan([[100, 100, 100, 100], [400], [10, 10, 300, 10, 10, 60]], 8)
+    assert group_of == [0, 1, 2, 0, 1, 2, 0, 1]
+    by_g = {g: [ranges[r] for r in range(8) if ranges[r][0] == g] for g in range(3)}
+    for g, n_rec in ((0, 4), (1, 1), (2, 6)):
+        rs = by_g[g]
+        assert [x[1] for x in rs] == list(range(len(rs))) and rs[0][2] == 0 and rs[-1][3] == n_rec
+        assert all(a[3] == b[2] for a, b in zip(rs, rs[1:])) and all(a[2] <= a[3] for a in rs)
+    assert [x[2:] for x in by_g[0]] == [(0, 2), (2, 3), (3, 4)] or sum(b - a for _, _, a, b in by_g[0]) == 4
+    assert [x[2:] for x in by_g[1]] == [(0, 0), (0, 0), (0, 1)] or sum(b - a for _, _, a, b in by_g[1]) == 1   # one record: one rank has it
+    iv = np.zeros(4, dtype=np.dtype([("rec", np.uint32), ("start", np.uint64), ("end", np.uint64)], align=True))
+    iv["rec"] = [0, 2, 3, 5]
+    iv["start"] = [5, 6, 7, 8]
+    got = shard_masks(iv, 2, 5)
+    assert got["rec"].tolist() == [0, 1] and got["start"].tolist() == [6, 7] and iv["rec"].tolist() == [0, 2, 3, 5]
+    assert shard_masks([(0, 1, 2), (4, 3, 9)], 3, 6) == [(1, 3, 9)] and shard_masks(None, 0, 1) is None

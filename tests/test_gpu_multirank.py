@@ -71,6 +71,57 @@ def test_bf_allreduce_and_one_piece(world, tmp_path):
     assert len(outs) == world
 
 
+@pytest.mark.parametrize("world", [3, 4])
+def test_bf_allreduce_groups_between_ranks(world, tmp_path):
+    """exchange 1 with fewer genomes than ranks (nts_bf_allreduce_groups): AND over genomes of the OR over a genome's shards, one
+    W-way reduction kernel per piece on a second stream, pieces forced small so that transfer and reduction alternate between
+    the two scratch halves; an all-but-empty result travels as set-bit indices"""
+    outs = _ranks(world, "groups", tmp_path, NTS_COMM_PIECE="65536")
+    for o in outs:
+        assert o["sparse"] == [False, False, False, True, True] and o["rejects_empty_group"]
+    outs = _ranks(world, "groups", tmp_path, NTS_COMM_SPARSE="0")        # the same through the dense all-gather only
+    assert all(o["sparse"] == [False] * 5 for o in outs)
+
+
+def test_genome_slice_and_list_concat_on_one_rank(tmp_path):
+    "nts_genome_slice + nts_mx_concat: the shards of a genome give its filter (OR) and its minimizer list (concatenation) exactly"
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from ntsynt_amd.device import BloomFilter, Context, Minimizers, bf_size_bytes, sketch
+    from ntsynt_amd.pipeline import shard_plan
+    from tests.helpers import random_records, to_device
+    ctx = Context(0)
+    rng = np.random.default_rng(5)
+    seqs = random_records(rng, [90_000, 0, 1500, 300_000, 40, 120_000, 2500, 60_000])
+    names = [f"r{i}" for i in range(len(seqs))]
+    g = to_device(ctx, names, seqs)
+    k, w = 24, 200
+    _, nbytes = bf_size_bytes(g.total_bp, 0.025)
+    whole = BloomFilter(ctx, nbytes, k)
+    whole.insert(g)
+    full = sketch(ctx, g, k, w, whole).to_numpy()
+    for n_shards in (2, 3, 5):
+        _, ranges = shard_plan([[len(s) for s in seqs], [1]], 2 * n_shards)      # genome 0 over the even ranks
+        cuts = [ranges[r][2:] for r in range(0, 2 * n_shards, 2)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(seqs) and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        union = BloomFilter(ctx, nbytes, k)
+        parts = []
+        for r0, r1 in cuts:
+            sub = g.slice(r0, r1)
+            assert sub.total_bp == sum(len(s) for s in seqs[r0:r1])
+            union.insert(sub)                                                     # OR into the same filter
+            parts.append(sketch(ctx, sub, k, w, whole))
+            sub.free()
+        assert np.array_equal(union.to_numpy(), whole.to_numpy())
+        cat = Minimizers.concat(ctx, parts, [c[0] for c in cuts])
+        for a, b in zip(cat.to_numpy(), full):
+            assert np.array_equal(a, b)
+        for m in parts + [cat]:
+            m.free()
+        union.free()
+    ctx.close()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_mx_allgather_between_ranks(world, tmp_path):
     "exchange 2: uneven list counts per rank, an empty list, lists of very different lengths; repeated genome numbers rejected"
@@ -90,6 +141,52 @@ def test_bench_two_ranks(tmp_path):
     assert out["config"]["exchanges"].startswith("libntsynt_hip.so (nts_bf_allreduce_and, nts_mx_allgather)")
     assert out["bloom"]["allreduce_and_s"] > 0
     assert "e2e" not in out and "cpu_baseline" not in out          # single-GPU legs only
+
+
+def test_bench_headline_workload_on_more_gpus_than_genomes(tmp_path):
+    "bench.py --gpus 4 --workload c3 (three genomes): records sharded over the groups' ranks instead of an exit"
+    r = _torchrun(4, [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--workload", "c3", "--mbp", "8", "--contigs", "4"],
+                  {"NTS_BENCH_BACKEND": "gloo"}, tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["value"] > 0 and "c3: 3 synthetic" in out["config"]["workload"]
+    assert "3 genomes over 4 GPUs" in out["config"]["parallelism"] and out["bloom"]["allreduce_and_s"] > 0
+    assert out["config"]["exchanges"].startswith("libntsynt_hip.so")
+    # the same family on one rank: the same number of minimizers per step
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "c3", "--mbp", "8", "--contigs", "4",
+                          "--no-e2e", "--no-cpu-baseline", "--no-dense-leg", "--no-cold-leg", "--no-c4-leg", "--no-nruns-leg", "--no-c5-leg"],
+                         cwd=tmp_path, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert ref["config"]["bases_per_step"] == out["config"]["bases_per_step"]
+    assert out["config"]["minimizers_per_step_all_genomes"] == ref["config"]["minimizers_per_step_rank0"]
+
+
+@pytest.mark.parametrize("world,n_genomes,contigs", [(4, 3, 3), (5, 2, 2), (3, 2, 1)])
+def test_pipeline_with_fewer_genomes_than_ranks_matches_single_rank(world, n_genomes, contigs, tmp_path):
+    """bin/ntSynt under torchrun with MORE ranks than genomes: every genome's records are shared out over the ranks of its group
+    (pipeline.shard_plan), the shards' filters are OR-ed inside the group and AND-ed across groups in one exchange
+    (nts_bf_allreduce_groups), every round's shard lists are gathered and strung together per genome (nts_mx_concat) -- byte for
+    byte what one rank writes, filter file and minimizer TSVs included.  (5 ranks on 2 genomes of 2 records: a rank with no
+    record at all; 3 ranks on 2 single-record genomes: likewise.)"""
+    from ntsynt_amd import synth
+    paths = synth.make_family(str(tmp_path), n_genomes, 1_500_000, contigs, 0.01, seed=45, micro=6, n_runs=True)
+    one = tmp_path / "one"
+    many = tmp_path / "many"
+    os.makedirs(one)
+    os.makedirs(many)
+    args = ["-k", "24", "-w", "500", "-d", "1", "--prefix", "p", "--indel", "5000", "--merge", "20000", "--force"] + paths
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.run([sys.executable, os.path.join(ROOT, "bin", "ntSynt")] + args, cwd=one, env=env, check=True,
+                   stdout=subprocess.DEVNULL, timeout=600)
+    r = _torchrun(world, [os.path.join(ROOT, "bin", "ntSynt")] + args, {"NTS_DIST_BACKEND": "gloo", "NTS_COMM_PIECE": "262144"}, many)
+    assert r.returncode == 0, r.stderr[-3000:]
+    names = ["p.synteny_blocks.tsv", "p.pre-collinear-merge.synteny_blocks.tsv", "p.common.bf"]
+    names += [os.path.basename(p) + ".k24.w500.tsv" for p in paths] + [os.path.basename(p) + ".fai" for p in paths]
+    for name in names:
+        assert (one / name).read_bytes() == (many / name).read_bytes(), name
+    assert len((one / "p.synteny_blocks.tsv").read_text().splitlines()) >= 4
+    assert not [n for n in os.listdir(many) if n.startswith(".ntsynt_rank")]
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -120,3 +120,41 @@ def test_records_longer_than_2_to_32(ctx):
     for g in (g0, g1):
         g.free()
     common.free()
+
+
+@pytest.mark.parametrize("record,family,div", [("r04_e2e_oracle_c3.json", "structural", 0.01), ("r04_e2e_oracle_c5_like.json", "assembly-like", 0.013)])
+def test_whole_output_at_headline_size_equals_the_recorded_oracle_run(ctx, record, family, div):
+    """BASELINE configs[2] (and configs[4]'s parameters on the assembly-like family) at full size, the WHOLE output: the common
+    filter's popcount and an order-independent digest of every genome's complete minimizer list (3 x ~6 M minimizers) against what
+    the CPU oracle pipeline left on record when it ran on these very families on a GPU box's host cores (scripts/e2e_oracle_check.py
+    -> profiles/: 8 minutes of CPU, so it is a record, not a step of the suite).  The slices above compare a few Mbp with a live
+    oracle; this compares everything with a recorded one."""
+    import argparse
+    import json
+    import os
+    import bench
+    from ntsynt_amd.device import BloomFilter, bf_size_bytes, sketch
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", record)
+    if not os.path.exists(path):
+        pytest.skip(f"{record}: no full-size oracle record committed")
+    rec = json.load(open(path))
+    assert rec["all_identical"]
+    args = argparse.Namespace(family=family, substitutions_only=False, k=24, w=1000, fpr=0.025)
+    total, contigs = 3_000_000_000, 24
+    assert rec["key"] == bench.e2e_key(args, 3, total, contigs, div), "the record is for another family / parameter set"
+    genomes = [bench.family_genome(ctx, args, total, contigs, j, div / 2.0) for j in range(3)]
+    _, nbytes = bf_size_bytes(genomes[0].total_bp, 0.025)           # (syn0.fa sorts first: it sizes the filter, cpp:105-118)
+    assert nbytes == rec["oracle_filter_bytes"]
+    common = BloomFilter(ctx, nbytes, 24)
+    common.insert(genomes[0])
+    for g in genomes[1:]:
+        common.insert_and(g)
+    assert common.popcount() == rec["oracle_filter_popcount"]
+    for j, g in enumerate(genomes):
+        mx = sketch(ctx, g, 24, 1000, common)
+        h1, r, pos = mx.to_numpy()
+        mx.free()
+        assert bench.mx_digest(h1, r, pos) == rec["oracle_minimizer_digests"][f"syn{j}.fa.k24.w1000.tsv"], j
+    common.free()
+    for g in genomes:
+        g.free()
