@@ -79,6 +79,7 @@ def test_bf_allreduce_groups_between_ranks(world, tmp_path):
     outs = _ranks(world, "groups", tmp_path, NTS_COMM_PIECE="65536")
     for o in outs:
         assert o["sparse"] == [False, False, False, True, True] and o["rejects_empty_group"]
+    os.remove(tmp_path / f"id_groups_{world}")                           # (a second communicator: a second id)
     outs = _ranks(world, "groups", tmp_path, NTS_COMM_SPARSE="0")        # the same through the dense all-gather only
     assert all(o["sparse"] == [False] * 5 for o in outs)
 
