@@ -882,10 +882,12 @@ def main():
             # the microbenchmark measures for the classes of the kernel's instruction mix
             key = "k_hash_select_hi" if hi_kernel else "k_hash_select"
             per_64 = 17.2 if hi_kernel else 29.8
-            for rnd in (3, 2):
+            sq_source = None
+            for rnd in (4, 3, 2):
                 try:
                     sq = json.load(open(os.path.join(ROOT, "profiles", f"r0{rnd}_sq_counters.json")))
                     per_64 = float(sq["kernels"][key]["valu_wave_instructions_per_64_kmers"])
+                    sq_source = f"profiles/r0{rnd}_sq_counters.json"
                     break
                 except (OSError, KeyError, ValueError):
                     continue
@@ -914,7 +916,7 @@ def main():
                 # (alignbit, bfi, lshl_add_u64 class): the roof of that mix
                 peak_v = 29.0 / (12.0 / fast + 17.0 / slow)
                 mix = "12 two-operand + 17 three-operand or 64-bit per k-mer"
-            valu.update({"kernel": key, "valu_wave_instr_per_64_kmers": per_64, "achieved": round(ach_v, 3),
+            valu.update({"kernel": key, "valu_wave_instr_per_64_kmers": per_64, "sq_source": sq_source, "achieved": round(ach_v, 3),
                          "peak": round(peak_v, 3), "frac": round(ach_v / peak_v, 3), "mix": mix,
                          "peak_if_all_slow_class": slow, "peak_if_all_fast_class": fast})
         out = {
@@ -983,7 +985,7 @@ def main():
             "from_committed_profiles": {
                 "traffic": (pm or {}).get("source"),
                 "achieved_at_128B_per_probe (its bytes)": (pm or {}).get("source"),
-                "valu.valu_wave_instr_per_64_kmers": "profiles/r03_sq_counters.json (SQ_INSTS_VALU pass)" if valu and "kernel" in valu else None,
+                "valu.valu_wave_instr_per_64_kmers": (valu.get("sq_source") or "built-in constant") + " (SQ_INSTS_VALU pass)" if valu and "kernel" in valu else None,
                 "valu.mix, valu.peak": "profiles/r03_valu_mix.json (instruction classes counted from the ISA) priced at this run's measured issue rates"
                 if valu and "kernel" in valu else None},
             "constants": {"peak": "MI355X_MICROARCH.md: HBM3E 8 TB/s", "algorithmic_bytes_per_base": "SURVEY.md 8(d): 64 B per probe; DESIGN.md 4.1"}}
@@ -1039,7 +1041,7 @@ def pmc_traffic(name, pruned_run, algorithmic_bytes=None, line_bytes=None):
     section prescribes for gfx950: FETCH_SIZE tallies every 128-byte request at 64 B, so it is doubled (the probes of this
     kernel are 128-byte requests one and all: profiles/r02_probe_granularity.md; so are its 16-byte-per-lane LDS-DMA reads of
     the base words); WRITE_SIZE is taken as it is (uncalibrated in the guide)."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (3, 2)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (4, 3, 2)) if os.path.exists(q)), None)
     if name != "c3" or path is None:
         return None
     kernels = json.load(open(path))["kernels"]

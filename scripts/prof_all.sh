@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof
 mkdir -p $O
-LEGS="--no-cpu-baseline --no-e2e --no-c4-leg --no-cold-leg --no-nruns-leg"
+LEGS="--no-cpu-baseline --no-e2e --no-c4-leg --no-cold-leg --no-nruns-leg --no-c5-leg"
 B1="python bench.py --steps 1 --warmup 0 $LEGS --no-dense-leg"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --steps 5 --warmup 2 $LEGS > $O/stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 1 --warmup 0 $LEGS > $O/pf.log 2>&1
@@ -34,6 +34,11 @@ rm -rf $O/c4_sq1 $O/c4_sq2 $O/c4_sq3 $O/c4_f $O/c4_w
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats4 -o s -- python bench.py --workload c4 --steps 2 --warmup 1 $LEGS --no-dense-leg > $O/stats4.log 2>&1
 find $O/stats4 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_c4.csv
 python profiles/summarize.py $O/kernel_stats_c4.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload c4 --steps 2 --warmup 1 (8 x 3 Gbp at 10 % on one GPU)" > $O/kernel_stats_c4.md
+# the assembly-like family (the c5_like leg's): kernel stats of sketch + Bloom build
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats5 -o s -- python bench.py --family assembly-like --divergence 0.013 --steps 3 --warmup 1 $LEGS --no-dense-leg > $O/stats5.log 2>&1
+find $O/stats5 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_c5_like.csv
+python profiles/summarize.py $O/kernel_stats_c5_like.csv "rocprofv3 --kernel-trace --stats -- python bench.py --family assembly-like --divergence 0.013 --steps 3 --warmup 1 (3 x 3 Gbp assembly-like genomes)" > $O/kernel_stats_c5_like.md
+rm -rf $O/stats5
 # end to end (FASTA files -> TSV)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_e2e -o s -- python scripts/e2e_synth.py > $O/e2e.json 2> $O/e2e.log
 find $O/stats_e2e -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_e2e.csv
