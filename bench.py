@@ -557,29 +557,14 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = Context(local_rank)
     ctx.sketch_mode(args.mode, args.prune_c)
-    # The two exchanges run inside libntsynt_hip.so over RCCL (nts_bf_allreduce_and, nts_mx_allgather).  Should the library's
-    # communicator not come up on this node (it has only ever been brought up with one rank), the bench still measures the
-    # sketch: the exchanges then go through torch.distributed on device tensors, and the line says so (config.exchanges).
+    # The two exchanges run inside libntsynt_hip.so over RCCL (nts_bf_allreduce_and / _groups, nts_mx_allgather) and nowhere else:
+    # a communicator that does not come up ends the run with its error (round 3 fell back to torch.distributed here)
     comm, exchanges = None, "none (one GPU)"
     pg_dev = "cpu" if shared_gpus else f"cuda:{local_rank}"
     if world > 1:
-        try:
-            comm = Comm.from_torch(ctx)
-            served_by = ctx.lib.nts_comm_library().decode()
-            exchanges = f"libntsynt_hip.so (nts_bf_allreduce_and, nts_mx_allgather) over {'RCCL' if served_by == 'librccl' else served_by}"
-        except Exception as exc:                              # noqa: BLE001 -- any failure of the communicator set-up
-            if shared_gpus:
-                raise
-            exchanges = f"torch.distributed (library communicator failed: {exc})"
-            print(f"[bench] rank {rank}: {exchanges}", file=sys.stderr, flush=True)
-        # every rank must take the same path
-        ok = torch.tensor([1 if comm is not None else 0], device=pg_dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
-            exchanges = "torch.distributed (library communicator failed on another rank)"
-    torch_comm = world > 1 and comm is None
+        comm = Comm.from_torch(ctx)
+        served_by = ctx.lib.nts_comm_library().decode()
+        exchanges = f"libntsynt_hip.so (nts_bf_allreduce_and, nts_mx_allgather) over {'RCCL' if served_by == 'librccl' else served_by}"
     k, w = args.k, args.w
     total_bp = int(mbp * 1e6)
 
@@ -592,8 +577,6 @@ def main():
         # (ntsynt_amd.pipeline.shard_plan); the shards' filters are OR-ed inside the group and AND-ed across groups in exchange 1
         # (nts_bf_allreduce_groups), the shards' lists strung together per genome behind exchange 2 (nts_mx_concat)
         from ntsynt_amd import pipeline, synth
-        if comm is None:
-            raise SystemExit("record sharding (fewer genomes than GPUs) needs the library's communicator")
         if args.substitutions_only:
             rec_lens = [[total_bp // contigs] * contigs] * n_fam
         elif args.family == "assembly-like":
@@ -619,14 +602,7 @@ def main():
     _, nbytes = bf_size_bytes(fam_bases[0], args.fpr)               # sized by the first file of the family, on every rank (A1)
     ctx.profile(True)
     t0 = time.time()
-    if torch_comm:
-        from ntsynt_amd import dist as ndist
-        from ntsynt_amd.device import and_raw, wrap_bloom
-        buf = torch.zeros(ndist.padded_len(nbytes, world), dtype=torch.uint8, device=f"cuda:{local_rank}")
-        torch.cuda.synchronize()
-        common = wrap_bloom(ctx, buf, nbytes, k)
-    else:
-        common = BloomFilter(ctx, nbytes, k, world=world if comm is not None else 1)
+    common = BloomFilter(ctx, nbytes, k, world=world if comm is not None else 1)
     common.insert(genomes[0])
     occ_single = common.get_fpr()
     for g in genomes[1:]:
@@ -638,14 +614,8 @@ def main():
         t1 = time.time()
         if shard is not None:
             comm.allreduce_groups(common, shard["group_of"])
-        elif comm is not None:
+        else:
             comm.allreduce_and(common)
-        elif torch_comm:
-            def and_into(a, b):
-                and_raw(ctx, a.data_ptr(), b.data_ptr(), a.numel())
-                ctx.sync()
-            ndist.allreduce_and(buf, and_into)
-            torch.cuda.synchronize()
         ctx.sync()
         t_allreduce = time.time() - t1
     ins_ms, ins_n = ctx.timing("bf_insert")
@@ -703,14 +673,10 @@ def main():
                 shard["n_all"] = n_all
                 for mx in parts:
                     mx.free()
-            elif comm is not None:
+            else:
                 everything = comm.allgather_minimizers(held, mine, n_fam)
                 for mx in everything:
                     mx.free()
-            else:
-                local = [mx.to_numpy() for mx in held]
-                box = [None] * world
-                dist.all_gather_object(box, local)
         for mx in held:
             mx.free()
         return n

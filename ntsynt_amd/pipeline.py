@@ -403,7 +403,7 @@ def _exchange_lists(backend, local, n_total):
 def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000, merge=10000,
         block_size=500, common=True, simplify=True, device=0, write_mx_tsv=True, mx_with_seq=True,
         benchmark=False, log=print, ctx=None, backend=None, bf_rounding="up", bf_signature=BF_SIGNATURE, dev=False, interarrivals=False, repeat=False,
-        mx_tsvs=None, common_file=None, m=90, n=0, initial_only=False, write_fai=True):
+        mx_tsvs=None, common_file=None, m=90, n=0, initial_only=False, write_fai=True, engine="device"):
     """FASTA paths -> engine (outputs in .outputs and in the CWD).  Mirrors oracle.synteny_oracle.run_pipeline's
     signature so the parity tests read alike.  Under torch.distributed (WORLD_SIZE > 1, process group already
     initialised by the caller) genomes are sharded over the ranks.
@@ -441,7 +441,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     owner = {p: i % world for i, p in enumerate(fastas)}
     mine = [p for p in fastas if owner[p] == rank]
     # fewer genomes than GPUs: every genome is shared out by records over a group of ranks (shard_plan); the device engine only
-    shard_mode = (world > len(fastas) and isinstance(backend, GpuBackend) and os.environ.get("NTS_ENGINE", "device") != "host"
+    shard_mode = (world > len(fastas) and isinstance(backend, GpuBackend) and engine != "host"
                   and mx_tsvs is None and not repeat and os.environ.get("NTS_SHARD_RECORDS", "1") != "0")
     if shard_mode:
         mine = [fastas[rank % len(fastas)]]                     # the genome of this rank's group (loaded whole, cut below)
@@ -565,12 +565,8 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
             if shard_mode:
                 backend.ctx.sync()
                 backend.comm.allreduce_groups(bf, shard["group_of"])
-            elif hasattr(backend, "allreduce_and"):
-                backend.allreduce_and(bf)
-            else:                                              # test doubles: CPU tensors
-                from .dist import allreduce_and
-                backend.sync()
-                allreduce_and(bf.tensor, backend.and_into)
+            else:
+                backend.allreduce_and(bf)                      # GpuBackend: nts_bf_allreduce_and; test doubles bring their own
         log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
         st.stop()
         st.mark("common_filter_done")
@@ -610,9 +606,10 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         own.free()
         rep_bf.save(f"{prefix}.repeat.bf", bf_header(rep_bytes, k, signature=bf_signature))
 
-    # Graph stage: resident in HBM (ntsynt_amd/synteny_device.py) on the GPU backend; NTS_ENGINE=host selects the
-    # host-array twin (ntsynt_amd/synteny.py), which test doubles without a GPU use as well.
-    device_engine = isinstance(backend, GpuBackend) and os.environ.get("NTS_ENGINE", "device") != "host"
+    # Graph stage: resident in HBM (ntsynt_amd/synteny_device.py) on the GPU backend.  engine="host": its host-array twin
+    # (ntsynt_amd/synteny.py, the class the device engine derives from) for a whole run -- an argument of this function that the
+    # lockstep tests and the CPU test doubles use, not a switch a user of the command line has.
+    device_engine = isinstance(backend, GpuBackend) and engine != "host"
     if rep_bf is not None and not device_engine:
         raise ValueError("the repeat filter is served by the device engine only")
     tsv_names = [f"{fa.basename(p)}.k{k}.w{w}.tsv" for p in fastas]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """FASTA files on disk -> final synteny TSV at full size with the family generated in HBM (what bench.py's e2e leg does),
-per stage and, with NTS_ENGINE_TIMES=1, per step of the graph stage; NTS_ENGINE=host runs the host-array engine.
+per stage and, with NTS_ENGINE_TIMES=1, per step of the graph stage; --engine host runs the host-array twin of the graph stage.
 
   NTS_ENGINE_TIMES=1 python scripts/e2e_synth.py --mbp 3000 --genomes 3 --contigs 24 --divergence 0.01
 """

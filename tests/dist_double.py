@@ -1,5 +1,8 @@
-"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed over RCCL/xGMI
-(SURVEY.md 8(e)).  Genomes are partitioned over ranks; two exchange steps exist:
+"""TEST INFRASTRUCTURE (moved out of the package in round 4: the product's exchanges are nts_bf_allreduce_and / _groups and
+nts_mx_allgather in csrc/nts_comm.inc, and nothing else): a torch.distributed statement of the same two exchange schedules, with
+which the CPU test doubles of tests/test_dist_*.py exercise ntsynt_amd.pipeline's multi-rank orchestration over gloo.
+
+Multi-GPU sharding of the hot path: genomes are partitioned over ranks; two exchange steps exist:
 
   1. common Bloom filter = bitwise AND of the per-genome filters.  RCCL has no
      bitwise reduction, so the all-reduce is: direct reduce-scatter (every rank sends chunk j of its

@@ -1,5 +1,5 @@
 """The N>1 path on CPU: world_size-2 and -3 `gloo` process groups exercising the schedule of
-ntsynt_amd/dist.py (bitwise-AND all-reduce = direct reduce-scatter + local AND + all-gather; all-gather(v)
+tests/dist_double.py (bitwise-AND all-reduce = direct reduce-scatter + local AND + all-gather; all-gather(v)
 of minimizer lists; genome->rank partition).  The AND operator is injected: on the GPU it is the HIP
 kernel behind nts_and_raw, here a tensor op stands in so the communication pattern can run without a GPU."""
 import os
@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ntsynt_amd import dist as ndist
+from tests import dist_double as ndist
 
 
 def _free_port():

@@ -33,7 +33,7 @@ class OracleBackend:
         pass
 
     def bf_new(self, nbytes, k, world=1, ones=False):
-        from ntsynt_amd.dist import padded_len
+        from tests.dist_double import padded_len
         bf = self._BF()
         bf.k, bf.nbytes = k, nbytes
         n = padded_len(nbytes, world) if world > 1 else nbytes
@@ -64,6 +64,11 @@ class OracleBackend:
 
     def and_into(self, a, b):
         a.bitwise_and_(b)
+
+    def allreduce_and(self, bf):
+        "exchange 1 of the test double: the schedule of tests/dist_double.py over gloo, CPU tensors"
+        from tests.dist_double import allreduce_and
+        allreduce_and(bf.tensor, self.and_into)
 
     def sync(self):
         pass

@@ -177,7 +177,6 @@ def test_device_engine_in_lockstep_with_host_engine(ctx, tmp_path, case):
 @pytest.mark.parametrize("engine", ["device", "host"])
 def test_both_engines_through_the_pipeline_match_the_oracle(tmp_path, monkeypatch, engine):
     from ntsynt_amd import pipeline
-    monkeypatch.setenv("NTS_ENGINE", engine)
     paths = synth.make_family(str(tmp_path), 3, 2_500_000, 30, 0.01, seed=12, micro=15, n_runs=True, soft_mask=True)
     kw = dict(k=24, w=300, w_rounds=[100, 20], indel=400, merge="10w", block_size=300)
     cwd = os.getcwd()
@@ -185,7 +184,7 @@ def test_both_engines_through_the_pipeline_match_the_oracle(tmp_path, monkeypatc
         os.makedirs(tmp_path / "hip")
         os.makedirs(tmp_path / "ora")
         os.chdir(tmp_path / "hip")
-        eng = pipeline.run(paths, prefix="p", log=lambda *a: None, **kw)
+        eng = pipeline.run(paths, prefix="p", log=lambda *a: None, engine=engine, **kw)
         os.chdir(tmp_path / "ora")
         ora = SO.run_pipeline(paths, prefix="p", **kw)
     finally:
