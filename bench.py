@@ -516,14 +516,7 @@ def c5_like_leg(args, ctx, device, total_bp, contigs, workdir):
     common.free()
     for g in gens:
         g.free()
-    if not args.no_e2e:
-        sub = os.path.join(workdir, "c5_like")
-        os.makedirs(sub, exist_ok=True)
-        try:
-            out["e2e"] = e2e_leg(a5, device, 3, total_bp, contigs, div, sub)
-        finally:
-            shutil.rmtree(sub, ignore_errors=True)
-    return out
+    return out, a5, div
 
 
 def main():
@@ -974,18 +967,26 @@ def main():
         workdir = args.e2e_dir or tempfile.mkdtemp(prefix="nts_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
         os.makedirs(workdir, exist_ok=True)
         try:
+            c5 = None
             if name == "c3" and not args.no_c5_leg and args.family == "structural":
                 for g in genomes:
                     g.free()
                 common.free()
                 genomes, common = [], None
-                out["c5_like"] = c5_like_leg(args, ctx, local_rank, total_bp, contigs, workdir)
+                out["c5_like"], a5, div5 = c5 = c5_like_leg(args, ctx, local_rank, total_bp, contigs, workdir)
             if not args.no_e2e:
-                for g in genomes:                                    # everything of the sketch legs goes, the pipeline
-                    g.free()                                         # starts from files like a user's run
-                if common is not None:
+                for g in genomes:                                    # everything of the sketch legs goes (workspaces included: the
+                    g.free()                                         # e2e legs' peak-memory figures are the pipeline's own), the
+                if common is not None:                               # pipeline starts from files like a user's run
                     common.free()
                 ctx.close()
+                if c5 is not None:
+                    sub = os.path.join(workdir, "c5_like")
+                    os.makedirs(sub, exist_ok=True)
+                    try:
+                        out["c5_like"]["e2e"] = e2e_leg(a5, local_rank, 3, total_bp, contigs, div5, sub)
+                    finally:
+                        shutil.rmtree(sub, ignore_errors=True)
                 out["e2e"] = e2e_leg(args, local_rank, n_fam, total_bp, contigs, div, workdir)
         finally:
             if not args.e2e_dir:
