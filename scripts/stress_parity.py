@@ -40,6 +40,9 @@ def main(argv=None):
                 lengths.append(int(rng.choice([0, 5, k - 1, k, k + 1, 1000, 17000, 60000])))
         n_frac = float(rng.choice([0.0, 0.001, 0.01]))
         seqs = random_records(rng, lengths, n_frac=n_frac)
+        if rng.random() < 0.4:        # (round 4) a satellite-like array: the copies of a unit pile into a few Bloom buckets
+            unit = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(rng.integers(5, 200)))])
+            seqs.append(unit * int(rng.integers(200, 40000 // len(unit) * 20 + 201)))
         names = [f"r{i}" for i in range(len(seqs))]
         og, dg = to_oracle(names, seqs), to_device(ctx, names, seqs)
         # a relative, for a common filter that accepts part of the k-mers
@@ -63,6 +66,22 @@ def main(argv=None):
                 print("BLOOM MISMATCH", dict(k=k, style=style, total=total, nbytes=nbytes, mode=mode, seed=args.seed, case=n_cases))
                 sys.exit(1)
             b.free()
+            # (round 4) the same level fused into the build's last pass, the parking list sometimes cut short
+            cap = rng.choice(["", "0", "7", "100000"])
+            if cap:
+                os.environ["NTS_BIN_LATE_CAP"] = str(cap)
+            else:
+                os.environ.pop("NTS_BIN_LATE_CAP", None)
+            f = BloomFilter(ctx, nbytes, k)
+            f.insert(dg)
+            if rng.random() < 0.5:
+                f.popcount()
+            f.insert_and(dg2)
+            os.environ.pop("NTS_BIN_LATE_CAP", None)
+            if not np.array_equal(f.to_numpy(), want) or f.popcount() != int(np.unpackbits(want).sum()):
+                print("FUSED AND MISMATCH", dict(k=k, style=style, total=total, nbytes=nbytes, mode=mode, cap=cap, seed=args.seed, case=n_cases))
+                sys.exit(1)
+            f.free()
             if mode == "atomic":
                 a.free()
         ctx.bf_build_mode("auto")
@@ -95,6 +114,32 @@ def main(argv=None):
                         sys.exit(1)
         ctx.sketch_mode("auto", 0)
         ctx.sketch_select("auto")
+        # (round 4) record shards: the shards' filters OR to the genome's, their lists concatenate to the genome's
+        if len(names) >= 2:
+            from ntsynt_amd.device import Minimizers
+            from ntsynt_amd.pipeline import shard_plan
+            n_sh = int(rng.integers(2, 6))
+            _, ranges = shard_plan([[len(x) for x in seqs], [1]], 2 * n_sh)
+            w = int(rng.choice([33, 250, 1000]))
+            whole_bf = BloomFilter(ctx, nbytes, k)
+            whole_bf.insert(dg)
+            union = BloomFilter(ctx, nbytes, k)
+            parts = []
+            for r in range(0, 2 * n_sh, 2):
+                sub = dg.slice(ranges[r][2], ranges[r][3])
+                union.insert(sub)
+                parts.append(sketch(ctx, sub, k, w, bf))
+                sub.free()
+            cat = Minimizers.concat(ctx, parts, [ranges[r][2] for r in range(0, 2 * n_sh, 2)])
+            full = sketch(ctx, dg, k, w, bf)
+            same = np.array_equal(union.to_numpy(), whole_bf.to_numpy()) and all(np.array_equal(x, y) for x, y in zip(cat.to_numpy(), full.to_numpy()))
+            for m in parts + [cat, full]:
+                m.free()
+            union.free()
+            whole_bf.free()
+            if not same:
+                print("SHARD MISMATCH", dict(k=k, w=w, style=style, n_sh=n_sh, seed=args.seed, case=n_cases))
+                sys.exit(1)
         batch.free()
         bf.free()
         dg.free()
