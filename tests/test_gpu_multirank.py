@@ -163,8 +163,8 @@ def test_bench_headline_workload_on_more_gpus_than_genomes(tmp_path):
     assert out["config"]["minimizers_per_step_all_genomes"] == ref["config"]["minimizers_per_step_rank0"]
 
 
-@pytest.mark.parametrize("world,n_genomes,contigs", [(4, 3, 3), (5, 2, 2), (3, 2, 1)])
-def test_pipeline_with_fewer_genomes_than_ranks_matches_single_rank(world, n_genomes, contigs, tmp_path):
+@pytest.mark.parametrize("world,n_genomes,contigs,extra", [(4, 3, 3, []), (5, 2, 2, []), (3, 2, 1, []), (4, 3, 2, ["--no-common", "--no-simplify-graph"])])
+def test_pipeline_with_fewer_genomes_than_ranks_matches_single_rank(world, n_genomes, contigs, extra, tmp_path):
     """bin/ntSynt under torchrun with MORE ranks than genomes: every genome's records are shared out over the ranks of its group
     (pipeline.shard_plan), the shards' filters are OR-ed inside the group and AND-ed across groups in one exchange
     (nts_bf_allreduce_groups), every round's shard lists are gathered and strung together per genome (nts_mx_concat) -- byte for
@@ -176,13 +176,13 @@ def test_pipeline_with_fewer_genomes_than_ranks_matches_single_rank(world, n_gen
     many = tmp_path / "many"
     os.makedirs(one)
     os.makedirs(many)
-    args = ["-k", "24", "-w", "500", "-d", "1", "--prefix", "p", "--indel", "5000", "--merge", "20000", "--force"] + paths
+    args = ["-k", "24", "-w", "500", "-d", "1", "--prefix", "p", "--indel", "5000", "--merge", "20000", "--force"] + extra + paths
     env = dict(os.environ, PYTHONPATH=ROOT)
     subprocess.run([sys.executable, os.path.join(ROOT, "bin", "ntSynt")] + args, cwd=one, env=env, check=True,
                    stdout=subprocess.DEVNULL, timeout=600)
     r = _torchrun(world, [os.path.join(ROOT, "bin", "ntSynt")] + args, {"NTS_DIST_BACKEND": "gloo", "NTS_COMM_PIECE": "262144"}, many)
     assert r.returncode == 0, r.stderr[-3000:]
-    names = ["p.synteny_blocks.tsv", "p.pre-collinear-merge.synteny_blocks.tsv", "p.common.bf"]
+    names = ["p.synteny_blocks.tsv", "p.pre-collinear-merge.synteny_blocks.tsv"] + ([] if "--no-common" in extra else ["p.common.bf"])
     names += [os.path.basename(p) + ".k24.w500.tsv" for p in paths] + [os.path.basename(p) + ".fai" for p in paths]
     for name in names:
         assert (one / name).read_bytes() == (many / name).read_bytes(), name
