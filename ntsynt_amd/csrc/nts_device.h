@@ -130,6 +130,38 @@ struct FastMod
   // quarter-rate multiplies instead of three).
   uint32_t inv32, m_lo, m_hi;
   uint32_t form; // 0 generic; 1: m > 2^32 (inv and the quotient fit 32 bits); 2: 2^32 < m < 2^38
+  // The same with the form fixed at compile time (kernels instantiated per form: k_bin1).  Left as a run-time field, `form` stays a
+  // branch per k-mer inside unrolled loops -- the compiler keeps all three forms there, materialises the uniform conditions through
+  // VCC for every k-mer and runs out of scalar registers (a dozen v_readlane per k-mer in k_bin1's hot loop).
+  template <int FORM> // (FORM < 0: the run-time field decides)
+  __device__ __forceinline__ uint64_t mod(uint64_t h) const
+  {
+    if (FORM < 0) return (*this)(h);
+    if (FORM != 0) {
+      const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
+      const uint64_t u = (uint64_t)hi * inv32 + __umulhi(lo, inv32);
+      const uint32_t q = (uint32_t)(u >> 32);
+      if (FORM == 2) {
+        const uint64_t p = (uint64_t)q * m_lo;
+        const uint32_t p_lo = (uint32_t)p;
+        const uint32_t r_lo = lo - p_lo;
+        uint32_t qm_hi;
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(qm_hi) : "s"(m_hi & 0x3Fu), "v"(q & 0x7Fu));
+        const uint32_t r_hi = (hi - (uint32_t)(p >> 32) - qm_hi - (lo < p_lo ? 1u : 0u)) & 0x7Fu;
+        uint64_t r = ((uint64_t)r_hi << 32) | r_lo;
+        if (r >= m) r -= m;
+        return r;
+      }
+      const uint64_t qm = (uint64_t)q * m_lo + ((uint64_t)(q * m_hi) << 32);
+      uint64_t r = h - qm;
+      if (r >= m) r -= m;
+      return r;
+    }
+    const uint64_t q = __umul64hi(h, inv);
+    uint64_t r = h - q * m;
+    if (r >= m) r -= m;
+    return r;
+  }
   __device__ __forceinline__ uint64_t operator()(uint64_t h) const
   {
     // Filters above 512 MiB (m > 2^32 bits, every genome beyond ~100 Mbp): inv and the quotient fit 32 bits, and the

@@ -3298,21 +3298,28 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
         // bases from the 2-bit image in registers (k_hash_accept4r); NTS_ACCEPT_REG=0: the LDS-staged kernel (tests)
         if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
         if (!ctx->acc4r_lds_set) {
-          HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4r<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(Accept4rLds)));
-          HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4r<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(Accept4rLds)));
+#define ACC4R_ATTR(B, F) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4r<B, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Accept4rLds)))
+          ACC4R_ATTR(8, 0);
+          ACC4R_ATTR(8, 1);
+          ACC4R_ATTR(8, 2);
+          ACC4R_ATTR(4, -1);
+#undef ACC4R_ATTR
           ctx->acc4r_lds_set = true;
         }
         // (persistent workgroups, one per CU -- 128 KiB of LDS each --, each loops over groups of four tiles; NTS_ACC4R_WGS overrides)
         const uint64_t groups4 = (n_kt + 3) / 4;
         const uint64_t wgs = getenv("NTS_ACC4R_WGS") ? (uint64_t)std::max(1, atoi(getenv("NTS_ACC4R_WGS"))) : 256ull;
+        const dim3 grid4((uint32_t)std::min<uint64_t>(groups4, wgs));
+#define ACC4R_RUN(B, F) hipLaunchKernelGGL((k_hash_accept4r<B, F>), grid4, dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A, g->d_pack, ctx->cur_fold, n_kt)
         if (getenv("NTS_ACC4R_BLOCK") && atoi(getenv("NTS_ACC4R_BLOCK")) == 4)
-          hipLaunchKernelGGL(k_hash_accept4r<4>, dim3((uint32_t)std::min<uint64_t>(groups4, wgs)), dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A,
-                             g->d_pack, ctx->cur_fold, n_kt);
+          ACC4R_RUN(4, -1); // (blocks of four, the modulus form read at run time: the kernel as it was, for comparisons)
+        else if (A.fm.form == 2)
+          ACC4R_RUN(8, 2);
+        else if (A.fm.form == 1)
+          ACC4R_RUN(8, 1);
         else
-          hipLaunchKernelGGL(k_hash_accept4r<8>, dim3((uint32_t)std::min<uint64_t>(groups4, wgs)), dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A,
-                             g->d_pack, ctx->cur_fold, n_kt);
+          ACC4R_RUN(8, 0);
+#undef ACC4R_RUN
       } else if (ctx->cur_fold) {
         if (!ctx->acc4_lds_set) {
           HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4), hipFuncAttributeMaxDynamicSharedMemorySize,

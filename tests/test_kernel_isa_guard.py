@@ -124,17 +124,31 @@ def test_bloom_build_kernels_keep_their_occupancy_and_batched_loads(code_object)
     spill reload would queue behind the stores of the tile before --, and k_bin2's four 16-byte loads of a whole tile issued
     together (the optimiser sinks each load to its first use unless a statement takes all sixteen values)."""
     co, notes = code_object
-    k1, k2 = "_ZN12_GLOBAL__N_16k_bin1ENS_9BinParamsE", "_ZN12_GLOBAL__N_16k_bin2ENS_10Bin2ParamsE"
-    for sym in (k1, k2):
+    k2 = "_ZN12_GLOBAL__N_16k_bin2ENS_10Bin2ParamsE"
+    k1s = [f"_ZN12_GLOBAL__N_16k_bin1ILi{form}EEEvNS_9BinParamsE" for form in (0, 1, 2)]      # one instantiation per form of `h mod bits`
+    for sym in k1s + [k2]:
         assert sym in notes, f"{sym} not found (renamed? update this guard with it)"
-    m1, m2 = _kernel_meta(notes, k1), _kernel_meta(notes, k2)
-    assert int(m1["vgpr_count"]) <= 64 and int(m2["vgpr_count"]) <= 64, (m1, m2)
-    assert int(m1["group_segment_fixed_size"]) * 2 <= 160 * 1024, m1      # two workgroups of k_bin1 per CU
+    m2 = _kernel_meta(notes, k2)
+    assert int(m2["vgpr_count"]) <= 64, m2
     assert int(m2["group_segment_fixed_size"]) * 4 <= 160 * 1024, m2      # four of k_bin2
     assert m2["private_segment_fixed_size"] == "0", m2
-    i1, i2 = _disassemble(co, k1), _disassemble(co, k2)
-    # k_bin1: at most the one reload of the rare path (a lane with a run boundary among its k-mers)
-    assert sum(i.startswith("scratch_load") for i in i1) <= 1, [i for i in i1 if i.startswith("scratch_")]
+    for k1 in k1s:
+        m1 = _kernel_meta(notes, k1)
+        assert int(m1["vgpr_count"]) <= 64, m1
+        assert int(m1["group_segment_fixed_size"]) * 2 <= 160 * 1024, m1  # two workgroups of k_bin1 per CU
+        i1 = _disassemble(co, k1)
+        # k_bin1: at most the one reload of the rare path (a lane with a run boundary among its k-mers)
+        assert sum(i.startswith("scratch_load") for i in i1) <= 1, [i for i in i1 if i.startswith("scratch_")]
+    # the form every filter beyond 512 MiB takes (2^32 < bits < 2^38): its unrolled loop over a whole tile inside one run is free of
+    # the scalar-register reloads (v_readlane) that a run-time `form` put there -- a dozen per k-mer, with all three forms and their
+    # branches in the loop: 90 instructions per k-mer instead of 46
+    i1 = _disassemble(co, k1s[2])
+    adds = [n for n, i in enumerate(i1) if i.startswith("ds_add_rtn_u32")]
+    gaps = sorted(b - a for a, b in zip(adds, adds[1:]))
+    assert len(adds) >= 16 and gaps[len(gaps) // 4] <= 55, gaps          # (the fast loop's eight k-mers: <= 55 instructions each)
+    fast = [a for a, b in zip(adds, adds[1:]) if b - a <= 55]
+    assert not [i for i in i1[fast[0]:fast[-1]] if i.startswith("v_readlane")]
+    i2 = _disassemble(co, k2)
     # k_bin2, whole-tile path: four global_load_dwordx4 with no wait for vector memory between them
     loads = [n for n, i in enumerate(i2) if i.startswith("global_load_dwordx4")]
     assert len(loads) == 4, loads
