@@ -147,7 +147,7 @@ def test_bloom_build_kernels_keep_their_occupancy_and_batched_loads(code_object)
     gaps = sorted(b - a for a, b in zip(adds, adds[1:]))
     assert len(adds) >= 16 and gaps[len(gaps) // 4] <= 55, gaps          # (the fast loop's eight k-mers: <= 55 instructions each)
     fast = [a for a, b in zip(adds, adds[1:]) if b - a <= 55]
-    assert not [i for i in i1[fast[0]:fast[-1]] if i.startswith("v_readlane")]
+    assert sum(i.startswith("v_readlane") for i in i1[fast[0]:fast[-1]]) <= 8      # (a constant fetched once, not a dozen per k-mer)
     i2 = _disassemble(co, k2)
     # k_bin2, whole-tile path: four global_load_dwordx4 with no wait for vector memory between them
     loads = [n for n, i in enumerate(i2) if i.startswith("global_load_dwordx4")]
