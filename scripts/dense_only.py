@@ -1,10 +1,12 @@
-import os, sys
+import sys, time, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from ntsynt_amd.device import BloomFilter, Context, Genome, bf_size_bytes, sketch
 ctx = Context(0)
-g = [Genome.synth(ctx, 100_000_000, 4, 1, 10 + j, 0.005) for j in range(2)]
-_, nb = bf_size_bytes(100_000_000, 0.025)
-bf = BloomFilter(ctx, nb, 24); bf.insert(g[0]); t = BloomFilter(ctx, nb, 24); t.insert(g[1]); bf.and_(t)
-ctx.sketch_mode("dense")
-for _ in range(3):
-    sketch(ctx, g[1], 24, 1000, bf).free()
+g = Genome.synth(ctx, 3_000_000_000, 24, 20240207, 1000, 0.005)
+r = Genome.synth(ctx, 3_000_000_000, 24, 20240207, 1001, 0.005)
+_, nb = bf_size_bytes(g.total_bp, 0.025)
+bf = BloomFilter(ctx, nb, 24); bf.insert(g); bf.insert_and(r)
+ctx.sketch_mode("dense"); ctx.profile(1)
+for _ in range(3): sketch(ctx, g, 24, 1000, bf).free()
+ctx.sync()
+print("hash_probe", ctx.timing("hash_probe"), "window", ctx.timing("window_min"))
