@@ -107,3 +107,50 @@ def test_reference_minimizer_files_through_the_stage3_command_line(tmp_path, gol
     finally:
         os.chdir(cwd)
     assert got == want and len(got.splitlines()) == n_blocks * len(keys)
+
+
+def test_stage_executables_options(tmp_path):
+    """--bf (explicit filter size, cpp:109-113), a gzip FASTA through indexlr with -o, indexlr without a filter, and stage 3
+    without --common (refinement rounds sketch unfiltered) -- each against the oracle on the same inputs"""
+    import gzip
+    import shutil
+    from oracle import nts_oracle as O
+    from ntsynt_amd.pipeline import read_bf
+    src = tmp_path / "in"
+    src.mkdir()
+    paths = synth.make_family(str(src), 2, 700_000, 2, 0.01, seed=52, micro=5, soft_mask=True)
+    k, w = 20, 300
+    # make_common_bf --bf: the size as given (+ the constructor's rounding), bits = the oracle's cascade at that size
+    _run([os.path.join(BIN, "ntsynt_make_common_bf"), "--genome", paths[1], paths[0], "-p", "sized", "-k", str(k), "--bf", "777777"], str(tmp_path))
+    bits, k_file = read_bf(str(tmp_path / "sized.bf"))
+    genomes = {p: O.read_fasta(p) for p in paths}
+    nbytes = O.bf_ctor_bytes(777777)
+    want = O.bf_build(genomes[sorted(paths)[1]], k, nbytes, prev=O.bf_build(genomes[sorted(paths)[0]], k, nbytes))
+    assert k_file == k and bits.size == nbytes and np.array_equal(bits, want)
+    # indexlr: gzip input, -o, with and without the filter
+    gz = str(tmp_path / "a.fa.gz")
+    with open(paths[0], "rb") as fi, gzip.open(gz, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    for label, extra, bf in (("filtered", ["-s", "sized.bf"], want), ("plain", [], None)):
+        out = tmp_path / f"{label}.tsv"
+        _run([os.path.join(BIN, "indexlr"), "-k", str(k), "-w", str(w), "--long", "--seq", "--pos", "-t", "5"] + extra + ["-o", str(out), gz], str(tmp_path))
+        ref = tmp_path / f"{label}.ora.tsv"
+        O.write_indexlr_tsv(str(ref), genomes[paths[0]], O.minimize(genomes[paths[0]], k, w, bf), k)
+        assert out.read_bytes() == ref.read_bytes() and out.stat().st_size > 1000, label
+    # stage 3 without --common: unfiltered initial lists in, unfiltered refinement sketches
+    tsvs = []
+    for p in paths:
+        t = f"{os.path.basename(p)}.k{k}.w{w}.tsv"
+        O.write_indexlr_tsv(str(tmp_path / t), genomes[p], O.minimize(genomes[p], k, w, None), k)
+        tsvs.append(t)
+    _run([os.path.join(BIN, "ntsynt_run.py")] + tsvs + ["-k", str(k), "-w", str(w), "--w-rounds", "100", "20", "-p", "nc", "--bp", "500", "--collinear-merge", "2w",
+                                                       "-z", "300", "--fastas"] + paths, str(tmp_path))
+    cwd = os.getcwd()
+    os.makedirs(tmp_path / "ora")
+    os.chdir(tmp_path / "ora")
+    try:
+        ora = SO.run_pipeline(paths, k=k, w=w, w_rounds=[100, 20], indel=500, merge="2w", block_size=300, prefix="nc", common=False, simplify=False)
+    finally:
+        os.chdir(cwd)
+    for n in ("nc.synteny_blocks.tsv", "nc.pre-collinear-merge.synteny_blocks.tsv"):
+        assert open(tmp_path / n).read() == ora.outputs[n], n
