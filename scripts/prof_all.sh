@@ -20,6 +20,7 @@ F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
 python profiles/pmc_summarize.py "$F" "$W" $O/pmc_traffic "python bench.py --steps 1 --warmup 0 $LEGS (3 x 3 Gbp, one launch sequence per genome; pruned step + dense leg + Bloom build)"
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_c3.csv
+grep '^{"metric"' $O/stats.log > $O/bench_under_rocprof.json   # the bench line of the profiled run itself: its HIP-event launch time next to rocprofv3's
 python profiles/summarize.py $O/kernel_stats_c3.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 $LEGS (3 x 3 Gbp)" > $O/kernel_stats_c3.md
 # config 4 on one GPU (8 x 3 Gbp at 10 %: accepted-list path), kernel stats + SQ counters and traffic of its select kernel
 C4="python bench.py --workload c4 --steps 1 --warmup 0 $LEGS --no-dense-leg"
