@@ -906,7 +906,10 @@ def main():
                        "parallelism": (f"{n_fam} genomes over {world} GPUs: the records of genome g shared out over the ranks r with r mod {n_fam} == g "
                                        f"(rank 0: records {shard['rec0']}..{shard['rec1']} of genome 0)" if shard is not None else
                                        f"genomes sharded over {world} GPU(s)") + (f"; the {n_at_once} genomes of a GPU sketched at once, a stream each" if n_at_once > 1 else ""),
-                       "synth_s": round(t_synth, 3)},
+                       "synth_s": round(t_synth, 3),
+                       # the N = 1 point of THIS workload's curve (the N = 1 bench line is quoted on c3; its `c4_n1` leg is c4 on one GPU):
+                       # from the committed line of the round, for whoever divides value(N) by value(1)
+                       "this_workload_on_one_gpu": n1_point(name) if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": kern,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -1012,6 +1015,19 @@ def main():
         if comm is not None:
             comm.close()
         dist.destroy_process_group()
+
+
+def n1_point(name):
+    "value of workload `name` on one GPU as the round's committed bench line has it (profiles/r04_bench_full.json)"
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_full.json")))
+        if name == "c4":
+            return {"Gbases_s": d["c4_n1"]["value_Gbases_s"], "source": "profiles/r04_bench_full.json c4_n1"}
+        if name == "c3":
+            return {"Gbases_s": d["value"], "source": "profiles/r04_bench_full.json value"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def pmc_traffic(name, pruned_run, algorithmic_bytes=None, line_bytes=None):
