@@ -159,3 +159,38 @@ def test_pipeline_with_the_experimental_repeat_filter(tmp_path):
     want = O.repeat_bf(genomes, 24, nb)
     raw = open(tmp_path / "hip" / "p.repeat.bf", "rb").read()
     assert raw[-nb:] == want.tobytes() and O.bf_popcount(want) > 10000
+
+
+def test_benchmark_writes_stage_times_and_peak_memory(tmp_path):
+    """`--benchmark` (bin/ntSynt:75; the reference wraps every rule in /usr/bin/time -v, smk:26-35, i.e. wall clock and peak RSS per
+    stage): <prefix>.stage_times.tsv with the stages' seconds, the library's HBM high-water mark of the run and the process's peak
+    RSS; the engine carries the same figures (bench.py's e2e leg reads them)."""
+    import os
+    from ntsynt_amd import pipeline, synth
+    from ntsynt_amd.device import Context
+    paths = synth.make_family(str(tmp_path), 2, 900_000, 2, 0.01, seed=8)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        eng = pipeline.run(paths, k=24, w=300, w_rounds=[100, 20], indel=500, merge=3000, block_size=300, prefix="b", benchmark=True, log=lambda *a: None)
+    finally:
+        os.chdir(cwd)
+    rows = dict(line.rstrip("\n").split("\t") for line in open(tmp_path / "b.stage_times.tsv"))
+    for stage in ("read_fasta+upload", "make_common_bf", "indexlr", "ntsynt_synteny", "wait_for_files"):
+        assert float(rows[stage]) >= 0.0
+    genome_bytes = sum(os.path.getsize(p) for p in paths)
+    assert int(rows["peak_hbm_bytes"]) > genome_bytes and int(rows["peak_host_rss_bytes"]) > 50 << 20
+    assert eng.memory["peak_hbm_bytes"] == int(rows["peak_hbm_bytes"]) and "bf_first_insert" in eng.memory["hbm_live_at_marks"]
+    # the counter itself: live bytes go up and down with allocations, the mark only up, a reset brings it down to what is live
+    ctx = Context(0)
+    before = ctx.mem_stats()
+    from ntsynt_amd.device import BloomFilter
+    bf = BloomFilter(ctx, 64 << 20, 24)
+    mid = ctx.mem_stats()
+    assert mid["live"] >= before["live"] + (64 << 20) and mid["peak"] >= mid["live"] and mid["device_total"] > mid["device_used"] > 0
+    bf.free()
+    after = ctx.mem_stats()
+    assert after["live"] <= mid["live"] - (64 << 20) and after["peak"] == mid["peak"]
+    ctx.mem_reset_peak()
+    assert ctx.mem_stats()["peak"] == ctx.mem_stats()["live"]
+    ctx.close()
