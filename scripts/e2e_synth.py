@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """FASTA files on disk -> final synteny TSV at full size with the family generated in HBM (what bench.py's e2e leg does),
-per stage and, with NTS_ENGINE_TIMES=1, per step of the graph stage; --engine host runs the host-array twin of the graph stage.
+per stage and, with NTS_ENGINE_TIMES=1, per step of the graph stage; --family assembly-like for the c5_like family.
 
   NTS_ENGINE_TIMES=1 python scripts/e2e_synth.py --mbp 3000 --genomes 3 --contigs 24 --divergence 0.01
 """
@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--fpr", type=float, default=0.025)
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--substitutions-only", action="store_true")
+    ap.add_argument("--family", choices=["structural", "assembly-like"], default="structural")
     args = ap.parse_args()
     import bench
     work = tempfile.mkdtemp(prefix="nts_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
