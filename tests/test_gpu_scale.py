@@ -122,9 +122,11 @@ def test_records_longer_than_2_to_32(ctx):
     common.free()
 
 
-@pytest.mark.parametrize("record,family,div", [("r04_e2e_oracle_c3.json", "structural", 0.01), ("r04_e2e_oracle_c5_like.json", "assembly-like", 0.013)])
-def test_whole_output_at_headline_size_equals_the_recorded_oracle_run(ctx, record, family, div):
-    """BASELINE configs[2] (and configs[4]'s parameters on the assembly-like family) at full size, the WHOLE output: the common
+@pytest.mark.parametrize("record,family,div,n_fam", [("r04_e2e_oracle_c3.json", "structural", 0.01, 3), ("r04_e2e_oracle_c5_like.json", "assembly-like", 0.013, 3),
+                                                     ("r04_e2e_oracle_2x3Gbp_d0.1.json", "structural", 0.001, 2)])
+def test_whole_output_at_headline_size_equals_the_recorded_oracle_run(ctx, record, family, div, n_fam):
+    """BASELINE configs[2] (and configs[4]'s parameters on the assembly-like family, and the reference's first published row: two 3 Gbp
+    genomes at 0.1 %, README.md:156) at full size, the WHOLE output: the common
     filter's popcount and an order-independent digest of every genome's complete minimizer list (3 x ~6 M minimizers) against what
     the CPU oracle pipeline left on record when it ran on these very families on a GPU box's host cores (scripts/e2e_oracle_check.py
     -> profiles/: 8 minutes of CPU, so it is a record, not a step of the suite).  The slices above compare a few Mbp with a live
@@ -141,8 +143,8 @@ def test_whole_output_at_headline_size_equals_the_recorded_oracle_run(ctx, recor
     assert rec["all_identical"]
     args = argparse.Namespace(family=family, substitutions_only=False, k=24, w=1000, fpr=0.025)
     total, contigs = 3_000_000_000, 24
-    assert rec["key"] == bench.e2e_key(args, 3, total, contigs, div), "the record is for another family / parameter set"
-    genomes = [bench.family_genome(ctx, args, total, contigs, j, div / 2.0) for j in range(3)]
+    assert rec["key"] == bench.e2e_key(args, n_fam, total, contigs, div), "the record is for another family / parameter set"
+    genomes = [bench.family_genome(ctx, args, total, contigs, j, div / 2.0) for j in range(n_fam)]
     _, nbytes = bf_size_bytes(genomes[0].total_bp, 0.025)           # (syn0.fa sorts first: it sizes the filter, cpp:105-118)
     assert nbytes == rec["oracle_filter_bytes"]
     common = BloomFilter(ctx, nbytes, 24)
