@@ -336,7 +336,7 @@ def write_fasta_from_device(g, path, chunk=1 << 28, soft_mask_seed=None, half_lo
                 fh.write(b"\n")
 
 
-ORACLE_RECORDS = [os.path.join(ROOT, "profiles", n) for n in ("r04_e2e_oracle_c3.json", "r04_e2e_oracle_c5_like.json", "r04_e2e_oracle_2x3Gbp_d0.1.json", "r03_e2e_oracle.json")]   # scripts/e2e_oracle_check.py
+ORACLE_RECORDS = [os.path.join(ROOT, "profiles", n) for n in ("r04_e2e_oracle_c3.json", "r04_e2e_oracle_c5_like.json", "r04_e2e_oracle_2x3Gbp_d0.1.json", "r04_e2e_oracle_c4.json", "r03_e2e_oracle.json")]   # scripts/e2e_oracle_check.py
 
 
 def oracle_record(key):
