@@ -515,6 +515,12 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     from concurrent.futures import ThreadPoolExecutor
     writers = ThreadPoolExecutor(max_workers=4)
     pending_files = []
+    file_of = {}                         # writer -> the file it leaves behind
+
+    def submit_file(name, fn, *a):
+        fut = writers.submit(fn, *a)
+        pending_files.append(fut)
+        file_of[fut] = name
     if common_file is not None:
         # stage 3 on its own: `--common <file>` (ntsynt_run.py:23; consumed by the refinement rounds' indexlr -s, S:175-177)
         if world > 1 or not isinstance(backend, GpuBackend):
@@ -628,9 +634,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 st.mark("bf_save_begin")
                 bf.save(f"{prefix}.common.bf", bf_header(bf.bytes, k, signature=bf_signature))
                 st.mark("bf_save_end")
-            pending_files.append(writers.submit(save_filter))
+            submit_file(f"{prefix}.common.bf", save_filter)
         else:
-            pending_files.append(writers.submit(lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k, signature=bf_signature)))
+            submit_file(f"{prefix}.common.bf", lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k, signature=bf_signature))
 
     if device_engine:
         from .synteny_device import DeviceSyntenyEngine
@@ -696,9 +702,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 recs = genomes[fastas[i]].recs
                 if recs.seq is None:                           # bases never left HBM: the k-mer text is gathered there
                     km = initial_dev[i].kmers(genomes[fastas[i]], k) if mx_with_seq else None
-                    pending_files.append(writers.submit(fa.write_indexlr_tsv_kmers, tsv_names[i], recs, out[0], out[1], out[2], k, km))
+                    submit_file(tsv_names[i], fa.write_indexlr_tsv_kmers, tsv_names[i], recs, out[0], out[1], out[2], k, km)
                 else:
-                    pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], recs, out[0], out[1], out[2], k, mx_with_seq))
+                    submit_file(tsv_names[i], write_indexlr_tsv, tsv_names[i], recs, out[0], out[1], out[2], k, mx_with_seq)
         st.stop()
         st.mark("sketches_done")
         st.start("ntsynt_synteny")
@@ -726,9 +732,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                             tmp_mx = Minimizers.from_numpy(backend.ctx, *out)
                             km = tmp_mx.kmers(genomes[p], k)
                             tmp_mx.free()
-                        pending_files.append(writers.submit(fa.write_indexlr_tsv_kmers, tsv_names[i], recs, out[0], out[1], out[2], k, km))
+                        submit_file(tsv_names[i], fa.write_indexlr_tsv_kmers, tsv_names[i], recs, out[0], out[1], out[2], k, km)
                     else:
-                        pending_files.append(writers.submit(write_indexlr_tsv, tsv_names[i], recs, out[0], out[1], out[2], k, mx_with_seq))
+                        submit_file(tsv_names[i], write_indexlr_tsv, tsv_names[i], recs, out[0], out[1], out[2], k, mx_with_seq)
         st.stop()
         st.start("ntsynt_synteny")
 
@@ -755,22 +761,18 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     try:
         eng.run(first)
     except BaseException:
-        # a run that dies after its first round must not leave a plausible-looking block table behind -- nor a filter file or
-        # minimizer TSVs cut short: the writers still stream from `bf` and the lists, so they are waited for before anything
-        # they read is freed (by the unwinding), and what they wrote goes
+        # a run that dies after its first round must not leave a plausible-looking block table behind.  The outputs of the stages
+        # before it stay, as under the reference's Snakemake (a failed rule loses its own outputs only: "no paths found", S:630-632,
+        # leaves <prefix>.common.bf and the minimizer TSVs of the rules that had finished) -- once their writers are through: those
+        # still stream from `bf` and the lists, so they are waited for before the unwinding frees what they read, and a file whose
+        # writer failed goes
+        doomed = [f"{out_prefix}.synteny_blocks.tsv", f"{out_prefix}.pre-collinear-merge.synteny_blocks.tsv"]
         for f in pending_files:
             try:
                 f.result()
             except Exception:                                   # noqa: BLE001 -- the run is failing already
-                pass
+                doomed.append(file_of[f])
         writers.shutdown()
-        doomed = [f"{out_prefix}.synteny_blocks.tsv", f"{out_prefix}.pre-collinear-merge.synteny_blocks.tsv"]
-        if rank == 0 and bf is not None:
-            doomed.append(f"{prefix}.common.bf")
-        if shard_mode:
-            doomed += [tsv_names[shard["genome"]]] if shard["leader"] and write_mx_tsv else []
-        else:
-            doomed += [tsv_names[i] for i, p in enumerate(fastas) if owner[p] == rank and write_mx_tsv]
         for name in doomed:
             if os.path.exists(name):
                 os.remove(name)

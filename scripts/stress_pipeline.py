@@ -37,6 +37,8 @@ def main(argv=None):
                   block_size=int(rng.choice([200, 500, 1000])))
         if isinstance(kw["merge"], str) and kw["merge"].isdigit():
             kw["merge"] = int(kw["merge"])
+        # the hidden switches of the reference's CLI and the Snakefile's experimental repeat filter, now and then
+        kw.update(common=bool(rng.random() >= 0.12), simplify=bool(rng.random() >= 0.2), repeat=bool(rng.random() < 0.1))
         tmp = tempfile.mkdtemp(prefix="nts_stress_")
         try:
             if rng.random() < 0.35:

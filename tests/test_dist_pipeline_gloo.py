@@ -173,3 +173,31 @@ def test_distributed_pipeline_matches_single_process(tmp_path, world, n_genomes)
     from ntsynt_amd.pipeline import read_bf
     bits, _ = read_bf(str(work / "d.common.bf"))
     assert np.array_equal(bits, ora.bf)
+
+
+def test_a_run_without_paths_keeps_the_finished_stages_outputs(tmp_path, monkeypatch, capsys):
+    """Stage 3's "no paths found" (bin/ntsynt_synteny.py:630-632, exit 1) under the reference's Snakemake fails rule ntsynt_synteny
+    only: <prefix>.common.bf (rule make_common_bf, smk:55-62), the minimizer TSVs (rule indexlr, smk:74-85) and the .fai files stay,
+    no block table appears.  Same here, and the TSVs are the oracle pipeline's."""
+    from ntsynt_amd import pipeline
+    from oracle import synteny_oracle as SO
+    paths = synth.make_family(str(tmp_path), 2, 300_000, 2, 0.35, seed=5)
+    names = [f"{os.path.basename(p)}.k24.w400.tsv" for p in paths]
+    texts = {}
+    for side in ("ora", "own"):
+        os.makedirs(tmp_path / side)
+        monkeypatch.chdir(tmp_path / side)
+        with pytest.raises(SystemExit) as e:
+            if side == "ora":
+                SO.run_pipeline(paths, prefix="d", **KW)
+            else:
+                pipeline.run(paths, prefix="d", backend=OracleBackend(), log=lambda *a: None, **KW)
+        assert e.value.code == 1
+        files = set(os.listdir("."))
+        assert not any(f.endswith("synteny_blocks.tsv") for f in files)
+        assert set(names) <= files
+        texts[side] = [open(n).read() for n in names]
+        if side == "own":
+            assert "d.common.bf" in files and all(f"{os.path.basename(p)}.fai" in files for p in paths)
+    assert texts["ora"] == texts["own"]
+    assert "no paths found" in capsys.readouterr().out

@@ -61,6 +61,36 @@ def test_pipeline_byte_identical(tmp_path, case):
     assert kk == k and np.array_equal(bits, ora.bf)
 
 
+def test_no_paths_found_leaves_filter_and_minimizer_files_like_snakemake(tmp_path):
+    """A family too distant for a chain of four common minimizers: both sides stop with the reference's "no paths found" (exit 1,
+    bin/ntsynt_synteny.py:630-632).  Under Snakemake that fails rule ntsynt_synteny alone -- the filter file and the minimizer TSVs
+    of the rules that had finished stay (complete: byte-identical to the oracle's), no block table is left behind."""
+    from ntsynt_amd import pipeline
+    paths = synth.make_family(str(tmp_path), 2, 400_000, 2, 0.35, seed=5)
+    kw = dict(k=24, w=400, w_rounds=[100, 10], indel=500, merge=3000, block_size=300)
+    names = [f"{os.path.basename(p)}.k24.w400.tsv" for p in paths]
+    cwd = os.getcwd()
+    texts = {}
+    try:
+        for side in ("ora", "hip"):
+            os.makedirs(tmp_path / side)
+            os.chdir(tmp_path / side)
+            with pytest.raises(SystemExit) as e:
+                if side == "ora":
+                    SO.run_pipeline(paths, prefix="p", **kw)
+                else:
+                    pipeline.run(paths, prefix="p", log=lambda *a: None, **kw)
+            assert e.value.code == 1
+            files = set(os.listdir("."))
+            assert not any(f.endswith("synteny_blocks.tsv") for f in files)
+            texts[side] = [open(n).read() for n in names]
+        assert texts["ora"] == texts["hip"]
+        bits, k_file = pipeline.read_bf("p.common.bf")
+        assert k_file == 24 and np.array_equal(bits, O.common_bf({p: O.read_fasta(p) for p in paths}, 24, 0.025, 1))
+    finally:
+        os.chdir(cwd)
+
+
 def test_graph_build_device_vs_numpy(tmp_path):
     from ntsynt_amd.device import Context
     from ntsynt_amd.graph import build_graph_device
