@@ -117,14 +117,19 @@ def main(argv=None):
     for fasta in fastas:
         if not os.path.isfile(fasta):
             raise FileNotFoundError(f"Input file {fasta} not found.")
-    if len(args.w_rounds) != len(set(args.w_rounds)):          # bin/ntsynt_synteny.py:597-599
-        print("Error: duplicate values found in w_rounds!", file=sys.stderr, flush=True)
-        sys.exit(1)
     plan = ["faidx x%d" % len(fastas)] + ([] if args.no_common else ["make_common_bf"]) + \
            ["indexlr x%d" % len(fastas), "ntsynt_synteny"]
     if args.dry_run:
         say("Stages (GPU, in process):", " -> ".join(plan))
         return 0
+    import subprocess
+
+    def stage_failed(cause=None):
+        "bin/ntSynt:166-170: a stage that stops (its message is on the terminal already) ends the run with this error, exit status 1"
+        raise subprocess.SubprocessError("ntSynt failed - check the logs for the error.") from cause
+    if len(args.w_rounds) != len(set(args.w_rounds)):          # stage 3's own check (bin/ntsynt_synteny.py:597-599): not under -n
+        print("Error: duplicate values found in w_rounds!", file=sys.stderr, flush=True)
+        stage_failed()
     from . import pipeline
     # one process per GPU under `python -m torch.distributed.run --nproc-per-node N bin/ntSynt ...`:
     # genomes are sharded over the ranks (ntsynt_amd/pipeline.py), rank 0 writes the outputs
@@ -147,17 +152,29 @@ def main(argv=None):
         else:
             dist.init_process_group(backend)
     quiet = (lambda *a, **k: None)
-    pipeline.run(fastas, k=args.k, w=args.w, fpr=args.fpr, prefix=args.prefix, w_rounds=args.w_rounds,
-                 indel=args.indel, merge=args.merge, block_size=args.block_size, common=not args.no_common,
-                 simplify=not args.no_simplify_graph, device=device, benchmark=args.benchmark,
-                 dev=args.dev, interarrivals=args.interarrivals, repeat=args.repeat, bf_rounding=args.bf_rounding, bf_signature=args.bf_signature or pipeline.BF_SIGNATURE,
-                 log=print if (args.dev and int(os.environ.get("RANK", "0")) == 0) else quiet)
+    try:
+        _run(pipeline, fastas, args, device, quiet)
+    except SystemExit as exc:                                  # a stage's own exit ("no paths found", S:630-632)
+        if exc.code in (0, None):
+            raise
+        stage_failed()
+    except Exception as exc:                                   # noqa: BLE001 -- whatever stopped a stage: its traceback is the log
+        stage_failed(exc)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
     if int(os.environ.get("RANK", "0")) == 0:
         print("Done ntSynt!")
     return 0
+
+
+def _run(pipeline, fastas, args, device, quiet):
+    pipeline.run(fastas, k=args.k, w=args.w, fpr=args.fpr, prefix=args.prefix, w_rounds=args.w_rounds,
+                 indel=args.indel, merge=args.merge, block_size=args.block_size, common=not args.no_common,
+                 simplify=not args.no_simplify_graph, device=device, benchmark=args.benchmark,
+                 dev=args.dev, interarrivals=args.interarrivals, repeat=args.repeat, bf_rounding=args.bf_rounding, bf_signature=args.bf_signature or pipeline.BF_SIGNATURE,
+                 log=print if (args.dev and int(os.environ.get("RANK", "0")) == 0) else quiet)
 
 
 if __name__ == "__main__":

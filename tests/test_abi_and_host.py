@@ -162,6 +162,40 @@ def test_cli_missing_file_and_dry_run(tmp_path, capsys):
     assert "make_common_bf" in capsys.readouterr().out
 
 
+def test_cli_ends_a_stopped_stage_like_the_reference(tmp_path, monkeypatch, capsys):
+    """bin/ntSynt:166-170: a stage that stops -- stage 3's "no paths found" exit (bin/ntsynt_synteny.py:630-632), its duplicate
+    --w_rounds check (:597-599), anything raised inside a stage -- ends the run with SubprocessError("ntSynt failed - check the logs
+    for the error."), the stage's own message already on the terminal.  Under -n no stage runs, so the duplicate check does not."""
+    import subprocess
+    import sys
+    from ntsynt_amd import cli, pipeline
+    a, b = tmp_path / "a.fa", tmp_path / "b.fa"
+    a.write_text(">x\nACGT\n")
+    b.write_text(">x\nACGT\n")
+    argv = [str(a), str(b), "-d", "1"]
+
+    def no_paths(*args, **kw):
+        print("Error - no paths found. Try adjusting the specified k/w parameters.")
+        sys.exit(1)
+
+    def dies(*args, **kw):
+        raise RuntimeError("a stage died")
+    monkeypatch.setattr(pipeline, "run", no_paths)
+    with pytest.raises(subprocess.SubprocessError, match="ntSynt failed - check the logs for the error.") as e:
+        cli.main(argv)
+    assert e.value.__cause__ is None and "no paths found" in capsys.readouterr().out
+    monkeypatch.setattr(pipeline, "run", dies)
+    with pytest.raises(subprocess.SubprocessError) as e:
+        cli.main(argv)
+    assert isinstance(e.value.__cause__, RuntimeError)
+    monkeypatch.setattr(pipeline, "run", lambda *args, **kw: None)
+    with pytest.raises(subprocess.SubprocessError):
+        cli.main(argv + ["--w_rounds", "100", "100"])
+    assert "duplicate values found in w_rounds" in capsys.readouterr().err
+    assert cli.main(argv + ["--w_rounds", "100", "100", "-n"]) == 0
+    assert cli.main(argv) == 0 and "Done ntSynt!" in capsys.readouterr().out
+
+
 def test_synthetic_family_is_deterministic(tmp_path):
     from ntsynt_amd import synth
     a = synth.derive_genome(synth.make_ancestor(50_000, 2, seed=3), 0.01, 1, seed=3, micro=3)
