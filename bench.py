@@ -802,9 +802,14 @@ def main():
         c4 = BloomFilter(ctx, nbytes, k)
         t1 = time.time()
         c4.insert(fam[0])
+        c4_levels = []
         for g in fam[1:]:
+            tl = time.time()
             c4.insert_and(g)
             c4.get_fpr()                         # (the pipeline prints the occupancy after every level; the library then knows when the filter is sparse)
+            # which way the level went: the build with the AND in its last pass, or -- the running filter all but empty -- the literal
+            # look-up of every k-mer (nts_bf_level_stats)
+            c4_levels.append({"ms": round((time.time() - tl) * 1e3, 2), "literal": bool(ctx.bf_level_stats()["sparse_level"])})
         ctx.sync()
         t_c4_build = time.time() - t1
         for g in fam:
@@ -822,7 +827,8 @@ def main():
         d4 = time.time() - t1
         c4_n1 = {"workload": "8 synthetic 3000 Mbp genomes at 10% divergence on one GPU (bench.py --workload c4 --gpus 1)",
                  "value_Gbases_s": round(sum(g.total_bp for g in fam) * 2 / d4 / 1e9, 3), "ms_per_step": round(d4 / 2 * 1e3, 2),
-                 "common_filter_occupancy": c4.get_fpr(), "minimizers_per_step": n4, "common_filter_build_s": round(t_c4_build, 4)}
+                 "common_filter_occupancy": c4.get_fpr(), "minimizers_per_step": n4, "common_filter_build_s": round(t_c4_build, 4),
+                 "common_filter_levels": c4_levels}
         c4.free()
         for g in fam:
             g.free()

@@ -131,6 +131,7 @@ SYMBOLS = [
     ("nts_sketch_select", ctypes.c_int, [c_vp, ctypes.c_int]),
     ("nts_sketch_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u64p, c_u32p]),
     ("nts_path_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u32p]),
+    ("nts_bf_level_stats", ctypes.c_int, [c_vp, c_u32p, c_u64p]),
     ("nts_mx_count", u64, [c_vp]),
     ("nts_mx_free", None, [c_vp, c_vp]),
     ("nts_mx_download", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),

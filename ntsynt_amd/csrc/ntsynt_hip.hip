@@ -162,6 +162,8 @@ struct nts_ctx
   uint64_t last_bf_direct = 0;   // indices of the last partitioned Bloom build that bypassed the buckets (full bucket, lanes in pieces)
   uint32_t last_comm_sparse = 0; // the last all-reduce of a filter gathered set-bit indices instead of chunks
   uint32_t last_bf_fallback = 0; // 1: its late list ran full (store-only build fell back to read-and-OR / fused AND build was redone unfused)
+  uint32_t last_bf_sparse_level = 0;     // the last nts_bf_insert_and went the literal way over a sparse running filter (bf_level_sparse)
+  uint64_t last_bf_sparse_accepted = 0;  // and accepted this many k-mers
   // dense sketch over a sparse filter: summary consulted before the filter, key tiles without an accepted k-mer skipped
   const uint32_t* cur_summary = nullptr;
   const uint32_t* cur_fold = nullptr; // folded copy of the filter for the LDS first look (k_hash_accept4), or null
@@ -1781,7 +1783,12 @@ int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const Genom
 
 #include "nts_pruned.inc"
 #include "nts_bloom_bin.inc"
+#include "nts_bf_sparse.inc"
 #include "nts_microbench.inc"
+
+// acc &= the filter of genome g the literal way, for a running filter that holds few bits (defined behind the sketch's host code,
+// whose accept kernels and summary it uses): 0 = done, 1 = does not apply or did not fit (acc is untouched), < 0 = error
+int bf_level_sparse(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, const GenomeTables& T, uint32_t k, int64_t pop_before);
 
 } // namespace
 
@@ -2465,8 +2472,6 @@ int nts_bf_insert_and(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, uint32_t k
 {
   if (!ctx || !acc || !g || k == 0) return fail(ctx, NTS_EINVAL, "nts_bf_insert_and: bad arguments");
   const int64_t pop_before = acc->owned ? acc->popcnt : -1;
-  acc->popcnt = -1;
-  ++acc->version;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   GenomeTables scratch;
   const GenomeTables* T = nullptr;
@@ -2474,6 +2479,16 @@ int nts_bf_insert_and(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, uint32_t k
   if (rc) return rc;
   uint32_t* late_ctl = (uint32_t*)(ctx->mail + MAIL_WORDS - 8);
   for (int i = 0; i < 8; ++i) late_ctl[i] = 0;
+  // a running filter that is all but empty: the literal level through the sparse-filter lookups (bf_level_sparse) instead of a build
+  rc = bf_level_sparse(ctx, acc, g, *T, k, pop_before);
+  if (rc < 0) return rc;
+  if (rc == 0) {
+    ctx->last_bf_direct = 0;
+    ctx->last_bf_fallback = 0;
+    return NTS_OK;
+  }
+  acc->popcnt = -1;
+  ++acc->version;
   // (a running filter known to hold fewer than one bit per 2^12: most 64 KiB slices are empty, k_bin3 looks before it reads residues)
   const bool sparse = pop_before >= 0 && (uint64_t)pop_before < ((acc->bytes * 8) >> 12);
   const bool fused_ok = ctx->bf_build_mode != 1 && !(getenv("NTS_BIN_FUSED_AND") && atoi(getenv("NTS_BIN_FUSED_AND")) == 0);
@@ -3175,6 +3190,182 @@ int scan_counts(nts_ctx* ctx, const T* d_in, uint64_t n, uint64_t* d_out)
   return NTS_OK;
 }
 
+// Summary of a sparse filter (one bit per 2^shift filter bits) and its two folded tables, kept with the filter until its contents
+// change (k_bf_summary: one streaming pass).  The caller holds filter->mu.
+int bf_make_summary(nts_ctx* ctx, const nts_bf* filter, uint32_t shift)
+{
+  if (filter->summary_version == filter->version && filter->summary_shift == shift) return NTS_OK;
+  const uint64_t n_gran = ((uint64_t)filter->bytes * 8 + (1ull << shift) - 1) >> shift;
+  const uint64_t words = (n_gran + 31) / 32 + 4;
+  if (filter->summary_words < words) {
+    if (filter->d_summary) dev_free(filter->d_summary);
+    filter->d_summary = nullptr;
+    filter->summary_words = 0;
+    HIP_TRY(ctx, dev_malloc((void**)&filter->d_summary, words * 4));
+    filter->summary_words = words;
+  }
+  HIP_TRY(ctx, hipMemsetAsync(filter->d_summary, 0, filter->summary_words * 4, ctx->stream));
+  if (!filter->d_fold) HIP_TRY(ctx, dev_malloc((void**)&filter->d_fold, 2 * FOLD_WORDS * 4)); // (two tables: k_bf_summary)
+  HIP_TRY(ctx, hipMemsetAsync(filter->d_fold, 0, 2 * FOLD_WORDS * 4, ctx->stream));
+  const uint64_t n16 = (filter->bytes + 15) / 16;
+  {
+    ScopedTimer t(ctx, "bf_summary");
+    hipLaunchKernelGGL(k_bf_summary, dim3((uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 16)), dim3(256), 0, ctx->stream,
+                       (const uint4*)filter->d_words, n16, shift, filter->d_summary, filter->d_fold, FOLD_WORDS);
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (another context may read the summary from its own stream as soon as the lock is free)
+  filter->summary_shift = shift;
+  filter->summary_version = filter->version;
+  return NTS_OK;
+}
+
+// The kernel that looks every k-mer of g up in a sparse filter through its summary (and, where they pay, the two folded tables in
+// LDS) and lists the accepted ones per 8192-k-mer tile: tile t's list sits in segment t % N_SEG at tile_off[t], tile_cnt[t] entries
+// (j, h0) in index order.  Used by the sketch (run_pruned, accept_all) and by the cascade level over a sparse running filter
+// (bf_level_sparse).
+int launch_accept(nts_ctx* ctx, const nts_genome* g, uint32_t k, const AcceptParams& A, const uint32_t* fold, uint64_t n_kt)
+{
+  if (fold && k <= 32 && !(getenv("NTS_ACCEPT_REG") && atoi(getenv("NTS_ACCEPT_REG")) == 0)) {
+    // bases from the 2-bit image in registers (k_hash_accept4r); NTS_ACCEPT_REG=0: the LDS-staged kernel (tests)
+    if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
+    if (!ctx->acc4r_lds_set) {
+#define ACC4R_ATTR(B, F) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4r<B, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Accept4rLds)))
+      ACC4R_ATTR(8, 0);
+      ACC4R_ATTR(8, 1);
+      ACC4R_ATTR(8, 2);
+      ACC4R_ATTR(4, -1);
+#undef ACC4R_ATTR
+      ctx->acc4r_lds_set = true;
+    }
+    // (persistent workgroups, one per CU -- 128 KiB of LDS each --, each loops over groups of four tiles; NTS_ACC4R_WGS overrides)
+    const uint64_t groups4 = (n_kt + 3) / 4;
+    const uint64_t wgs = getenv("NTS_ACC4R_WGS") ? (uint64_t)std::max(1, atoi(getenv("NTS_ACC4R_WGS"))) : 256ull;
+    const dim3 grid4((uint32_t)std::min<uint64_t>(groups4, wgs));
+#define ACC4R_RUN(B, F) hipLaunchKernelGGL((k_hash_accept4r<B, F>), grid4, dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A, g->d_pack, fold, n_kt)
+    if (getenv("NTS_ACC4R_BLOCK") && atoi(getenv("NTS_ACC4R_BLOCK")) == 4)
+      ACC4R_RUN(4, -1); // (blocks of four, the modulus form read at run time: the kernel as it was, for comparisons)
+    else if (A.fm.form == 2)
+      ACC4R_RUN(8, 2);
+    else if (A.fm.form == 1)
+      ACC4R_RUN(8, 1);
+    else
+      ACC4R_RUN(8, 0);
+#undef ACC4R_RUN
+  } else if (fold) {
+    if (!ctx->acc4_lds_set) {
+      HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(Accept4Lds)));
+      ctx->acc4_lds_set = true;
+    }
+    hipLaunchKernelGGL(k_hash_accept4, dim3((uint32_t)((n_kt + 3) / 4)), dim3(ACC4_THREADS), sizeof(Accept4Lds), ctx->stream, A, fold,
+                       n_kt);
+  } else {
+    hipLaunchKernelGGL(k_hash_accept, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, A);
+  }
+  return NTS_OK;
+}
+
+// One cascade level over a sparse running filter (nts_bf_sparse.inc): every k-mer of g is looked up in acc (the sketch's accept
+// kernels), acc's set bits are cleared granule by granule, the accepted k-mers' bits are set again -- together with the summary and
+// the folded tables of the new contents.  acc is touched only once the lists are known to have fitted.
+int bf_level_sparse(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, const GenomeTables& T, uint32_t k, int64_t pop_before)
+{
+  ctx->last_bf_sparse_level = 0;
+  ctx->last_bf_sparse_accepted = 0;
+  // (a build mode forced by the caller -- tests -- means the build: only the automatic choice comes here)
+  if (pop_before < 0 || !acc->owned || ctx->summary_mode != 0 || ctx->bf_build_mode != 0) return 1;
+  if (getenv("NTS_BF_SPARSE_LEVEL") && atoi(getenv("NTS_BF_SPARSE_LEVEL")) == 0) return 1;
+  const uint64_t V = T.rt.n_valid;
+  if (V == 0 || pop_before == 0) return 1; // (nothing to look up / nothing to keep: the build's own finish handles both)
+  const double bits = (double)acc->bytes * 8.0;
+  uint32_t shift = 7;
+  const uint32_t sum_log2 = getenv("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(getenv("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
+  while ((bits / (double)(1ull << shift)) > (double)(1ull << sum_log2) && shift < 30) ++shift; // (the sketch's choice: nts_sketch_ex)
+  // the sketch's own criterion for "sparse" (a summary bit set with probability < 0.3), and a level must beat a whole build:
+  // NTS_BF_SPARSE_MAX_OCC overrides the occupancy below which the level goes this way (tests)
+  // -- and it must beat a whole build (22 ms per 3 Gbp): with the folded tables in LDS a genome takes 8 ms; through the summary alone
+  // 15 ms plus a read of the filter for every k-mer whose summary bit is set, which pays up to a few per cent of set summary bits.
+  // NTS_BF_SPARSE_MAX_OCC overrides both limits with an occupancy (tests: every accept kernel at any occupancy).
+  const double occ = (double)pop_before / bits;
+  const bool fold_fits = bits >= (double)(1u << FOLD_BITS_LOG2) && (double)pop_before < 1.2 * (double)(1u << FOLD_BITS_LOG2);
+  if (getenv("NTS_BF_SPARSE_MAX_OCC")) {
+    if (occ >= atof(getenv("NTS_BF_SPARSE_MAX_OCC"))) return 1;
+  } else if (occ >= 0.3 / (double)(1ull << shift) || !(fold_fits || occ * (double)(1ull << shift) < 0.06)) {
+    return 1;
+  }
+  const uint64_t n_kt = (V + KEY_TILE - 1) / KEY_TILE;
+  if (n_kt > 0x7FFFFFFFULL) return 1;
+  std::lock_guard<std::mutex> summary_lock(acc->mu);
+  if (int rc = bf_make_summary(ctx, acc, shift)) return rc;
+  const uint32_t* fold = (ctx->fold_mode == 0 && fold_fits) ? acc->d_fold : nullptr;
+  // room for the accepted k-mers: a related genome hits a good share of the set bits, once per copy of the k-mer
+  const double own = bits * (1.0 - std::exp(-(double)V / bits));
+  const double p = own > 0 ? std::min(1.0, (double)pop_before / own) : 1.0;
+  const uint64_t seg_cap = (uint64_t)((double)V * std::min(1.0, 1.5 * p + 1e-4) * 1.25 / N_SEG) + 8192;
+#define SL_WS(ptr, type, name, bytes)                                                               \
+  type ptr = (type)ws_get(ctx, name, bytes);                                                        \
+  if (!ptr) return NTS_ENOMEM
+  SL_WS(d_toff, uint64_t*, "spl_tile_off", n_kt * 8);
+  SL_WS(d_tcnt, uint32_t*, "spl_tile_cnt", n_kt * 4 + 8);
+  SL_WS(d_tord, uint8_t*, "spl_tile_ord", n_kt);
+  SL_WS(d_ctl, unsigned long long*, "spl_ctl", (N_SEG + 2) * 8); // [0..63] segment counters, [64] bits turned on
+  SL_WS(d_sj, uint64_t*, "spl_seg_j", seg_cap * N_SEG * 8);
+  SL_WS(d_sk, uint64_t*, "spl_seg_key", seg_cap * N_SEG * 8);
+#undef SL_WS
+  HIP_TRY(ctx, hipMemsetAsync(d_ctl, 0, (N_SEG + 2) * 8, ctx->stream));
+  AcceptParams A;
+  A.code = g->d_code + PAD;
+  A.run_pos = T.d_run_pos;
+  A.run_vstart = T.d_run_vstart;
+  A.n_runs = T.n_runs;
+  A.n_valid = V;
+  if (int rc_hp = hash_params_for(ctx, k, &A.hp)) return rc_hp;
+  A.bf = acc->d_words;
+  A.fm = make_fastmod(acc->bytes * 8);
+  A.summary = acc->d_summary;
+  A.shift = shift;
+  A.probe_mask = ~0u;
+  A.seg_j = d_sj;
+  A.seg_key = d_sk;
+  A.seg_cap = seg_cap;
+  A.seg_count = d_ctl;
+  A.tile_off = d_toff;
+  A.tile_cnt = d_tcnt;
+  A.tile_ordered = d_tord;
+  ScopedTimer t(ctx, "bf_sparse_level", true);
+  if (int rc_a = launch_accept(ctx, g, k, A, fold, n_kt)) return rc_a;
+  HIP_TRY(ctx, hipGetLastError());
+  unsigned long long counts[N_SEG];
+  HIP_TRY(ctx, hipMemcpyAsync(counts, d_ctl, N_SEG * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t accepted = 0;
+  for (uint32_t sgm = 0; sgm < N_SEG; ++sgm) {
+    if (counts[sgm] > seg_cap) return 1; // a list did not fit: acc is as it was, the level goes the build's way
+    accepted += counts[sgm];
+  }
+  const uint64_t n16 = (acc->bytes + 15) / 16;
+  const uint64_t n_gran = ((uint64_t)acc->bytes * 8 + (1ull << shift) - 1) >> shift;
+  const uint64_t n_sw = (n_gran + 31) / 32;
+  acc->popcnt = -1; // from here on the filter changes
+  ++acc->version;
+  hipLaunchKernelGGL(k_bf_sparse_clear, dim3((uint32_t)std::min<uint64_t>((n_sw + 3) / 4, 256 * 16)), dim3(256), 0, ctx->stream, (uint4*)acc->d_words, n16,
+                     acc->d_summary, n_sw, shift);
+  HIP_TRY(ctx, hipMemsetAsync(acc->d_summary, 0, acc->summary_words * 4, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(acc->d_fold, 0, 2 * FOLD_WORDS * 4, ctx->stream));
+  hipLaunchKernelGGL(k_bf_sparse_set, dim3((uint32_t)((n_kt * 32 + 255) / 256)), dim3(256), 0, ctx->stream, acc->d_words, A.fm, d_sk, seg_cap, d_toff, d_tcnt,
+                     n_kt, acc->d_summary, shift, acc->d_fold, d_ctl + N_SEG);
+  HIP_TRY(ctx, hipGetLastError());
+  unsigned long long n_set = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&n_set, d_ctl + N_SEG, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  acc->popcnt = (int64_t)n_set;
+  acc->summary_shift = shift; // summary and folded tables describe the new contents
+  acc->summary_version = acc->version;
+  ctx->last_bf_sparse_level = 1;
+  ctx->last_bf_sparse_accepted = accepted;
+  return 0;
+}
+
 // Pruned path; see nts_pruned.inc.  `res` gets every minimizer, ordered (sparse winners come out ordered by
 // construction; winners of uncovered ranges, if any, are sorted and merged in).
 // accept_all: the filter is sparse and its summary (ctx->cur_summary) is in place -- every k-mer is looked up, the accepted
@@ -3294,43 +3485,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       A.tile_cnt = d_tcnt;
       A.tile_ordered = d_tord;
       ScopedTimer t(ctx, "hash_accept", true);
-      if (ctx->cur_fold && k <= 32 && !(getenv("NTS_ACCEPT_REG") && atoi(getenv("NTS_ACCEPT_REG")) == 0)) {
-        // bases from the 2-bit image in registers (k_hash_accept4r); NTS_ACCEPT_REG=0: the LDS-staged kernel (tests)
-        if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
-        if (!ctx->acc4r_lds_set) {
-#define ACC4R_ATTR(B, F) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4r<B, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Accept4rLds)))
-          ACC4R_ATTR(8, 0);
-          ACC4R_ATTR(8, 1);
-          ACC4R_ATTR(8, 2);
-          ACC4R_ATTR(4, -1);
-#undef ACC4R_ATTR
-          ctx->acc4r_lds_set = true;
-        }
-        // (persistent workgroups, one per CU -- 128 KiB of LDS each --, each loops over groups of four tiles; NTS_ACC4R_WGS overrides)
-        const uint64_t groups4 = (n_kt + 3) / 4;
-        const uint64_t wgs = getenv("NTS_ACC4R_WGS") ? (uint64_t)std::max(1, atoi(getenv("NTS_ACC4R_WGS"))) : 256ull;
-        const dim3 grid4((uint32_t)std::min<uint64_t>(groups4, wgs));
-#define ACC4R_RUN(B, F) hipLaunchKernelGGL((k_hash_accept4r<B, F>), grid4, dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A, g->d_pack, ctx->cur_fold, n_kt)
-        if (getenv("NTS_ACC4R_BLOCK") && atoi(getenv("NTS_ACC4R_BLOCK")) == 4)
-          ACC4R_RUN(4, -1); // (blocks of four, the modulus form read at run time: the kernel as it was, for comparisons)
-        else if (A.fm.form == 2)
-          ACC4R_RUN(8, 2);
-        else if (A.fm.form == 1)
-          ACC4R_RUN(8, 1);
-        else
-          ACC4R_RUN(8, 0);
-#undef ACC4R_RUN
-      } else if (ctx->cur_fold) {
-        if (!ctx->acc4_lds_set) {
-          HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_accept4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(Accept4Lds)));
-          ctx->acc4_lds_set = true;
-        }
-        hipLaunchKernelGGL(k_hash_accept4, dim3((uint32_t)((n_kt + 3) / 4)), dim3(ACC4_THREADS), sizeof(Accept4Lds), ctx->stream, A, ctx->cur_fold,
-                           n_kt);
-      } else {
-        hipLaunchKernelGGL(k_hash_accept, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, A);
-      }
+      if (int rc_a = launch_accept(ctx, g, k, A, ctx->cur_fold, n_kt)) return rc_a;
     } else {
       ScopedTimer t(ctx, filter ? "hash_select" : "hash_select_nofilter", true);
       // a lane rolls 64 k-mers and keeps 64*c/w candidates on average: 8 private slots while that is small, 16 beyond
@@ -3574,6 +3729,14 @@ extern "C" int nts_path_stats(nts_ctx* ctx, uint64_t* sketch_many_listed, uint64
   return NTS_OK;
 }
 
+extern "C" int nts_bf_level_stats(nts_ctx* ctx, uint32_t* sparse_level, uint64_t* accepted_kmers)
+{
+  if (!ctx) return NTS_EINVAL;
+  if (sparse_level) *sparse_level = ctx->last_bf_sparse_level;
+  if (accepted_kmers) *accepted_kmers = ctx->last_bf_sparse_accepted;
+  return NTS_OK;
+}
+
 extern "C" int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers, uint32_t* prune_c_used)
 {
   if (!ctx) return NTS_EINVAL;
@@ -3704,27 +3867,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     const uint32_t sum_log2 = getenv("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(getenv("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
     while ((bits / (double)(1ull << shift)) > (double)(1ull << sum_log2) && shift < 30) ++shift; // summary <= 2^sum_log2 bits
     if ((double)pc / bits * (double)(1ull << shift) < 0.3) {
-      if (filter->summary_version != filter->version || filter->summary_shift != shift) {
-        const uint64_t n_gran = ((uint64_t)filter->bytes * 8 + (1ull << shift) - 1) >> shift;
-        const uint64_t words = (n_gran + 31) / 32 + 4;
-        if (filter->summary_words < words) {
-          if (filter->d_summary) dev_free(filter->d_summary);
-          filter->d_summary = nullptr;
-          filter->summary_words = 0;
-          SK_HIP(dev_malloc((void**)&filter->d_summary, words * 4));
-          filter->summary_words = words;
-        }
-        SK_HIP(hipMemsetAsync(filter->d_summary, 0, filter->summary_words * 4, ctx->stream));
-        if (!filter->d_fold) SK_HIP(dev_malloc((void**)&filter->d_fold, 2 * FOLD_WORDS * 4)); // (two tables: k_bf_summary)
-        SK_HIP(hipMemsetAsync(filter->d_fold, 0, 2 * FOLD_WORDS * 4, ctx->stream));
-        const uint64_t n16 = (filter->bytes + 15) / 16;
-        ScopedTimer t(ctx, "bf_summary");
-        hipLaunchKernelGGL(k_bf_summary, dim3((uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 16)), dim3(256), 0, ctx->stream,
-                           (const uint4*)filter->d_words, n16, shift, filter->d_summary, filter->d_fold, FOLD_WORDS);
-        SK_HIP(hipStreamSynchronize(ctx->stream)); // (another context may read the summary from its own stream as soon as the lock is free)
-        filter->summary_shift = shift;
-        filter->summary_version = filter->version;
-      }
+      SK_TRY(bf_make_summary(ctx, filter, shift));
       const uint64_t key_tiles = (rt.n_valid + KEY_TILE - 1) / KEY_TILE;
       SK_WS(d_any, uint32_t*, "tile_any", (key_tiles + 4) * 4);
       ctx->cur_summary = filter->d_summary;

@@ -88,6 +88,13 @@ class Context:
         self.check(self.lib.nts_path_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "nts_path_stats")
         return {"sketch_many_listed": a.value, "bf_direct_indices": b.value, "bf_list_fallback": c.value}
 
+    def bf_level_stats(self):
+        """dict(sparse_level, accepted_kmers): whether the last BloomFilter.insert_and went the literal way over a running filter that
+        is all but empty (every k-mer looked up, the bits that were hit kept) and how many k-mers it accepted (nts_bf_level_stats)"""
+        a, b = ctypes.c_uint32(), u64()
+        self.check(self.lib.nts_bf_level_stats(self.h, ctypes.byref(a), ctypes.byref(b)), "nts_bf_level_stats")
+        return {"sparse_level": a.value, "accepted_kmers": b.value}
+
     VALU_KINDS = ["v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64", "v_lshlrev_b64", "v_mul_lo_u32", "v_mad_u64_u32",
                   "v_add_co_u32+v_addc_co_u32", "v_xor_b32 (dependent chain)", "v_add3_u32", "v_cmp_ge_u32+v_addc_co_u32",
                   "roll31 step (9 instructions)"]

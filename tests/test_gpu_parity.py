@@ -207,6 +207,86 @@ def test_bloom_fused_and_equals_insert_then_and_and_the_oracle_cascade(ctx, nbyt
         ctx.bf_build_mode("auto")
 
 
+def _diverged(rng, seqs, d):
+    out = []
+    for s_ in seqs:
+        a = np.frombuffer(s_, dtype=np.uint8).copy()
+        hit = (rng.random(a.size) < d) & (a != ord("N"))
+        a[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+        out.append(a.tobytes())
+    return out
+
+
+@pytest.mark.parametrize("variant", ["auto", "LDS-staged accept kernel", "summary only", "forced from level 1", "k=40", "repeats"])
+def test_bloom_sparse_level_equals_the_build_and_the_oracle_cascade(ctx, variant, monkeypatch):
+    """A cascade level over a running filter that is all but empty goes the reference's literal way (cpp:134-160: every k-mer of
+    the genome looked up, the bits that were hit kept -- bf_level_sparse) instead of through a whole partitioned build: same bits as
+    the build with the AND in its last pass, as the oracle's cascade, same popcount, through each of the three accept kernels, from
+    the first level on when forced, with k > 32, and with repeats whose copies overflow the accept lists (the level then falls
+    back to the build, the running filter untouched).  The summary and folded tables the level leaves behind are the ones the
+    sketch uses next: minimizers with the final filter == oracle."""
+    from ntsynt_amd.device import BloomFilter, sketch
+    k = 40 if variant == "k=40" else 24
+    w = 50
+    nbytes = 100 << 20
+    rng = np.random.default_rng(4242)
+    names, anc = _family(91, lengths=[400000, 0, 30, 250000, 12000, 90001, 23, 24], n_frac=0.0002)
+    rep = [b"ACGTTGCA" * 40000, b"A" * 300000] if variant == "repeats" else []
+    fam = []
+    for j in range(5):
+        sq = _diverged(rng, anc, 0.03) + rep
+        nm = [f"r{i}" for i in range(len(sq))]
+        fam.append((to_oracle(nm, sq), to_device(ctx, nm, sq)))
+    o = O.bf_build(fam[0][0], k, nbytes)
+    levels = [o]
+    for og, _ in fam[1:]:
+        o = O.bf_build(og, k, nbytes, prev=o)
+        levels.append(o)
+    pops = [int(np.unpackbits(x).sum()) for x in levels]
+    assert pops[0] > pops[1] > pops[2] > pops[3] > pops[4] > 0, pops
+    if variant == "LDS-staged accept kernel":
+        monkeypatch.setenv("NTS_ACCEPT_REG", "0")
+    if variant == "forced from level 1":
+        monkeypatch.setenv("NTS_BF_SPARSE_MAX_OCC", "1.0")
+    try:
+        if variant == "summary only":
+            ctx.sketch_summary("no-lds")
+        res = {}
+        for how in ("sparse", "build"):
+            if how == "build":
+                monkeypatch.setenv("NTS_BF_SPARSE_LEVEL", "0")
+            acc = BloomFilter(ctx, nbytes, k)
+            acc.insert(fam[0][1])
+            went = []
+            for lvl, (_, dg) in enumerate(fam[1:], start=1):
+                acc.insert_and(dg)
+                st = ctx.bf_level_stats()
+                went.append(st["sparse_level"])
+                assert acc.popcount() == pops[lvl], (variant, how, lvl, st)
+                assert np.array_equal(acc.to_numpy(), levels[lvl]), (variant, how, lvl, st)
+                if st["sparse_level"]:
+                    assert st["accepted_kmers"] >= pops[lvl], st          # every kept bit was hit by at least one k-mer
+            if how == "build":
+                assert went == [0, 0, 0, 0], went
+            elif variant == "forced from level 1":
+                assert went == [1, 1, 1, 1], went
+            elif variant == "repeats":
+                assert went[0] == 0, went                                   # (what the later levels did depends on how the lists fell)
+            else:
+                assert went[0] == 0 and went[-1] == 1 and sum(went) >= 2, (went, pops)   # the library chose it once the filter was sparse
+            # the tables the last level left with the filter serve the sketch
+            for og, dg in fam[:2]:
+                h1, rec, pos = sketch(ctx, dg, k, w, acc).to_numpy()
+                exp = O.minimize(og, k, w, levels[-1])
+                assert np.array_equal(h1, np.concatenate([e[0] for e in exp])) and np.array_equal(pos, np.concatenate([e[1] for e in exp])), (variant, how)
+            res[how] = went
+            acc.free()
+    finally:
+        ctx.sketch_summary("auto")
+        for _, dg in fam:
+            dg.free()
+
+
 @pytest.mark.parametrize("k,w", [(24, 1000), (24, 100), (20, 10), (24, 1), (32, 17), (24, 16), (24, 15),
                                  (24, 4097), (20, 250)])
 def test_sketch_no_filter(ctx, k, w):
