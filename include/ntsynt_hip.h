@@ -313,8 +313,8 @@ int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ran
 int nts_path_stats(nts_ctx* ctx, uint64_t* sketch_many_listed, uint64_t* bf_direct_indices, uint32_t* bf_list_fallback);
 /* Of the last nts_bf_insert_and: whether the level went the literal way of src/ntsynt_make_common_bf.cpp:134-160 -- every k-mer of
  * the genome looked up in the running filter, the bits that were hit kept -- which the library chooses by itself once the running
- * filter is all but empty (its popcount known and below ~6 * 10^5 bits, or below one set summary bit in 16: BASELINE configs[3]'s
- * last levels), and how many k-mers were accepted.  Otherwise the level is the partitioned build with the AND in its last pass.
+ * filter is all but empty (its popcount known and below ~6 * 10^5 bits, where two folded tables in LDS answer most look-ups: what is
+ * left of BASELINE configs[3]'s filter after its eighth genome), and how many k-mers were accepted.  Otherwise the level is the partitioned build with the AND in its last pass.
  * Same bits either way (tests/test_gpu_parity.py).  NTS_BF_SPARSE_LEVEL=0 in the environment keeps every level on the build. */
 int nts_bf_level_stats(nts_ctx* ctx, uint32_t* sparse_level, uint64_t* accepted_kmers);
 uint64_t nts_mx_count(const nts_mx* mx);

@@ -3281,16 +3281,17 @@ int bf_level_sparse(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, const Genome
   uint32_t shift = 7;
   const uint32_t sum_log2 = getenv("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(getenv("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
   while ((bits / (double)(1ull << shift)) > (double)(1ull << sum_log2) && shift < 30) ++shift; // (the sketch's choice: nts_sketch_ex)
-  // the sketch's own criterion for "sparse" (a summary bit set with probability < 0.3), and a level must beat a whole build:
-  // NTS_BF_SPARSE_MAX_OCC overrides the occupancy below which the level goes this way (tests)
-  // -- and it must beat a whole build (22 ms per 3 Gbp): with the folded tables in LDS a genome takes 8 ms; through the summary alone
-  // 15 ms plus a read of the filter for every k-mer whose summary bit is set, which pays up to a few per cent of set summary bits.
-  // NTS_BF_SPARSE_MAX_OCC overrides both limits with an occupancy (tests: every accept kernel at any occupancy).
+  // the sketch's own criterion for "sparse" (a summary bit set with probability < 0.3) -- and the level must beat the build, which with a sparse running filter (k_bin3 skips the residues of empty slices) takes 20-21 ms per
+  // 3 Gbp.  Measured level by level on BASELINE configs[3] (scripts/c4_levels.py, profiles/r04_c4_levels.json): through the summary
+  // alone the literal level takes 60 / 31 / 22 / 20.3 ms at 27.8 M / 9.0 M / 3.0 M / 1.05 M set bits (17.3 with the tables already in
+  // place) -- never ahead; only with the two folded tables in LDS in front of the summary (k_hash_accept4*: 8 ms per genome, up to
+  // ~6 * 10^5 set bits) does it win, so that is the automatic choice.  NTS_BF_SPARSE_MAX_OCC replaces both limits by an occupancy
+  // (tests and measurements: every accept kernel at any occupancy).
   const double occ = (double)pop_before / bits;
   const bool fold_fits = bits >= (double)(1u << FOLD_BITS_LOG2) && (double)pop_before < 1.2 * (double)(1u << FOLD_BITS_LOG2);
   if (getenv("NTS_BF_SPARSE_MAX_OCC")) {
     if (occ >= atof(getenv("NTS_BF_SPARSE_MAX_OCC"))) return 1;
-  } else if (occ >= 0.3 / (double)(1ull << shift) || !(fold_fits || occ * (double)(1ull << shift) < 0.06)) {
+  } else if (occ >= 0.3 / (double)(1ull << shift) || !fold_fits || ctx->fold_mode != 0) {
     return 1;
   }
   const uint64_t n_kt = (V + KEY_TILE - 1) / KEY_TILE;
