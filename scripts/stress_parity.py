@@ -23,7 +23,7 @@ def main(argv=None):
     ctx = Context(0)
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
-    n_cases = n_sketches = 0
+    n_cases = n_sketches = n_literal = n_levels = 0
     while time.time() < t_end:
         k = int(rng.choice([16, 20, 24, 31, 32, 40, 64, 100]))
         style = rng.choice(["few", "many", "tiny", "mixed"])
@@ -114,6 +114,62 @@ def main(argv=None):
                         sys.exit(1)
         ctx.sketch_mode("auto", 0)
         ctx.sketch_select("auto")
+        # (round 4) a cascade of several relatives: once the running filter is all but empty the level goes the literal way
+        # (bf_level_sparse) -- by the library's own choice, or forced at any occupancy, through each of the accept kernels; every
+        # level against the oracle's cascade, and a sketch with the tables the last level left behind
+        if rng.random() < 0.6:
+            forced = str(rng.choice(["", "", "1.0", "0.01"]))
+            acc_reg = str(rng.choice(["", "0"]))
+            ctx.sketch_summary(str(rng.choice(["auto", "auto", "no-lds"])))
+            big = int(rng.choice([nbytes, 8 << 20, 64 << 20]))     # (folded tables need >= 2^19 bits: 64 KiB)
+            want_l = O.bf_build(og, k, big)
+            chain = BloomFilter(ctx, big, k)
+            chain.insert(dg)
+            went = []
+            last = (og, dg)
+            for lvl in range(int(rng.integers(2, 5))):
+                d = float(rng.choice([0.01, 0.03, 0.06, 0.1]))
+                rl = []
+                for s in seqs:
+                    a = np.frombuffer(s, dtype=np.uint8).copy()
+                    hit = rng.random(a.size) < d
+                    a[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+                    rl.append(a.tobytes())
+                ol, dl = to_oracle(names, rl), to_device(ctx, names, rl)
+                want_l = O.bf_build(ol, k, big, prev=want_l)
+                for var, val in (("NTS_BF_SPARSE_MAX_OCC", forced), ("NTS_ACCEPT_REG", acc_reg)):
+                    if val:
+                        os.environ[var] = val
+                    else:
+                        os.environ.pop(var, None)
+                if rng.random() < 0.7:
+                    chain.popcount()
+                chain.insert_and(dl)
+                went.append(ctx.bf_level_stats()["sparse_level"])
+                for var in ("NTS_BF_SPARSE_MAX_OCC", "NTS_ACCEPT_REG"):
+                    os.environ.pop(var, None)
+                if not np.array_equal(chain.to_numpy(), want_l) or chain.popcount() != int(np.unpackbits(want_l).sum()):
+                    print("CASCADE LEVEL MISMATCH", dict(k=k, style=style, total=total, nbytes=big, lvl=lvl, went=went, forced=forced, acc_reg=acc_reg,
+                                                         seed=args.seed, case=n_cases))
+                    sys.exit(1)
+                if last[1] is not dg:
+                    last[1].free()
+                last = (ol, dl)
+            n_literal += sum(went)
+            n_levels += len(went)
+            w = int(rng.choice([10, 64, 150]))
+            ctx.sketch_mode("auto", 0)
+            e = oracle_flat(O.minimize(last[0], k, w, want_l))
+            mx = sketch(ctx, last[1], k, w, chain)
+            g = mx.to_numpy()
+            mx.free()
+            if not all(np.array_equal(y, x.astype(y.dtype)) for x, y in zip(e, g)):
+                print("SKETCH AFTER CASCADE MISMATCH", dict(k=k, w=w, style=style, total=total, nbytes=big, went=went, forced=forced, seed=args.seed, case=n_cases))
+                sys.exit(1)
+            if last[1] is not dg:
+                last[1].free()
+            chain.free()
+            ctx.sketch_summary("auto")
         # (round 4) record shards: the shards' filters OR to the genome's, their lists concatenate to the genome's
         if len(names) >= 2:
             from ntsynt_amd.device import Minimizers
@@ -145,7 +201,8 @@ def main(argv=None):
         dg.free()
         dg2.free()
         n_cases += 1
-    print(f"ok: {n_cases} genomes pairs, {n_sketches} sketches, {2 * n_cases} filter builds x 2 modes, seed {args.seed}")
+    print(f"ok: {n_cases} genomes pairs, {n_sketches} sketches, {2 * n_cases} filter builds x 2 modes, {n_levels} further cascade levels "
+          f"({n_literal} of them the literal way), seed {args.seed}")
 
 
 if __name__ == "__main__":
