@@ -87,7 +87,8 @@ def test_select_hi_pipeline_has_only_its_own_vector_memory_operations(code_objec
 def test_select_hi_m0_is_only_ever_used_next_to_its_own_write(code_object, has_bf, per):
     """The LDS-DMA loads take their LDS address from m0, which the kernel's inline asm writes itself (`s_mov_b32 m0, sN;
     s_nop 0; global_load_lds_*` in ONE asm statement each, csrc/nts_pruned.inc stage_dma / issue_probes).  m0 is a reserved
-    register: the compiler ignores the clobber (it warns about it) and uses m0 as a scratch scalar of its own -- today for the lane
+    register: a clobber of it is ignored by the compiler (hence none is written; with one the code object is the same byte for byte),
+    which uses m0 as a scratch scalar of its own -- today for the lane
     index of `v_writelane_b32 v, s, m0`, written by an `s_mov_b32 m0` right in front.  Both uses are safe only while every reader
     of m0 sits directly behind the write that serves it, with nothing of the other party in between.  This walks the ISA of the
     four instantiations and checks exactly that."""
