@@ -307,3 +307,35 @@ def test_shard_plan_and_mask_renumbering():
     got = shard_masks(iv, 2, 5)
     assert got["rec"].tolist() == [0, 1] and got["start"].tolist() == [6, 7] and iv["rec"].tolist() == [0, 2, 3, 5]
     assert shard_masks([(0, 1, 2), (4, 3, 9)], 3, 6) == [(1, 3, 9)] and shard_masks(None, 0, 1) is None
+
+
+def test_bf_file_layout_round_trip_and_rejections(tmp_path):
+    """The `{prefix}.common.bf` layout (header table, keys, [HeaderEnd], raw bits: src/ntsynt_make_common_bf.cpp:164 -> btllib's
+    save, as recalled -- DESIGN.md 2, u1/u2): what write_bf writes, read_bf reads back bit for bit; files that are not in that
+    layout, whose header disagrees with their size, or that hold more than one hash function (ntSynt's filter has one,
+    cpp:18-19) are refused with a message instead of being handed to nts_bf_upload."""
+    import pytest
+    from ntsynt_amd.pipeline import BF_SIGNATURE, bf_header, read_bf, write_bf
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 256, size=1000, dtype=np.uint8)
+    p = str(tmp_path / "a.bf")
+    write_bf(p, bits, 24)
+    got, k = read_bf(p)
+    assert k == 24 and np.array_equal(got, bits)
+    raw = open(p, "rb").read()
+    assert raw.startswith(BF_SIGNATURE.encode() + b"\n") and raw.endswith(bits.tobytes())
+    assert raw[:len(raw) - bits.size] == bf_header(bits.size, 24)
+    other = str(tmp_path / "b.bf")
+    write_bf(other, bits, 32, signature="[BTLKmerBloomFilter_v6]")          # (--bf-signature: the table name is the caller's)
+    got, k = read_bf(other)
+    assert k == 32 and np.array_equal(got, bits)
+    bad = str(tmp_path / "bad.bf")
+    open(bad, "wb").write(b">chr1\nACGT\n")
+    with pytest.raises(ValueError, match="HeaderEnd"):
+        read_bf(bad)
+    open(bad, "wb").write(bf_header(999, 24) + bits.tobytes())
+    with pytest.raises(ValueError, match="header says 999 bytes"):
+        read_bf(bad)
+    open(bad, "wb").write(bf_header(bits.size, 24, hash_num=3) + bits.tobytes())
+    with pytest.raises(ValueError, match="hash functions"):
+        read_bf(bad)
