@@ -154,3 +154,23 @@ def test_bloom_build_kernels_keep_their_occupancy_and_batched_loads(code_object)
     loads = [n for n, i in enumerate(i2) if i.startswith("global_load_dwordx4")]
     assert len(loads) == 4, loads
     assert not [i for i in i2[loads[0]:loads[-1]] if i.startswith("s_waitcnt") and "vmcnt" in i]
+
+
+def test_sparse_filter_kernels_fit_their_launch_shapes(code_object):
+    """The accept kernels of the sparse-filter sketch and of the literal cascade level (csrc/nts_pruned.inc, nts_bf_sparse.inc): a
+    workgroup of k_hash_accept4 / k_hash_accept4r is 1024 lanes -- four waves per SIMD, which is a launch failure above 128 vector
+    registers -- and keeps its accumulators in registers (they sat in scratch memory once: an array indexed by a run-time count,
+    DESIGN.md 4.2); none of them may spill vector registers."""
+    co, notes = code_object
+    acc4r = [f"_ZN12_GLOBAL__N_115k_hash_accept4rILi8ELi{form}EEEvNS_12AcceptParamsEPKjS3_m" for form in (0, 1, 2)]
+    others = ["_ZN12_GLOBAL__N_114k_hash_accept4ENS_12AcceptParamsEPKjm", "_ZN12_GLOBAL__N_113k_hash_acceptENS_12AcceptParamsE"]
+    for sym in acc4r + others:
+        assert sym in notes, f"{sym} not found (renamed? update this guard with it)"
+        m = _kernel_meta(notes, sym)
+        assert m["private_segment_fixed_size"] == "0" and m["vgpr_spill_count"] == "0", (sym, m)
+        assert int(m["vgpr_count"]) <= 128, (sym, m)
+    small = re.findall(r"\.name:\s+(\S*k_bf_sparse_\S*)\n", notes)                # the level's two small kernels: plain streaming shapes
+    assert len(small) == 2, small
+    for sym in small:
+        m = _kernel_meta(notes, sym)
+        assert m["private_segment_fixed_size"] == "0" and int(m["vgpr_count"]) <= 32, (sym, m)
