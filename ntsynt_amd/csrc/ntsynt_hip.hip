@@ -3281,8 +3281,8 @@ int bf_level_sparse(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, const Genome
   uint32_t shift = 7;
   const uint32_t sum_log2 = getenv("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(getenv("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
   while ((bits / (double)(1ull << shift)) > (double)(1ull << sum_log2) && shift < 30) ++shift; // (the sketch's choice: nts_sketch_ex)
-  // the sketch's own criterion for "sparse" (a summary bit set with probability < 0.3) -- and the level must beat the build, which with a sparse running filter (k_bin3 skips the residues of empty slices) takes 20-21 ms per
-  // 3 Gbp.  Measured level by level on BASELINE configs[3] (scripts/c4_levels.py, profiles/r04_c4_levels.json): through the summary
+  // the sketch's own criterion for "sparse" (a summary bit set with probability < 0.3) -- and the level must beat the build, which
+  // with a sparse running filter (k_bin3 skips the residues of empty slices) takes 20-21 ms per 3 Gbp.  Measured level by level on BASELINE configs[3] (scripts/c4_levels.py, profiles/r04_c4_levels.json): through the summary
   // alone the literal level takes 60 / 31 / 22 / 20.3 ms at 27.8 M / 9.0 M / 3.0 M / 1.05 M set bits (17.3 with the tables already in
   // place) -- never ahead; only with the two folded tables in LDS in front of the summary (k_hash_accept4*: 8 ms per genome, up to
   // ~6 * 10^5 set bits) does it win, so that is the automatic choice.  NTS_BF_SPARSE_MAX_OCC replaces both limits by an occupancy
