@@ -40,6 +40,14 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats5 -o
 find $O/stats5 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_c5_like.csv
 python profiles/summarize.py $O/kernel_stats_c5_like.csv "rocprofv3 --kernel-trace --stats -- python bench.py --family assembly-like --divergence 0.013 --steps 3 --warmup 1 (3 x 3 Gbp assembly-like genomes)" > $O/kernel_stats_c5_like.md
 rm -rf $O/stats5
+# config 4's cascade level by level (the build against the literal level over a sparse running filter) and the kernels of a run with a
+# ninth genome, whose level the library takes the literal way
+timeout 300 python scripts/c4_levels.py --force-from 4 > $O/c4_levels.json 2> $O/c4_levels.log
+timeout 300 python scripts/c4_levels.py --genomes 9 --force-from 8 --modes "build,auto,forced" > $O/c4_levels_9genomes.json 2>> $O/c4_levels.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lv -o s -- python scripts/c4_levels.py --genomes 9 --modes auto > $O/stats_lv.log 2>&1
+find $O/stats_lv -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_c4_levels.csv
+python profiles/summarize.py $O/kernel_stats_c4_levels.csv "rocprofv3 --kernel-trace --stats -- python scripts/c4_levels.py --genomes 9 --modes auto (8 cascade levels, the last the literal way)" > $O/kernel_stats_c4_levels.md
+rm -rf $O/stats_lv
 # end to end (FASTA files -> TSV)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_e2e -o s -- python scripts/e2e_synth.py > $O/e2e.json 2> $O/e2e.log
 find $O/stats_e2e -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_e2e.csv
