@@ -300,6 +300,15 @@ int nts_sketch_summary(nts_ctx* ctx, int mode, uint32_t* last_shift);
    than one run of valid bases per two tiles), 1 = always the full-width kernel, 2 = the upper-halves kernel wherever it
    applies, fragmented assemblies included.  Results are identical; tests and measurements switch it. */
 int nts_sketch_select(nts_ctx* ctx, int impl);
+/* Tiered selection (k_hash_tiers, ntsynt_amd/csrc/nts_tiers.inc): for filters that accept a few per cent of a genome's k-mers
+ * (three genomes at 10 % divergence, eight at 4 %, the reference's eleven-genome benchmark row, README.md:158) one threshold would list a
+ * quarter of the k-mers or more.  Thresholds tau_0 2^t, t = 0, 1, ..., are then probed one after the other, each only where
+ * some window still holds no accepted k-mer: ~3.4 / p probes per window instead of 11 / p (p = accepted share), identical
+ * output (the filter-in semantics of indexlr -s, bin/ntsynt_run_pipeline.smk:81-85).  mode 0 = automatic (default), 1 = never,
+ * 2 = wherever the kernel applies, -1 = leave as is; x0 = accepted k-mers per window the first tier aims at (0: default 2.4);
+ * half_steps: thresholds grow by 1.5 / 1.33 instead of 2.  Of the last nts_sketch call that went this way: k-mers probed,
+ * rounds run summed over the tiles, tiers planned (0: it did not go this way). */
+int nts_sketch_tiers(nts_ctx* ctx, int mode, double x0, int half_steps, uint64_t* last_probes, uint64_t* last_rounds, uint32_t* last_tiers);
 /* of the last nts_sketch call: accepted candidates, uncovered ranges handed to the dense kernels, the number of
  * k-mers in them, and the c that was used (all 0 for a dense-mode call) */
 int nts_sketch_stats(nts_ctx* ctx, uint64_t* candidates, uint64_t* uncovered_ranges, uint64_t* uncovered_kmers, uint32_t* prune_c_used);

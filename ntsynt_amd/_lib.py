@@ -129,6 +129,7 @@ SYMBOLS = [
     ("nts_sketch_mode", ctypes.c_int, [c_vp, ctypes.c_int, u32]),
     ("nts_sketch_summary", ctypes.c_int, [c_vp, ctypes.c_int, c_u32p]),
     ("nts_sketch_select", ctypes.c_int, [c_vp, ctypes.c_int]),
+    ("nts_sketch_tiers", ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ("nts_sketch_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u64p, c_u32p]),
     ("nts_path_stats", ctypes.c_int, [c_vp, c_u64p, c_u64p, c_u32p]),
     ("nts_bf_level_stats", ctypes.c_int, [c_vp, c_u32p, c_u64p]),

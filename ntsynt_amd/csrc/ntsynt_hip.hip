@@ -185,6 +185,11 @@ struct nts_ctx
   int select_impl = 0;  // candidate selection of the pruned sketch: 0 auto, 1 full-width kernel, 2 upper-halves kernel also for assemblies in pieces
   int summary_mode = 0; // 0 auto, 1 never (tests)
   uint32_t last_summary = 0;
+  // tiered selection (nts_tiers.inc): 0 auto, 1 never, 2 wherever it applies; figures of the last call that went that way
+  int tier_mode = 0;
+  double tier_x0 = 0;       // accepted k-mers per window the first tier aims at (0: the default)
+  uint32_t tier_half = 0;   // 1: tiers in steps of 1.5 / 1.33 instead of 2
+  uint64_t last_tier_probes = 0, last_tier_rounds = 0, last_tiers = 0;
 };
 
 struct nts_genome
@@ -1782,6 +1787,7 @@ int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const Genom
 }
 
 #include "nts_pruned.inc"
+#include "nts_tiers.inc"
 #include "nts_bloom_bin.inc"
 #include "nts_bf_sparse.inc"
 #include "nts_microbench.inc"
@@ -3371,8 +3377,19 @@ int bf_level_sparse(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, const Genome
 // construction; winners of uncovered ranges, if any, are sorted and merged in).
 // accept_all: the filter is sparse and its summary (ctx->cur_summary) is in place -- every k-mer is looked up, the accepted
 // ones are the candidates (k_hash_accept), windows without one have no minimizer: no uncovered ranges to evaluate
+// (tp: the tiered selection of nts_tiers.inc instead of one threshold -- its list holds every window's minimizer, like the
+//  accepted-list path's, so no range is left to the dense kernels)
+struct TierPlan
+{
+  float scale = 0;
+  uint32_t exp_shift = 23;
+  int32_t exp_bias = 126;
+  uint32_t n_tiers = 2, halo = 0, core = 0;
+  double c0 = 0;
+};
+
 int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter, uint32_t prune_c,
-               double p_accept, SortedOut& res, bool accept_all = false)
+               double p_accept, SortedOut& res, bool accept_all = false, const TierPlan* tp = nullptr)
 {
   const RunTable& rt = T.rt;
   const uint64_t V = rt.n_valid;
@@ -3385,10 +3402,10 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   // Margins measured at 3 Gbp, pairs at 2-8 % divergence: two per lane up to a mean of 107 (c = 22: select 1.79 ms against 2.00
   // with four per lane), four per lane up to 223 (c = 53: 4.32 ms against 4.79 for k_hash_select); NTS_HI_M2 / NTS_HI_M4 override)
   const double hi_m4 = getenv("NTS_HI_M4") ? atof(getenv("NTS_HI_M4")) : 1.15, hi_m2 = getenv("NTS_HI_M2") ? atof(getenv("NTS_HI_M2")) : 1.2;
-  const bool sel_hi = !accept_all && ctx->select_impl != 1 && k <= HI_K_MAX && 4096.0 * prune_c / w * hi_m4 <= 256.0 &&
+  const bool sel_hi = !accept_all && !tp && ctx->select_impl != 1 && k <= HI_K_MAX && 4096.0 * prune_c / w * hi_m4 <= 256.0 &&
                       (ctx->select_impl == 2 || 2ull * T.n_runs <= (V + HIW_TILE - 1) / HIW_TILE + 64);
   const uint32_t hi_per = 4096.0 * prune_c / w * hi_m2 <= 128.0 ? 2u : 4u; // listed k-mers per lane and round
-  const uint64_t sel_tile = accept_all ? (uint64_t)KEY_TILE : sel_hi ? (uint64_t)HIW_TILE : (uint64_t)SEL_TILE;
+  const uint64_t sel_tile = tp ? (uint64_t)tp->core : accept_all ? (uint64_t)KEY_TILE : sel_hi ? (uint64_t)HIW_TILE : (uint64_t)SEL_TILE;
   const uint64_t n_kt = (V + sel_tile - 1) / sel_tile; // tiles of the select kernel (16384 indices each; 8192 for k_hash_accept)
   if (n_kt > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
   // threshold: a fraction c/w of all hashes
@@ -3398,6 +3415,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   uint64_t tau = t128 >= full - 1 ? KEY_MAX - 1 : ((uint64_t)t128 | 0xFFFFFFFFULL);
   if (tau == KEY_MAX) tau = KEY_MAX - 1;
   const double frac = accept_all ? 1.0 : std::min(1.0, (double)prune_c / (double)w);
+  if (tp) accept_all = true; // (everything behind the selection is the accepted-list path's)
 #define PR_WS(ptr, type, name, bytes)                                                               \
   type ptr = (type)ws_get(ctx, name, bytes);                                                        \
   if (!ptr) return NTS_ENOMEM
@@ -3412,6 +3430,8 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   PR_WS(d_ghi, uint64_t*, "gap_hi", gap_cap * 8);
   // room for the ACCEPTED candidates (share p_accept of the candidates, 1 if unknown); too little is seen and retried
   uint64_t cseg_cap = (uint64_t)((double)V * frac * std::min(1.0, 1.5 * p_accept + (accept_all ? 1e-4 : 0.02)) * 1.25 / N_SEG) + 8192;
+  // tiers: the accepted k-mers found are ~p x (3.4/p probes per window) plus what conserved stretches add; a retry follows if it was too small
+  if (tp) cseg_cap = (uint64_t)((double)V * (6.0 / (double)w + 0.002) * 1.25 / N_SEG) + 8192;
   // the upper-halves kernel drops about 70 % of the accepted k-mers again (those that cannot win a window) -- where its tiles lie inside
   // one run; the window and gather kernels are launched over the capacity, so half of it is what they get until a call has
   // needed more (an assembly in pieces: the retry below, once per context)
@@ -3439,7 +3459,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     ctx->sel_ctl_clean = false;
     SelParams S;
     S.code = g->d_code + PAD;
-    if (!accept_all) {
+    if (!accept_all || tp) {
       if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
     }
     S.pack = g->d_pack;
@@ -3460,7 +3480,43 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     S.tile_ordered = d_tord;
     // k_hash_select_hi drops accepted k-mers that cannot be a window's minimum (NTS_SELECT_ELIM=0: keeps them all; same result)
     S.w_elim = (getenv("NTS_SELECT_ELIM") && atoi(getenv("NTS_SELECT_ELIM")) == 0) ? 0u : w;
-    if (accept_all) {
+    if (tp) {
+      PR_WS(d_dir, uint32_t*, "tier_dir", n_kt * 12);
+      PR_WS(d_tstats, unsigned long long*, "tier_stats", 16);
+      HIP_TRY(ctx, hipMemsetAsync(d_tstats, 0, 16, ctx->stream));
+      TierParams Q;
+      Q.code = S.code;
+      Q.pack = S.pack;
+      Q.run_pos = S.run_pos;
+      Q.run_vstart = S.run_vstart;
+      Q.n_runs = S.n_runs;
+      Q.n_valid = V;
+      Q.rec_vstart = T.d_rec_vstart;
+      Q.n_rec = g->n_rec;
+      Q.dir = d_dir;
+      Q.hp = S.hp;
+      Q.bf = S.bf;
+      Q.fm = S.fm;
+      Q.w = w;
+      Q.halo = tp->halo;
+      Q.core = tp->core;
+      Q.scale = tp->scale;
+      Q.exp_shift = tp->exp_shift;
+      Q.exp_bias = tp->exp_bias;
+      Q.n_tiers = tp->n_tiers;
+      Q.seg_j = d_sj;
+      Q.seg_key = d_sk;
+      Q.seg_cap = cseg_cap;
+      Q.seg_count = d_ctl;
+      Q.tile_off = d_toff;
+      Q.tile_cnt = d_tcnt;
+      Q.tile_ordered = d_tord;
+      Q.stats = d_tstats;
+      ScopedTimer t(ctx, "hash_tiers", true);
+      hipLaunchKernelGGL(k_tier_dir, dim3((uint32_t)((n_kt + 255) / 256)), dim3(256), 0, ctx->stream, T.d_run_vstart, T.n_runs, T.d_rec_vstart, g->n_rec, V,
+                         tp->halo, tp->core, n_kt, d_dir);
+      hipLaunchKernelGGL(k_hash_tiers, dim3((uint32_t)n_kt), dim3(TR_THREADS), 0, ctx->stream, Q);
+    } else if (accept_all) {
       AcceptParams A;
       A.code = S.code;
       A.run_pos = S.run_pos;
@@ -3558,7 +3614,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     // one synchronisation: candidate counters, uncovered-range count + a first batch of ranges, winner count
     uint64_t last_scan = 0, last_cnt = 0, listed = 0;
     {
-      static_assert(N_SEG + 5 + 2 * GAP_PEEK < MAIL_WORDS - 8, "mailbox too small (the last word is the arrival flag)");
+      static_assert(N_SEG + 7 + 2 * GAP_PEEK < MAIL_WORDS - 8, "mailbox too small (the last word is the arrival flag)");
       const uint32_t peek = (uint32_t)std::min<uint64_t>(GAP_PEEK, gap_cap);
       Mail mb(ctx);
       const uint32_t a_ctl = mb.add(d_ctl, N_SEG + 1);
@@ -3568,6 +3624,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       const uint32_t a_tcnt = mb.add((const uint64_t*)(d_tcnt + ((n_kt - 1) & ~1ull)), 1); // (32-bit counts: the pair holding the last one)
       const uint32_t a_lo = mb.add(d_glo, peek);
       const uint32_t a_hi = mb.add(d_ghi, peek);
+      const uint32_t a_tier = tp ? mb.add((const uint64_t*)ws_get(ctx, "tier_stats", 16), 2) : 0u;
       // the gather runs behind the mail kernel: the counters are on their way to the host while it works
       int rc_m = mb.launch(ctx);
       if (rc_m) return rc_m;
@@ -3583,6 +3640,10 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       listed = ctx->mail[a_tscan] + (uint32_t)(ctx->mail[a_tcnt] >> (32 * ((n_kt - 1) & 1ull)));
       memcpy(glo.data(), ctx->mail + a_lo, (size_t)peek * 8);
       memcpy(ghi.data(), ctx->mail + a_hi, (size_t)peek * 8);
+      if (tp) {
+        ctx->last_tier_probes = ctx->mail[a_tier];
+        ctx->last_tier_rounds = ctx->mail[a_tier + 1];
+      }
     }
     uint64_t worst = 0;
     m = 0;
@@ -3721,6 +3782,21 @@ extern "C" int nts_sketch_select(nts_ctx* ctx, int impl)
   return NTS_OK;
 }
 
+extern "C" int nts_sketch_tiers(nts_ctx* ctx, int mode, double x0, int half_steps, uint64_t* last_probes, uint64_t* last_rounds, uint32_t* last_tiers)
+{
+  if (!ctx || mode < -1 || mode > 2 || x0 < 0 || x0 > 64)
+    return fail(ctx, NTS_EINVAL, "nts_sketch_tiers: mode is -1 (query), 0 (auto), 1 (never) or 2 (wherever the kernel applies); 0 <= x0 <= 64");
+  if (mode >= 0) {
+    ctx->tier_mode = mode;
+    ctx->tier_x0 = x0;
+    ctx->tier_half = half_steps ? 1u : 0u;
+  }
+  if (last_probes) *last_probes = ctx->last_tier_probes;
+  if (last_rounds) *last_rounds = ctx->last_tier_rounds;
+  if (last_tiers) *last_tiers = (uint32_t)ctx->last_tiers;
+  return NTS_OK;
+}
+
 extern "C" int nts_path_stats(nts_ctx* ctx, uint64_t* sketch_many_listed, uint64_t* bf_direct_indices, uint32_t* bf_list_fallback)
 {
   if (!ctx) return NTS_EINVAL;
@@ -3813,7 +3889,11 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   if (filter_out) pruned = false;
   uint32_t prune_c = ctx->prune_c;
   double p = 1.0; // accepted share of the candidates (1 when unknown: sizes the candidate arrays)
-  if (pruned && prune_c == 0) {
+  bool tiered = false;
+  TierPlan plan;
+  // (tiers forced: also below w = 200, where one threshold is not the default)
+  const bool tiers_forced = ctx->tier_mode == 2 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0;
+  if ((pruned || tiers_forced) && prune_c == 0) {
     if (filter) {
       uint64_t pc = 0;
       SK_TRY(nts_bf_popcount(ctx, filter, &pc));
@@ -3849,9 +3929,36 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     // 3 x 100 Mbp: c = 35 -> 56 Gbases/s against 34 dense, c = 50 -> 17; at w = 1000, c = 203 still gives 94)
     const double cap = (w >= 512 ? 0.25 : 0.15) * (double)w;
     prune_c = (uint32_t)std::min(want, cap);
-    if (ctx->sketch_mode == 0 && want > cap) pruned = false;
+    if ((ctx->sketch_mode == 0 && want > cap) || w < 200) pruned = ctx->sketch_mode == 2;
+    // Tiered selection (nts_tiers.inc): thresholds tau_0 2^t instead of one threshold, each probed only where a window is still
+    // without an accepted k-mer -- ~3.4/p probes per window instead of 11/p.  It takes over where one threshold lists so many
+    // k-mers that the upper-halves kernel no longer applies, down to accepted shares where even the first tier is half of all k-mers.
+    if (filter && ctx->sketch_mode == 0 && ctx->tier_mode != 1 && k <= FAST_K_MAX && w >= 64 && w <= 4097) {
+      const double x0 = ctx->tier_x0 > 0 ? ctx->tier_x0 : 2.4;
+      const double c0 = x0 / std::max(p, 1e-6);
+      const double switch_c = 54.0 * (double)w / 1000.0; // (beyond it k_hash_select takes over from k_hash_select_hi)
+      if (c0 <= 0.5 * (double)w && (ctx->tier_mode == 2 || want > switch_c)) {
+        tiered = true;
+        pruned = false;
+        plan.c0 = c0;
+        const double t0 = std::max(1.0, std::floor(c0 / (double)w * 4294967296.0));
+        plan.scale = (float)(1.0 / (t0 + 1.0));
+        plan.exp_shift = ctx->tier_half ? 22u : 23u;
+        plan.exp_bias = ctx->tier_half ? 253 : 126;
+        // explicit tiers while their threshold stays below ~3/4 of all hashes; the last tier takes the rest
+        uint32_t n_exp = 1;
+        auto c_of = [&](uint32_t t) { return ctx->tier_half ? c0 * ((t & 1u) ? 1.5 : 1.0) * (double)(1u << (t >> 1)) : c0 * (double)(1u << t); };
+        while (n_exp < TR_TIERS_MAX - 1 && c_of(n_exp) <= 0.75 * (double)w) ++n_exp;
+        plan.n_tiers = n_exp + 1;
+        plan.halo = ((w - 1 + 63) / 64) * 64;
+        plan.core = TR_EXT - 2 * plan.halo;
+        prune_c = (uint32_t)std::max(1.0, std::ceil(c0));
+      }
+    }
   }
-  ctx->last_c = pruned ? prune_c : 0;
+  ctx->last_c = (pruned || tiered) ? prune_c : 0;
+  ctx->last_tiers = tiered ? plan.n_tiers : 0;
+  ctx->last_tier_probes = ctx->last_tier_rounds = 0;
   // Dense pass over a sparse filter: with occupancy o, a summary bit covering 2^shift filter bits is set with probability
   // ~ o * 2^shift; when that is small the summary answers nearly every probe from the L2 (k_hash_keys_sparse).
   ctx->cur_summary = nullptr;
@@ -3859,7 +3966,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   ctx->cur_tile_any = nullptr;
   ctx->last_summary = 0;
   bool accept_all = false;
-  if (!pruned && filter && filter->owned && ctx->summary_mode == 0 && !filter_out) {
+  if (!pruned && !(tiered && ctx->tier_mode == 2) && filter && filter->owned && ctx->summary_mode == 0 && !filter_out) {
     std::lock_guard<std::mutex> summary_lock(filter->mu);
     uint64_t pc = 0;
     SK_TRY(nts_bf_popcount(ctx, filter, &pc));
@@ -3879,6 +3986,10 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
       const double own = bits * (1.0 - std::exp(-(double)rt.n_valid / bits));
       p = own > 0 ? std::min(1.0, (double)pc / own) : 1.0;
       accept_all = ctx->sketch_mode != 1; // (mode "dense" keeps the key / window kernels, with the summary in front of the probes)
+      if (accept_all) {
+        tiered = false;
+        ctx->last_tiers = 0;
+      }
       // the folded copy pays while it rejects a good share of the k-mers: set bits / 2^19 below ~1.2 (about 70 % of its bits set)
       ctx->cur_fold = (ctx->fold_mode == 0 && bits >= (double)(1u << FOLD_BITS_LOG2) && (double)pc < 1.2 * (double)(1u << FOLD_BITS_LOG2))
                         ? filter->d_fold : nullptr;
@@ -3887,8 +3998,8 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
 
   for (int attempt = 0;; ++attempt) {
     SortedOut res;
-    if (pruned || accept_all)
-      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, prune_c, p, res, accept_all));
+    if (pruned || accept_all || tiered)
+      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, prune_c, p, res, accept_all, tiered ? &plan : nullptr));
     else
       SK_TRY(run_dense_sorted(ctx, g, *T, k, w, filter, nullptr, nullptr, nullptr, rt.n_valid, "", res));
     const uint64_t count = res.count; // exact, or an upper bound when the count still lives on the device
@@ -3914,7 +4025,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     }
     // the last kernel of the call also clears the pruned pass's control block for the next call (one fill launch less
     // at the head of every sketch)
-    uint64_t* const sel_ctl = (pruned || accept_all) ? (uint64_t*)ws_get(ctx, "sel_ctl", (N_SEG + 2) * 8) : nullptr;
+    uint64_t* const sel_ctl = (pruned || accept_all || tiered) ? (uint64_t*)ws_get(ctx, "sel_ctl", (N_SEG + 2) * 8) : nullptr;
     if (!res.d_ctl) {
       Mail done(ctx); // nothing to fetch: only the arrival flag
       if (sel_ctl) done.clear_after(sel_ctl, N_SEG + 2);

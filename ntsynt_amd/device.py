@@ -68,6 +68,16 @@ class Context:
         halves rolled, also for assemblies in many pieces); same result"""
         self.check(self.lib.nts_sketch_select(self.h, {"auto": 0, "full": 1, "hi": 2}[impl]), "nts_sketch_select")
 
+    def sketch_tiers(self, mode=None, x0=0.0, half_steps=False):
+        """Tiered selection for filters that accept a few per cent of the k-mers (nts_sketch_tiers): mode 'auto' / 'never' / 'always'
+        (wherever the kernel applies) / None (leave as is).  Returns (k-mers probed, rounds summed over the tiles, tiers planned) of
+        the last sketch call; tiers == 0: it did not go that way.  Same result whichever way."""
+        a, b, c = u64(), u64(), ctypes.c_uint32()
+        code = {None: -1, "auto": 0, "never": 1, "always": 2}[mode]
+        self.check(self.lib.nts_sketch_tiers(self.h, code, float(x0), int(bool(half_steps)), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
+                   "nts_sketch_tiers")
+        return a.value, b.value, c.value
+
     def bf_build_mode(self, mode="auto"):
         """How BloomFilter.insert sets the bits: 'auto' (partitioned streaming build for large genomes), 'atomic'
         (one atomic OR per k-mer) or 'binned' (partitioned whenever the filter layout allows); same filter."""

@@ -1,0 +1,135 @@
+"""Tiered selection (csrc/nts_tiers.inc, nts_sketch_tiers) == every k-mer probed == CPU oracle, bit-exact, through the C ABI.
+
+The regime: a common filter that accepts a few per cent of a genome's k-mers (BASELINE's scaling config before its last levels, the
+reference's eleven-genome row, README.md:158) -- filter-in semantics as `indexlr -s` (bin/ntsynt_run_pipeline.smk:81-85).  Ragged
+records (empty, shorter than k, shorter than w, exactly w k-mers), N runs, soft masks of a refinement round, records that start
+inside a tile, tiles whose halo reaches into the neighbours, conserved stretches (every k-mer accepted) next to stretches that share
+nothing.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from oracle import nts_oracle as O
+from tests.helpers import oracle_flat, random_records, to_device, to_oracle
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ntsynt_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _relative(rng, seqs, rate, conserved=(), novel=()):
+    "the same records with substitutions at `rate`; `conserved` / `novel`: (record, start, end) kept as they are / replaced"
+    out = []
+    for r, s in enumerate(seqs):
+        a = np.frombuffer(s, dtype=np.uint8).copy()
+        keep = a.copy()
+        hit = (rng.random(a.size) < rate) & (a != ord("N"))
+        a[hit] = ACGT[rng.integers(0, 4, size=int(hit.sum()))]
+        for rr, s0, s1 in conserved:
+            if rr == r:
+                a[s0:s1] = keep[s0:s1]
+        for rr, s0, s1 in novel:
+            if rr == r:
+                a[s0:s1] = ACGT[rng.integers(0, 4, size=len(a[s0:s1]))]
+        out.append(a.tobytes())
+    return out
+
+
+def _case(ctx, seed, lengths, k, fpr, rate, n_rel=2, **kw):
+    from ntsynt_amd.device import BloomFilter
+    rng = np.random.default_rng(seed)
+    seqs = random_records(rng, lengths, n_frac=0.002)
+    names = [f"r{i}" for i in range(len(seqs))]
+    fam = [seqs] + [_relative(rng, seqs, rate, **kw) for _ in range(n_rel)]
+    og = [to_oracle(names, s) for s in fam]
+    dg = [to_device(ctx, names, s) for s in fam]
+    nbytes = O.bf_ctor_bytes(O.bf_approx_bytes(og[0].total_bp, fpr))
+    obf = None
+    for o in og:
+        obf = O.bf_build(o, k, nbytes, prev=obf)
+    dbf = BloomFilter(ctx, nbytes, k)
+    dbf.from_numpy(obf)
+    return og, dg, obf, dbf
+
+
+def _check(ctx, og, dg, obf, dbf, k, w, masks=None, **tiers):
+    from ntsynt_amd.device import sketch
+    n_total = 0
+    for o, d in zip(og, dg):
+        ctx.sketch_tiers("always", **tiers)
+        got = sketch(ctx, d, k, w, dbf, masks).to_numpy()
+        probes, rounds, n_tiers = ctx.sketch_tiers()
+        assert n_tiers >= 2, "the call did not go through k_hash_tiers"
+        assert probes > 0 and rounds > 0
+        ctx.sketch_tiers("never")
+        ctx.sketch_mode("dense")
+        dense = sketch(ctx, d, k, w, dbf, masks).to_numpy()
+        ctx.sketch_mode("auto")
+        ctx.sketch_tiers("auto")
+        for a, b in zip(got, dense):
+            assert np.array_equal(a, b)
+        if masks is None:
+            exp = oracle_flat(O.minimize(o, k, w, obf))
+            for a, b in zip(got, exp):
+                assert np.array_equal(a, b.astype(a.dtype))
+        # fewer probes than k-mers, or the tiers are pointless (tiny inputs aside)
+        n_total += len(got[0])
+    assert n_total > 0
+
+
+LENGTHS = [150000, 0, 5, 23, 24, 25, 1023, 1046, 1047, 1500, 70001, 3, 12000, 40000, 16384 + 23, 900]
+
+
+@pytest.mark.parametrize("k,w,rate,fpr", [(24, 1000, 0.10, 0.025), (24, 1000, 0.06, 0.025), (24, 250, 0.08, 0.025), (40, 1000, 0.05, 0.025),
+                                          (24, 2000, 0.10, 0.025), (70, 500, 0.03, 0.025), (24, 64, 0.05, 0.3), (129, 300, 0.02, 0.025)])
+def test_tiers_equal_dense_and_oracle(ctx, k, w, rate, fpr):
+    if k > 128:
+        pytest.skip("k_hash_tiers rolls k <= 128 (FAST_K_MAX); longer k-mers stay on the dense path")
+    og, dg, obf, dbf = _case(ctx, 900 + k + w, LENGTHS, k, fpr, rate,
+                             conserved=[(0, 20000, 26000), (10, 0, 3000)], novel=[(0, 60000, 75000), (13, 1000, 9000)])
+    _check(ctx, og, dg, obf, dbf, k, w)
+
+
+@pytest.mark.parametrize("x0,half", [(0.2, False), (0.7, True), (2.4, True), (6.0, False), (8.0, False)])
+def test_tier_schedules_give_the_same_list(ctx, x0, half):
+    "many thin tiers, few fat ones, steps of 1.5: the schedule changes the probes, never the result"
+    k, w = 24, 1000
+    og, dg, obf, dbf = _case(ctx, 77, LENGTHS, k, 0.025, 0.09, conserved=[(0, 100000, 103000)], novel=[(10, 30000, 50000)])
+    _check(ctx, og, dg, obf, dbf, k, w, x0=x0, half_steps=half)
+
+
+def test_tiers_with_masks_of_a_refinement_round(ctx):
+    k, w = 24, 250
+    og, dg, obf, dbf = _case(ctx, 31, LENGTHS, k, 0.025, 0.07)
+    masks = [(0, 1000, 30000), (0, 90000, 90100), (10, 100, 50000), (13, 0, 40000), (14, 16000, 16384 + 23)]
+    _check(ctx, og, dg, obf, dbf, k, w, masks=masks)
+
+
+def test_tiers_on_many_short_records(ctx):
+    "thousands of records per tile: record starts are what closes a stretch, almost everywhere"
+    rng = np.random.default_rng(5)
+    lengths = [int(x) for x in rng.integers(0, 2500, size=400)] + [60000]
+    k, w = 24, 500
+    og, dg, obf, dbf = _case(ctx, 6, lengths, k, 0.025, 0.08)
+    _check(ctx, og, dg, obf, dbf, k, w)
+
+
+def test_tiers_probe_a_fraction_of_the_kmers(ctx):
+    "at an accepted share of a few per cent the rounds probe a small part of the k-mers, not all of them"
+    from ntsynt_amd.device import sketch
+    k, w = 24, 1000
+    og, dg, obf, dbf = _case(ctx, 41, [400000], k, 0.025, 0.10, n_rel=2)
+    ctx.sketch_tiers("always")
+    mx = sketch(ctx, dg[0], k, w, dbf)
+    probes, rounds, n_tiers = ctx.sketch_tiers()
+    ctx.sketch_tiers("auto")
+    n_kmers = dg[0].valid_kmers(k)
+    assert len(mx) > 0 and n_tiers >= 3
+    assert probes < 0.45 * n_kmers, (probes, n_kmers)
