@@ -12,17 +12,23 @@ set of structural events of its own (5 inversions of 1-5 Mbp, 2 inter-contig tra
 rearrangements, 200 indels of 1-50 bp: ntsynt_amd/synth.py structural_plan), so that the graph stage of the end-to-end leg has indel cuts, erosions and merges to make
 (--substitutions-only gives round 2's family).  `nruns` is the sketch on the variant with 0.5 % of the bases in N runs.
 
-Workloads (--workload; default c3 at N=1, c4 at N>1):
+`python bench.py --gpus N` on its own starts the N ranks itself (torch.distributed.run on 127.0.0.1); under a launcher WORLD_SIZE must equal
+--gpus or the run refuses.  ONE workload along the scaling curve: c3 is `value` at every N, c4 is the `c4` leg of the same line at every N.
+
+Workloads (--workload; default c3):
   c3   BASELINE configs[2], the configuration the metric is quoted on: 3 synthetic 3 Gbp genomes (24 contigs) at 1 %
-       divergence, k=24 w=1000 fpr=0.025.  Fits one GPU (9 GB of bases + 2 x 14.8 GB of filters).
+       divergence, k=24 w=1000 fpr=0.025.  Fits one GPU (9 GB of bases + 2 x 14.8 GB of filters).  At N > 1 the family's 72 records
+       are shared out over the ranks by bases, across genome boundaries (ntsynt_amd.pipeline.partition_plan: 8 x ~1.125 Gbp at N = 8);
+       a rank builds a filter per genome its range touches, exchange 1 is nts_bf_allreduce_parts (OR over a genome's parts, AND across
+       genomes), every step ends with the all-gather of the part lists (nts_mx_allgather_ex) strung together per genome.
   c4   BASELINE configs[3]: 8 synthetic 3 Gbp genomes at 10 % divergence, genome g on rank g mod N (one per GPU at
        N=8), common filter = AND over all eight (exchange 1: nts_bf_allreduce_and over RCCL), every step ends with the
        all-gather of the minimizer lists (exchange 2: nts_mx_allgather).  The family, the filter and therefore the work
        per genome are the same at every N: strong scaling.  At N=1 all eight genomes live on one GPU.
   c2   BASELINE configs[1]: 3 x 100 Mbp at 1 %, sketched as one batch genome (round 1's bench line).
-Extra legs at N=1 (rank 0), all inside the one JSON line: `cold` (first sketch of a fresh genome: 2-bit image, run
-table, first-k-mer tables included), `roofline.unpruned` (every k-mer probed), `c4_n1` (config 4's eight genomes on
-this one GPU: the N=1 point of the c4 curve), `e2e` (FASTA files on disk -> final synteny TSV through the product
+Extra legs at N=1 (rank 0), all inside the one JSON line: `cold` (first sketch of a fresh genome, three times, split into allocation
+and the rest), `roofline.unpruned` (every k-mer probed), `valley` (filters that accept a few per cent of the k-mers: 3 x 3 Gbp at
+10 %, 8 x 3 Gbp at 4 %), `e2e` (FASTA files on disk -> final synteny TSV through the product
 pipeline, per stage), `cpu_baseline` (the CPU oracle on the host cores, per stage, at the reference's default
 parallelism and on all cores).
 """
@@ -83,6 +89,7 @@ def parse():
                     help="assembly-like: ntsynt_amd.synth.realistic_plan + REPEATS (interspersed repeat families, satellite arrays, segmental "
                          "duplications, thousands of scaffolds with a tail of short ones, N gaps) -- the family of the c5_like leg, for every leg")
     ap.add_argument("--no-c5-leg", action="store_true")
+    ap.add_argument("--no-valley-leg", action="store_true")
     ap.add_argument("--e2e-dir", default=None, help="where the e2e leg writes its FASTA files [a temp dir]")
     return ap.parse_args()
 
@@ -519,18 +526,295 @@ def c5_like_leg(args, ctx, device, total_bp, contigs, workdir):
     return out, a5, div
 
 
+class Rig:
+    """One workload resident on this rank -- the family's genomes (whole, or this rank's ranges of records), the common filter built
+    through exchange 1 -- and step(): one sketch pass over what the rank holds followed by exchange 2.  Genomes deal out whole when their
+    number is a multiple of the ranks (c4: eight genomes on 1 / 2 / 4 / 8 GPUs); otherwise the family's records are shared out by bases
+    across genome boundaries (ntsynt_amd.pipeline.partition_plan: c3's three genomes on 8 GPUs are eight ranges of ~1.125 Gbp)."""
+
+    def __init__(self, name, args, ctx, comm, world, rank, use_overrides=True):
+        from ntsynt_amd import pipeline, synth
+        from ntsynt_amd.device import Genome
+        self.name, self.args, self.ctx, self.comm, self.world, self.rank = name, args, ctx, comm, world, rank
+        n_fam, mbp, contigs, div, self.scaling = WORKLOADS[name]
+        if use_overrides:
+            n_fam = args.genomes or n_fam
+            div = args.divergence if args.divergence is not None else div
+        mbp, contigs = args.mbp or mbp, args.contigs or contigs            # (a leg on another workload keeps its family, at the run's size)
+        self.n_fam, self.mbp, self.contigs, self.div = n_fam, mbp, contigs, div
+        self.total_bp = total_bp = int(mbp * 1e6)
+        self.fam_bases = family_bases(args, n_fam, total_bp, contigs)
+        self.plan = None
+        t0 = time.time()
+        if world > 1 and n_fam % world != 0:
+            if args.substitutions_only:
+                rec_lens = [np.full(contigs, total_bp // contigs, dtype=np.int64)] * n_fam
+            elif args.family == "assembly-like":
+                rec_lens = [synth.realistic_plan(contigs, total_bp // contigs, j, ANCESTOR_SEED)[0] for j in range(n_fam)]
+            else:
+                rec_lens = [synth.structural_plan(contigs, total_bp // contigs, j, ANCESTOR_SEED)[0] for j in range(n_fam)]
+            self.plan = pipeline.partition_plan(rec_lens, world)
+            self.n_rec = [len(x) for x in rec_lens]
+            self.filters_of, self.slot_group, self.n_groups = pipeline.partition_groups(self.plan, self.n_rec)
+            self.parts = self.plan[rank]
+            self.genomes = []
+            for g, a, b in self.parts:
+                whole = family_genome(ctx, args, total_bp, contigs, g, div / 2.0)
+                if a == 0 and b == self.n_rec[g]:
+                    self.genomes.append(whole)
+                else:
+                    self.genomes.append(whole.slice(a, b))
+                    whole.free()
+            self.part_base = sum(len(ps) for ps in self.plan[:rank])
+            self.n_parts = sum(len(ps) for ps in self.plan)
+            self.list_slots = max(1, max(len(ps) for ps in self.plan))
+            self.mine = [self.part_base + i for i in range(len(self.parts))]        # (exchange 2 numbers the parts in family order)
+            all_bases = [sum(int(rec_lens[g][a:b].sum()) for g, a, b in ps) for ps in self.plan]
+            self.balance = {"bases_per_rank": all_bases, "max_over_mean": round(max(all_bases) / (sum(all_bases) / world), 4)}
+        else:
+            self.mine = [g for g in range(n_fam) if g % world == rank]
+            self.genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in self.mine]
+            per_rank = [sum(self.fam_bases[g] for g in range(n_fam) if g % world == r) for r in range(world)]
+            self.balance = {"bases_per_rank": per_rank, "max_over_mean": round(max(per_rank) / (sum(per_rank) / world), 4)}
+        self.t_synth = time.time() - t0
+        self.bases = sum(g.total_bp for g in self.genomes)
+        batch = name == "c2" and not args.no_batch and len(self.genomes) > 1 and world == 1
+        self.units = [Genome.concat(ctx, self.genomes)] if batch else self.genomes
+        self.common = None
+        self.n_all = None
+
+    def build_filter(self, again=False, levels=False):
+        "per-genome filters, local cascade, exchange 1; returns the timings"
+        self.levels = []
+        from ntsynt_amd.device import BloomFilter, bf_size_bytes
+        ctx, comm, world, k = self.ctx, self.comm, self.world, self.args.k
+        _, self.nbytes = bf_size_bytes(self.fam_bases[0], self.args.fpr)       # sized by the first file of the family, on every rank (A1)
+        t0 = time.time()
+        common = BloomFilter(ctx, self.nbytes, k, world=world if comm is not None else 1)
+        extra = []
+        occ_single = None
+        if self.plan is not None:
+            # one filter for the genomes this rank holds whole (their cascade is local), one per genome it holds a part of
+            for fi, (_, idxs) in enumerate(self.filters_of[self.rank]):
+                f_ = common if fi == 0 else BloomFilter(ctx, self.nbytes, k, world=world)
+                if fi:
+                    extra.append(f_)
+                f_.insert(self.genomes[idxs[0]])
+                for i_ in idxs[1:]:
+                    f_.insert_and(self.genomes[i_])
+        else:
+            common.insert(self.genomes[0])
+            occ_single = common.get_fpr()
+            for g in self.genomes[1:]:
+                tl = time.time()
+                common.insert_and(g)                 # one cascade level inside the build's last pass (nts_bf_insert_and), as pipeline.run does
+                if levels:
+                    common.get_fpr()                 # (the pipeline prints the occupancy after every level; the library then knows when the filter is sparse)
+                    # which way the level went: the build with the AND in its last pass, or -- the running filter all but empty -- the
+                    # literal look-up of every k-mer (nts_bf_level_stats)
+                    self.levels.append({"ms": round((time.time() - tl) * 1e3, 2), "literal": bool(ctx.bf_level_stats()["sparse_level"])})
+        ctx.sync()
+        t_build = time.time() - t0
+        t_warm = None
+        if world == 1 and again:
+            # the same filter once more, into the same allocation, with the build's workspaces (two bucket arrays and the bypass list:
+            # ~25 GB of hipMalloc at 3 Gbp) in place: what a level costs once a run is under way
+            t1 = time.time()
+            common.clear()
+            common.insert(self.genomes[0])
+            for g in self.genomes[1:]:
+                common.insert_and(g)
+            ctx.sync()
+            t_warm = time.time() - t1
+        t_allreduce = 0.0
+        if world > 1:
+            t1 = time.time()
+            if self.plan is not None:
+                comm.allreduce_parts([common] + extra, self.slot_group, max(1, max(len(x) for x in self.slot_group)), self.n_groups)
+            else:
+                comm.allreduce_and(common)
+            ctx.sync()
+            t_allreduce = time.time() - t1
+        for f_ in extra:
+            f_.free()
+        self.common = common
+        return {"build_s": t_build, "build_again_s": t_warm, "allreduce_s": t_allreduce, "occ_single": occ_single}
+
+    def step(self, pool=None):
+        from ntsynt_amd.device import Minimizers, sketch
+        ctx, comm, world, k, w = self.ctx, self.comm, self.world, self.args.k, self.args.w
+        held, n = [], 0
+        if pool is not None:
+            held = pool.sketch(self.units, k, w, self.common)
+            n = sum(len(mx) for mx in held)
+        else:
+            for g in self.units:
+                mx = sketch(ctx, g, k, w, self.common)
+                n += len(mx)
+                held.append(mx)
+        if world > 1:                                               # exchange 2: every rank receives every list
+            if self.plan is not None:
+                parts = comm.allgather_minimizers(held, self.mine, self.n_parts, self.list_slots)
+                by_genome, at = {}, 0
+                for ps in self.plan:
+                    for g_, a, b in ps:
+                        by_genome.setdefault(g_, []).append((parts[at], a))
+                        at += 1
+                n_all = 0
+                for g_ in range(self.n_fam):                        # the genome's list: its parts in record order
+                    whole_list = Minimizers.concat(ctx, [m for m, _ in by_genome[g_]], [a for _, a in by_genome[g_]])
+                    n_all += len(whole_list)
+                    whole_list.free()
+                self.n_all = n_all
+                for mx in parts:
+                    mx.free()
+            else:
+                everything = comm.allgather_minimizers(held, self.mine, self.n_fam)
+                self.n_all = sum(len(mx) for mx in everything)
+                for mx in everything:
+                    mx.free()
+        for mx in held:
+            mx.free()
+        return n
+
+    def free(self):
+        for g in self.genomes:
+            g.free()
+        if len(self.units) == 1 and self.units[0] not in self.genomes:
+            self.units[0].free()
+        self.genomes, self.units = [], []
+        if self.common is not None:
+            self.common.free()
+            self.common = None
+
+
+def valley_leg(args, ctx, total_bp, contigs, n_fam, div, reps=2):
+    """Filters that accept a few per cent of a genome's k-mers -- between the pruned path's regime (one threshold, ~11 / p probes per
+    window) and the sparse-filter one: three genomes at ~10 %, eight at ~4 %, the reference's eleven-genome row (README.md:158).  The
+    tiered selection (k_hash_tiers, csrc/nts_tiers.inc) against every k-mer probed, which is what these inputs got until round 4."""
+    from ntsynt_amd.device import BloomFilter, bf_size_bytes, sketch
+    k, w = args.k, args.w
+    g0 = family_genome(ctx, args, total_bp, contigs, 0, div / 2.0)
+    _, nbytes = bf_size_bytes(g0.total_bp, args.fpr)
+    bf = BloomFilter(ctx, nbytes, k)
+    bf.insert(g0)
+    g0.free()
+    for j in range(1, n_fam):
+        g = family_genome(ctx, args, total_bp, contigs, j, div / 2.0)
+        bf.insert_and(g)
+        g.free()
+    occ = bf.get_fpr()
+    t_all, bases, n_mx, probes, kmers, path = 0.0, 0, 0, 0, 0, None
+    dense = None
+    for j in range(n_fam):
+        g = family_genome(ctx, args, total_bp, contigs, j, div / 2.0)
+        sketch(ctx, g, k, w, bf).free()
+        ctx.sync()
+        t1 = time.time()
+        for _ in range(reps):
+            mx = sketch(ctx, g, k, w, bf)
+            n = len(mx)
+            mx.free()
+        ctx.sync()
+        t_all += (time.time() - t1) / reps
+        bases += g.total_bp
+        n_mx += n
+        pr, rounds, tiers = ctx.sketch_tiers()
+        probes += pr
+        kmers += g.valid_kmers(k)
+        path = "k_hash_tiers (%d tiers)" % tiers if tiers else ("one threshold, c = %d" % ctx.last_prune_c if ctx.sketch_stats() and ctx.last_prune_c else "every k-mer probed")
+        if j == 0:                                                  # the same genome with every k-mer probed: what it replaces
+            ctx.sketch_tiers("never")
+            ctx.sketch_mode("dense")
+            sketch(ctx, g, k, w, bf).free()
+            ctx.sync()
+            t1 = time.time()
+            mx = sketch(ctx, g, k, w, bf)
+            n_d = len(mx)
+            mx.free()
+            ctx.sync()
+            dense = {"Gbases_s": round(g.total_bp / (time.time() - t1) / 1e9, 2), "same_list_length": n_d == n}
+            ctx.sketch_mode(args.mode, args.prune_c)
+            ctx.sketch_tiers("auto")
+        g.free()
+    bf.free()
+    return {"workload": f"{n_fam} synthetic {total_bp / 1e6:g} Mbp genomes at {div * 100:g}% divergence, k={k} w={w}", "common_filter_occupancy": occ,
+            "value_Gbases_s": round(bases / t_all / 1e9, 2), "ms_per_genome": round(t_all / n_fam * 1e3, 2), "path": path,
+            "probes_per_kmer": round(probes / max(kmers, 1), 4) if probes else None, "minimizers_per_step": n_mx,
+            "every_kmer_probed_genome0": dense}
+
+
+def cold_leg(args, ctx, rig):
+    """The first sketch of a genome nothing has been derived from yet (rule indexlr runs once per genome, bin/ntsynt_run_pipeline.smk:74-85:
+    in a pipeline run cold is the real case) -- three times, on three fresh genomes, each split into what the call spends in
+    hipMalloc / hipFree (nts_alloc_stats around the call), what the library's workspaces grew by, and the rest (derived structures --
+    2-bit image, run table, first-k-mer tables -- plus the sketch itself); then one more fresh genome with every kernel group between
+    events.  The first of the three meets a context whose sketch workspaces do not exist yet (the Bloom build's do)."""
+    from ntsynt_amd.device import sketch
+    k, w = args.k, args.w
+    runs = []
+    n_cold = 0
+    for j in range(3):
+        fresh = family_genome(ctx, args, rig.total_bp, rig.contigs, rig.mine[0] if rig.plan is None else 0, rig.div / 2.0)
+        ctx.sync()
+        c0, a0 = ctx.alloc_stats()
+        live0 = ctx.mem_stats()["live"]
+        t1 = time.time()
+        mx = sketch(ctx, fresh, k, w, rig.common)
+        n_cold = len(mx)
+        dt = time.time() - t1
+        c1, a1 = ctx.alloc_stats()
+        live1 = ctx.mem_stats()["live"]
+        runs.append({"ms": round(dt * 1e3, 2), "hipMalloc_hipFree_calls": c1 - c0, "ms_in_hipMalloc_hipFree": round(a1 - a0, 2),
+                     "workspace_growth_MB": round((live1 - live0) / 1048576.0, 1)})
+        mx.free()
+        fresh.free()
+    fresh = family_genome(ctx, args, rig.total_bp, rig.contigs, rig.mine[0] if rig.plan is None else 0, rig.div / 2.0)
+    ctx.sync()
+    ctx.profile(1)
+    sketch(ctx, fresh, k, w, rig.common).free()
+    ctx.sync()
+    groups = {n: ctx.timing(n) for n in SKETCH_KERNELS + ["pack_image"]}
+    ctx.profile(True)
+    fresh.free()
+    t1 = time.time()
+    sketch(ctx, rig.genomes[-1], k, w, rig.common).free()           # after its Bloom insert (2-bit image exists): the
+    t_first = time.time() - t1                                      # pipeline's situation
+    ms = [r["ms"] for r in runs]
+    return {"first_sketch_of_a_fresh_genome_ms": ms[0], "min_ms": min(ms), "max_ms": max(ms), "three_fresh_genomes": runs,
+            "Gbases_s": round(rig.genomes[0].total_bp / (ms[0] * 1e-3) / 1e9, 2),
+            "kernel_groups_ms_of_a_fourth": {n: round(v[0], 3) for n, v in groups.items() if v[1]},
+            "first_sketch_after_its_bloom_insert_ms": round(t_first * 1e3, 2), "minimizers": n_cold,
+            "includes": "2-bit image, run table of valid k-mers, first-k-mer tables, workspace allocation (the first of the three)"}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one per GPU, rendezvous on
+    127.0.0.1) and hand their exit status on; the line comes from rank 0 of that job."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))                     # (plain `python bench.py --gpus N`: the ranks are ours to start)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    name = args.workload or ("c3" if world == 1 else "c4")
-    n_fam, mbp, contigs, div, scaling = WORKLOADS[name]
-    n_fam = args.genomes or n_fam
-    mbp = args.mbp or mbp
-    contigs = args.contigs or contigs
-    div = args.divergence if args.divergence is not None else div
-    shard_records = n_fam < world         # fewer genomes than GPUs: a genome's records are shared out over the ranks of its group
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report one as the other")
+    # ONE workload along the scaling curve: BASELINE configs[2] (c3, the configuration the metric is quoted on) is `value` at every N;
+    # configs[3] (c4) is the `c4` leg of the same line at every N
+    name = args.workload or "c3"
     import torch
     import torch.distributed as dist
     from ntsynt_amd.device import BloomFilter, Comm, Context, Genome, SketchPool, allgather_minimizers, bf_size_bytes, sketch
@@ -550,78 +834,28 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = Context(local_rank)
     ctx.sketch_mode(args.mode, args.prune_c)
-    # The two exchanges run inside libntsynt_hip.so over RCCL (nts_bf_allreduce_and / _groups, nts_mx_allgather) and nowhere else:
+    # The two exchanges run inside libntsynt_hip.so over RCCL (nts_bf_allreduce_and / _parts, nts_mx_allgather) and nowhere else:
     # a communicator that does not come up ends the run with its error (round 3 fell back to torch.distributed here)
-    comm, exchanges = None, "none (one GPU)"
+    comm, exchanges, rccl_ranks, served_by = None, "none (one GPU)", 1, None
     pg_dev = "cpu" if shared_gpus else f"cuda:{local_rank}"
     if world > 1:
         comm = Comm.from_torch(ctx)
         served_by = ctx.lib.nts_comm_library().decode()
-        exchanges = f"libntsynt_hip.so (nts_bf_allreduce_and, nts_mx_allgather) over {'RCCL' if served_by == 'librccl' else served_by}"
+        rccl_ranks = comm.rccl_ranks()
+        if rccl_ranks != world:
+            sys.exit(f"bench.py: the communicator holds {rccl_ranks} ranks, the launcher started {world}")
+        exchanges = f"libntsynt_hip.so (nts_bf_allreduce_and / nts_bf_allreduce_parts, nts_mx_allgather) over {'RCCL' if served_by == 'librccl' else served_by}"
     k, w = args.k, args.w
-    total_bp = int(mbp * 1e6)
 
-    # ---- the family: genome g lives on rank g mod world ------------------------------------------------------
-    mine = [g for g in range(n_fam) if g % world == rank]
-    t0 = time.time()
-    shard = None
-    if shard_records:
-        # SURVEY.md 8(e), last paragraph: genome g is worked on by the ranks r with r mod G == g, each taking a range of its records
-        # (ntsynt_amd.pipeline.shard_plan); the shards' filters are OR-ed inside the group and AND-ed across groups in exchange 1
-        # (nts_bf_allreduce_groups), the shards' lists strung together per genome behind exchange 2 (nts_mx_concat)
-        from ntsynt_amd import pipeline, synth
-        if args.substitutions_only:
-            rec_lens = [[total_bp // contigs] * contigs] * n_fam
-        elif args.family == "assembly-like":
-            rec_lens = [synth.realistic_plan(contigs, total_bp // contigs, j, ANCESTOR_SEED)[0] for j in range(n_fam)]
-        else:
-            rec_lens = [synth.structural_plan(contigs, total_bp // contigs, j, ANCESTOR_SEED)[0] for j in range(n_fam)]
-        group_of, ranges = pipeline.shard_plan(rec_lens, world)
-        gi, si, rec0, rec1 = ranges[rank]
-        whole = family_genome(ctx, args, total_bp, contigs, gi, div / 2.0)
-        shard = {"genome": gi, "rec0": rec0, "rec1": rec1, "group_of": group_of, "ranges": ranges}
-        genomes = [whole.slice(rec0, rec1)]
-        whole.free()
-        mine = [rank]                                                 # (exchange 2 numbers the shards by rank)
-    else:
-        genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in mine]
-    t_synth = time.time() - t0
-    bases = sum(g.total_bp for g in genomes)
-    fam_bases = family_bases(args, n_fam, total_bp, contigs)
-    batch = name == "c2" and not args.no_batch and len(genomes) > 1 and world == 1
-    units = [Genome.concat(ctx, genomes)] if batch else genomes
-
-    # ---- common Bloom filter: per-genome filters, local AND, AND-all-reduce over the ranks (exchange 1) --------------
-    _, nbytes = bf_size_bytes(fam_bases[0], args.fpr)               # sized by the first file of the family, on every rank (A1)
+    # ---- the family and its common filter (Rig) ------------------------------------------------------------------------------
+    rig = Rig(name, args, ctx, comm, world, rank)
+    n_fam, mbp, contigs, div, scaling, total_bp = rig.n_fam, rig.mbp, rig.contigs, rig.div, rig.scaling, rig.total_bp
+    genomes, units, mine, fam_bases, bases, t_synth = rig.genomes, rig.units, rig.mine, rig.fam_bases, rig.bases, rig.t_synth
+    shard = rig.plan
     ctx.profile(True)
-    t0 = time.time()
-    common = BloomFilter(ctx, nbytes, k, world=world if comm is not None else 1)
-    common.insert(genomes[0])
-    occ_single = common.get_fpr()
-    for g in genomes[1:]:
-        common.insert_and(g)                     # one cascade level inside the build's last pass (nts_bf_insert_and), as pipeline.run does
-    ctx.sync()
-    t_build = time.time() - t0
-    # the same filter once more, into the same allocation, with the build's workspaces (two bucket arrays and the bypass list: ~25 GB
-    # of hipMalloc at 3 Gbp) in place: what a level costs once a run is under way
-    t_build_warm = None
-    if world == 1:
-        t1 = time.time()
-        common.clear()
-        common.insert(genomes[0])
-        for g in genomes[1:]:
-            common.insert_and(g)
-        ctx.sync()
-        t_build_warm = time.time() - t1
-    t_allreduce = 0.0
-    if world > 1:
-        t1 = time.time()
-        if shard is not None:
-            comm.allreduce_groups(common, shard["group_of"])
-        else:
-            comm.allreduce_and(common)
-        ctx.sync()
-        t_allreduce = time.time() - t1
+    bt = rig.build_filter(again=True)
+    common, nbytes = rig.common, rig.nbytes
+    t_build, t_build_warm, t_allreduce, occ_single = bt["build_s"], bt["build_again_s"], bt["allreduce_s"], bt["occ_single"]
     ins_ms, ins_n = ctx.timing("bf_insert")
     insa_ms, insa_n = ctx.timing("bf_insert_and")
     occ_common = common.get_fpr()
@@ -629,21 +863,7 @@ def main():
     # ---- cold leg: the first sketch of a genome nothing has been derived from yet ---------------------------------
     cold = None
     if world == 1 and not args.no_cold_leg:
-        fresh = family_genome(ctx, args, total_bp, contigs, mine[0], div / 2.0)
-        ctx.sync()
-        t1 = time.time()
-        mx = sketch(ctx, fresh, k, w, common)
-        n_cold = len(mx)
-        t_fresh = time.time() - t1
-        mx.free()
-        fresh.free()
-        t1 = time.time()
-        sketch(ctx, genomes[-1], k, w, common).free()               # after its Bloom insert (2-bit image exists): the
-        t_first = time.time() - t1                                  # pipeline's situation
-        cold = {"first_sketch_of_a_fresh_genome_ms": round(t_fresh * 1e3, 2),
-                "Gbases_s": round(genomes[0].total_bp / t_fresh / 1e9, 2),
-                "first_sketch_after_its_bloom_insert_ms": round(t_first * 1e3, 2), "minimizers": n_cold,
-                "includes": "2-bit image, run table of valid k-mers, first-k-mer tables, workspace allocation"}
+        cold = cold_leg(args, ctx, rig)
 
     # --at-once: the genomes of a step are sketched at once, each on a context of its own (device.SketchPool; NTS_SKETCH_POOL=3
     # in the pipeline): one genome's latency-bound tail and the host's round trips overlap another's rolling.  Between +6 %
@@ -655,35 +875,7 @@ def main():
         pool.configure(lambda c: c.sketch_mode(args.mode, args.prune_c))
 
     def step():
-        held, n = [], 0
-        if pool is not None:
-            held = pool.sketch(units, k, w, common)
-            n = sum(len(mx) for mx in held)
-        else:
-            for g in units:
-                mx = sketch(ctx, g, k, w, common)
-                n += len(mx)
-                held.append(mx)
-        if world > 1:                                               # exchange 2: every rank receives every list
-            if shard is not None:
-                from ntsynt_amd.device import Minimizers
-                parts = comm.allgather_minimizers(held, mine, world)
-                n_all = 0
-                for g_ in range(n_fam):                                 # the genome's list: its shards in record order
-                    rs = [r for r in range(world) if shard["ranges"][r][0] == g_]
-                    whole_list = Minimizers.concat(ctx, [parts[r] for r in rs], [shard["ranges"][r][2] for r in rs])
-                    n_all += len(whole_list)
-                    whole_list.free()
-                shard["n_all"] = n_all
-                for mx in parts:
-                    mx.free()
-            else:
-                everything = comm.allgather_minimizers(held, mine, n_fam)
-                for mx in everything:
-                    mx.free()
-        for mx in held:
-            mx.free()
-        return n
+        return rig.step(pool)
 
     def fence():
         ctx.sync()
@@ -698,7 +890,7 @@ def main():
     def timing_of(n):
         return pool.timing(n) if pool is not None else ctx.timing(n)
 
-    def timed(n_warm, n_steps, level=2):
+    def timed(n_warm, n_steps, level=2, step=step):
         for _ in range(n_warm):
             step()
         all_ctx(lambda c: c.profile(level))   # 2: HIP events around the dominant kernel only (every pair is a bubble in the stream)
@@ -793,46 +985,30 @@ def main():
         valu = {"wave_instr_per_s_per_cu": {n: round(r["wave_instr_per_s_per_cu"] / 1e9, 3) for n, r in rows.items()},
                 "unit": "G wave-instructions/s/CU", "how": "nts_bench_valu: 8 waves per SIMD, eight independent chains per lane, wall clock"}
 
-    c4_n1 = None
-    if world == 1 and name == "c3" and not args.no_c4_leg:
-        # config 4's family on this one GPU: the N=1 point of the strong-scaling curve `--gpus N` measures
-        for g in units:
+    c4 = valley = None
+    if name == "c3" and not args.no_c4_leg:
+        # BASELINE configs[3] at this N, in the same line: eight genomes at 10 %, genome g on rank g mod N, the filter's cascade local,
+        # then the AND all-reduce; every step ends with the all-gather of the lists.  (At N = 1: all eight on this GPU.)
+        for g in rig.genomes:
             g.free()
-        fam = [family_genome(ctx, args, total_bp, contigs, g, 0.10 / 2.0) for g in range(8)]
-        c4 = BloomFilter(ctx, nbytes, k)
-        t1 = time.time()
-        c4.insert(fam[0])
-        c4_levels = []
-        for g in fam[1:]:
-            tl = time.time()
-            c4.insert_and(g)
-            c4.get_fpr()                         # (the pipeline prints the occupancy after every level; the library then knows when the filter is sparse)
-            # which way the level went: the build with the AND in its last pass, or -- the running filter all but empty -- the literal
-            # look-up of every k-mer (nts_bf_level_stats)
-            c4_levels.append({"ms": round((time.time() - tl) * 1e3, 2), "literal": bool(ctx.bf_level_stats()["sparse_level"])})
-        ctx.sync()
-        t_c4_build = time.time() - t1
-        for g in fam:
-            sketch(ctx, g, k, w, c4).free()
-        ctx.sync()
-        t1 = time.time()
-        n4 = 0
-        for _ in range(2):
-            n4 = 0
-            for g in fam:
-                mx = sketch(ctx, g, k, w, c4)
-                n4 += len(mx)
-                mx.free()
-        ctx.sync()
-        d4 = time.time() - t1
-        c4_n1 = {"workload": "8 synthetic 3000 Mbp genomes at 10% divergence on one GPU (bench.py --workload c4 --gpus 1)",
-                 "value_Gbases_s": round(sum(g.total_bp for g in fam) * 2 / d4 / 1e9, 3), "ms_per_step": round(d4 / 2 * 1e3, 2),
-                 "common_filter_occupancy": c4.get_fpr(), "minimizers_per_step": n4, "common_filter_build_s": round(t_c4_build, 4),
-                 "common_filter_levels": c4_levels}
-        c4.free()
-        for g in fam:
-            g.free()
-        genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in mine]
+        rig.genomes, rig.units = [], []
+        r4 = Rig("c4", args, ctx, comm, world, rank, use_overrides=False)
+        b4 = r4.build_filter(levels=(world == 1))
+        d4, n4 = timed(1, 2, level=0, step=r4.step)
+        c4 = {"workload": f"c4: 8 synthetic {r4.mbp:g} Mbp genomes at 10% divergence, genome g on GPU g mod {world}",
+              "n_gpus": world, "value_Gbases_s": round(sum(r4.fam_bases) * 2 / d4 / 1e9, 3), "ms_per_step": round(d4 / 2 * 1e3, 2),
+              "common_filter_occupancy": r4.common.get_fpr(), "minimizers_per_step_rank0": n4, "minimizers_per_step_all_genomes": r4.n_all if world > 1 else n4,
+              "common_filter_build_s": round(b4["build_s"], 4), "allreduce_and_s": round(b4["allreduce_s"], 4),
+              "all_reduce_gathered_set_bit_indices": bool(comm.last_sparse()) if comm is not None else None,
+              "common_filter_levels": r4.levels or None, "balance": r4.balance}
+        r4.free()
+        if world == 1 and not args.no_valley_leg:
+            valley = {"three_genomes_at_10pct": valley_leg(args, ctx, total_bp, contigs, 3, 0.10),
+                      "eight_genomes_at_4pct": valley_leg(args, ctx, total_bp, contigs, 8, 0.04)}
+        if world == 1:                                                  # the later legs of the N = 1 line work on the headline family again
+            rig.genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in mine]
+            rig.units = rig.genomes
+            genomes = units = rig.genomes
 
     out = None
     if rank == 0:
@@ -908,15 +1084,20 @@ def main():
                                  "substitutions + per genome 5 inversions (1-5 Mbp), 2 inter-contig translocations, 20 indels (1-60 kbp), "
                                  "60 small rearrangements (2-20 kbp moved / copied / inverted within 80 kbp), 200 indels of 1-50 bp",
                        "all_reduce_gathered_set_bit_indices": bool(comm.last_sparse()) if comm is not None else None,
-                       "minimizers_per_step_rank0": n_mx, "minimizers_per_step_all_genomes": shard["n_all"] if shard is not None else None,
-                       "parallelism": (f"{n_fam} genomes over {world} GPUs: the records of genome g shared out over the ranks r with r mod {n_fam} == g "
-                                       f"(rank 0: records {shard['rec0']}..{shard['rec1']} of genome 0)" if shard is not None else
-                                       f"genomes sharded over {world} GPU(s)") + (f"; the {n_at_once} genomes of a GPU sketched at once, a stream each" if n_at_once > 1 else ""),
+                       "minimizers_per_step_rank0": n_mx, "minimizers_per_step_all_genomes": rig.n_all if world > 1 else n_mx,
+                       "parallelism": ((f"{n_fam} genomes over {world} GPUs: the family's records shared out by bases across genome boundaries "
+                                        f"(rank 0: {', '.join(f'records {a}..{b} of genome {g}' for g, a, b in rig.parts) or 'none'})") if shard is not None else
+                                       f"genomes dealt out whole over {world} GPU(s)") + (f"; the {n_at_once} genomes of a GPU sketched at once, a stream each" if n_at_once > 1 else ""),
+                       "balance": rig.balance,
+                       # did RCCL see N ranks, and which library served the exchanges
+                       "rccl_ranks": rccl_ranks, "rccl_library": served_by, "library": ctx.lib._name,
+                       "scaling_base": "c3 (BASELINE configs[2], the metric's configuration) is `value` at every N; c4 (configs[3]) is the `c4` leg of the same line at every N",
                        "synth_s": round(t_synth, 3),
-                       # the N = 1 point of THIS workload's curve (the N = 1 bench line is quoted on c3; its `c4_n1` leg is c4 on one GPU):
-                       # from the committed line of the round, for whoever divides value(N) by value(1)
-                       "this_workload_on_one_gpu": n1_point(name) if world > 1 else None},
-            "roofline": {"bound": "hbm", "kernel": kern,
+                       },
+            # `bound`: what the counters say limits the dominant kernel -- the pruned select kernel issues VALU instructions in 0.9 of
+            # its cycles (profiles/r0N_sq_counters.json; its roof: `valu` below), the every-k-mer kernel waits for HBM.  achieved / peak /
+            # unit / frac stay the HBM figures the contract names (algorithmic bytes per launch / launch time against 8 TB/s)
+            "roofline": {"bound": "valu" if pruned_run else "hbm", "achieved_peak_frac_are": "HBM bytes per second against the 8 TB/s peak", "kernel": kern,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_base": round(bpb, 3),
@@ -940,10 +1121,8 @@ def main():
                       # a cascade level = the same build with the running filter AND-ed in its last pass (nts_bf_insert_and)
                       "bf_insert_and_avg_ms": round(insa_ms / max(insa_n, 1), 4) if insa_n else None,
                       "bf_insert_and_Gbases_s": round(total_bp / (insa_ms / max(insa_n, 1) * 1e-3) / 1e9, 3) if insa_ms > 0 else None,
-                      # SURVEY.md 8(d) prices the build at 129 B/base (sector read + write-back per k-mer)
-                      "bf_insert_GBs_at_129B_per_base": round(129.0 * total_bp / (ins_ms / max(ins_n, 1) * 1e-3) / 1e9, 1)
-                      if ins_ms > 0 else None,
-                      "occupancy_one_genome": round(occ_single, 6), "occupancy_common": occ_common},
+                      "roofline": bloom_roofline(total_bp, ins_ms / max(ins_n, 1)) if ins_ms > 0 else None,
+                      "occupancy_one_genome": round(occ_single, 6) if occ_single is not None else None, "occupancy_common": occ_common},
         }
         pm = pmc_traffic(name, pruned_run, bpb * per_launch_bases,
                          (0.25 + L2_LINE * probe_frac + 16.0 * cand / per_launch_bases) * per_launch_bases if pruned_run else None)
@@ -973,8 +1152,12 @@ def main():
             out["cold"] = cold
         if nruns:
             out["nruns"] = nruns
-        if c4_n1:
-            out["c4_n1"] = c4_n1
+        if valley:
+            out["valley"] = valley
+        if c4:
+            out["c4"] = c4
+            if world == 1:
+                out["c4_n1"] = c4                                       # (the name rounds 2-4 gave the N = 1 point)
     if world == 1:
         sample = bf_np = None
         e2e_slices = e2e_par = None
@@ -1023,17 +1206,31 @@ def main():
         dist.destroy_process_group()
 
 
-def n1_point(name):
-    "value of workload `name` on one GPU as the round's committed bench line has it (profiles/r04_bench_full.json)"
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_full.json")))
-        if name == "c4":
-            return {"Gbases_s": d["c4_n1"]["value_Gbases_s"], "source": "profiles/r04_bench_full.json c4_n1"}
-        if name == "c3":
-            return {"Gbases_s": d["value"], "source": "profiles/r04_bench_full.json value"}
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+def bloom_roofline(total_bp, insert_ms):
+    """The partitioned Bloom build (k_bin1 -> k_bin2 -> k_bin3) against HBM: the formulation's own bytes -- per k-mer
+    0.25 B of bases in, a 4-byte level-1 residue out and in, a packed level-2 residue (2.9 B) out and in, 4.9 B of filter out: 19 B --
+    over this run's average insert time, and next to it the bytes the counters saw per genome (rocprofv3 --pmc passes of this command,
+    2 x FETCH_SIZE + WRITE_SIZE summed over the three kernels; committed, not collected in a timed run).  SURVEY.md 8(d)'s 129 B/base
+    prices a sector read-modify-write per k-mer, which this build does not do: it is not this formulation's roofline."""
+    alg = 19.0 * total_bp
+    out = {"bound": "hbm", "formulation_bytes_per_kmer": 19.0, "achieved": round(alg / (insert_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(alg / (insert_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+           "limiter": "k_bin1 (half of the build's time) is co-limited by VALU issue and the LDS pipe, k_bin2 / k_bin3 stream at 4.4-5.5 TB/s (DESIGN.md 4.3)"}
+    for rnd in (5, 4):
+        path = os.path.join(ROOT, "profiles", f"r0{rnd}_pmc_traffic.json")
+        try:
+            kern = json.load(open(path))["kernels"]
+            tot = 0
+            for name in ("k_bin1", "k_bin2", "k_bin3<true, false>"):       # (k_bin3: the store-only finish of an insert into an empty filter)
+                e = next(v for n_, v in kern.items() if n_.startswith(name))
+                tot += 2 * e["fetch_MB_per_launch_max"] * 1048576 + e["write_MB_per_launch_max"] * 1048576
+            out["traffic"] = {"bytes_per_genome": int(tot), "GBs_at_this_runs_time": round(tot / (insert_ms * 1e-3) / 1e9, 1),
+                              "frac": round(tot / (insert_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ratio_to_formulation_bytes": round(tot / alg, 2),
+                              "source": os.path.relpath(path, ROOT), "correction": "2 x FETCH_SIZE + WRITE_SIZE"}
+            break
+        except (OSError, KeyError, ValueError, StopIteration):
+            continue
+    return out
 
 
 def pmc_traffic(name, pruned_run, algorithmic_bytes=None, line_bytes=None):

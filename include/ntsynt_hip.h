@@ -69,6 +69,10 @@ int nts_timing(nts_ctx* ctx, const char* name, double* total_ms, uint64_t* launc
  * nts_mem_reset_peak: the mark restarts from the bytes live now. */
 int nts_mem_stats(nts_ctx* ctx, uint64_t* live_bytes, uint64_t* peak_bytes, uint64_t* device_used_bytes, uint64_t* device_total_bytes);
 void nts_mem_reset_peak(void);
+/* hipMalloc / hipFree calls the library has made in this process and the host time they took, in ms: what a call that meets a
+ * context without workspaces (the first sketch of a run: rule indexlr runs once per genome, bin/ntsynt_run_pipeline.smk:74-85) spends
+ * allocating -- bench.py's `cold` leg takes the difference around a call. */
+int nts_alloc_stats(uint64_t* calls, double* ms);
 
 /* ---- A1: Bloom filter sizing ----------------------------------------------------------------
  * replaces approximate_bf_size(), src/ntsynt_make_common_bf.cpp:28-40, and the byte rounding of
@@ -229,7 +233,9 @@ int nts_and_raw(nts_ctx* ctx, void* acc_dev, const void* other_dev, uint64_t byt
  * nts_comm_wrap      : adopt an existing ncclComm_t (not destroyed by nts_comm_destroy)
  * nts_comm_library   : which library serves the collectives: "librccl" (the process's copy or the system's), the path
  *                      given in NTS_RCCL_LIB (a site's own build; the test suite's stand-in for ranks that share one
- *                      GPU), or "" when none could be loaded
+ *                      GPU), or "" when none could be loaded.  (The environment variables the product build reads are four:
+ *                      NTS_RCCL_LIB, NTS_COMM_PIECE, NTS_IO_THREADS, NTS_HOST_THREADS -- csrc/nts_knobs.h; the experiment switches
+ *                      exist only in libntsynt_hip_exp.so.)
  * nts_bf_create_sharded : a filter whose allocation is `world` chunks of a multiple of 16 bytes -- the layout the
  *                      all-reduce exchanges; otherwise identical to nts_bf_create
  * nts_bf_fill_ones   : identity of AND, for a rank that owns no genome
@@ -259,8 +265,23 @@ int nts_bf_allreduce_and(nts_ctx* ctx, nts_bf* bf, nts_comm* comm);
  * reduced filter that is all but empty -- BASELINE config 4 -- moves megabytes instead of the filter's size). */
 int nts_bf_allreduce_groups(nts_ctx* ctx, nts_bf* bf, nts_comm* comm, const int32_t* group_of, uint32_t n_groups);
 int nts_comm_last_sparse(const nts_ctx* ctx);
+/* Exchange 1 when a family's records are shared out over the ranks by bases, across genome boundaries (ntsynt_amd/pipeline.py
+ * partition_plan: three genomes on eight GPUs are eight ranges of 1.125 Gbp, not 3/3/2 ranks per genome): a rank holds one filter per
+ * genome its range of records touches.  bfs[0 .. n_local): this rank's filters, all of one size (nts_bf_create_sharded); the first
+ * n_of[rank] of them are contributions, and bfs[0] receives the result on every rank (a rank without records still passes one
+ * filter, the destination).  slot_group[r * n_slots + s] = group (genome) of rank r's s-th filter, -1 = none (a rank's contributions
+ * are its first slots); every group in [0, n_groups) needs a filter somewhere; at most 128 filters in all.  Result as
+ * nts_bf_allreduce_groups: AND over groups of (OR over the group's filters) -- the reference's cascade with the OR of
+ * src/ntsynt_make_common_bf.cpp:128-131 (the records of a file inserted into one filter) spread over ranks.  comm == NULL or world 1:
+ * the reduction over this rank's own filters. */
+int nts_bf_allreduce_parts(nts_ctx* ctx, nts_bf* const* bfs, uint32_t n_local, nts_comm* comm, uint32_t n_slots, const int32_t* slot_group,
+                           uint32_t n_groups);
 int nts_mx_allgather(nts_ctx* ctx, nts_comm* comm, uint32_t n_local, const nts_mx* const* local, const uint32_t* local_ids,
                      uint32_t n_total, nts_mx** out);
+/* nts_mx_allgather with the list slots per rank said by the caller (0: ceil(n_total / world)): with records shared out by bases a
+ * rank holds one list per genome its range touches, and the plan's maximum is the slot count on every rank. */
+int nts_mx_allgather_ex(nts_ctx* ctx, nts_comm* comm, uint32_t n_local, const nts_mx* const* local, const uint32_t* local_ids,
+                        uint32_t n_total, uint32_t slots_per_rank, nts_mx** out);
 
 /* ---- B1-B3, B5: minimizer sketch -----------------------------------------------------------------
  * replaces `indexlr -k K -w W --long --pos -s common.bf genome.fa` (smk:81-85) and the re-sketch of

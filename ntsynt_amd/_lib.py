@@ -8,6 +8,10 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libntsynt_hip.so")
+# The same sources built with -DNTS_EXPERIMENTS: the environment switches that pick kernel variants, force fallbacks or cut lists short
+# (csrc/nts_knobs.h) exist only there.  Tests and measurement scripts that use them ask for it (Context(variant="experiments"), or
+# NTS_LIB_VARIANT=experiments for a whole process); the product -- bin/, bench.py, the pipeline -- loads libntsynt_hip.so.
+EXP_LIB_PATH = os.path.join(_HERE, "libntsynt_hip_exp.so")
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -120,6 +124,9 @@ SYMBOLS = [
     ("nts_bf_allreduce_groups", ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_int32), u32]),
     ("nts_comm_last_sparse", ctypes.c_int, [c_vp]),
     ("nts_mx_allgather", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_vp), c_u32p, u32, ctypes.POINTER(c_vp)]),
+    ("nts_alloc_stats", ctypes.c_int, [c_vp, c_vp]),
+    ("nts_mx_allgather_ex", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_vp), c_u32p, u32, u32, ctypes.POINTER(c_vp)]),
+    ("nts_bf_allreduce_parts", ctypes.c_int, [c_vp, ctypes.POINTER(c_vp), u32, c_vp, u32, ctypes.POINTER(ctypes.c_int32), u32]),
     ("nts_mx_export", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("nts_mx_export_async", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("nts_sketch", ctypes.c_int, [c_vp, c_vp, u32, u32, c_vp, ctypes.POINTER(Interval), u64,
@@ -189,22 +196,26 @@ def build(force=False):
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(variant=None):
+    """variant None: the product build (or what NTS_LIB_VARIANT names); 'experiments': libntsynt_hip_exp.so"""
+    variant = variant or os.environ.get("NTS_LIB_VARIANT") or "product"
+    if variant not in ("product", "experiments"):
+        raise ValueError(f"unknown library variant {variant!r}")
+    if variant in _libs:
+        return _libs[variant]
+    path = LIB_PATH if variant == "product" else EXP_LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: the HIP extension is required (there is no CPU fallback). "
+            f"{path} is missing: the HIP extension is required (there is no CPU fallback). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C ntsynt_amd/csrc`.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)       # AttributeError if the ABI and the header drift apart
         fn.restype = restype
         fn.argtypes = argtypes
-    _lib = lib
+    _libs[variant] = lib
     return lib

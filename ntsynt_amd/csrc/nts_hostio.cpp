@@ -7,6 +7,8 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "nts_knobs.h"
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -478,7 +480,8 @@ unsigned host_threads(unsigned cap)
     }
     fclose(f);
   }
-  if (const char* e = getenv("NTS_HOST_THREADS")) { // (an upper limit set by the user, e.g. to leave cores to other work)
+  static const char* const e = getenv("NTS_HOST_THREADS"); // (an upper limit set by the user, e.g. to leave cores to other work; read once)
+  if (e) {
     const long v = atol(e);
     if (v > 0) n = std::min<unsigned>(n, (unsigned)v);
   }
@@ -519,7 +522,7 @@ static int walk_impl(uint64_t nv, uint64_t ne, const EdgeT* e_u, const EdgeT* e_
   const unsigned T = host_threads(16);
   const uint32_t NONE = 0xFFFFFFFFu;
   auto t_last = std::chrono::steady_clock::now();
-  const bool debug = getenv("NTS_HOST_DEBUG") != nullptr;
+  const bool debug = NTS_KNOB("NTS_HOST_DEBUG") != nullptr;
   auto lap = [&](const char* what) {
     if (!debug) return;
     const auto now = std::chrono::steady_clock::now();

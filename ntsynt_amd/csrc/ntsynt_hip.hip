@@ -36,6 +36,7 @@
 
 #include "../../include/ntsynt_hip.h"
 #include "nts_device.h"
+#include "nts_knobs.h"
 
 using namespace nts;
 
@@ -48,9 +49,21 @@ namespace nts_mem {
 std::mutex mu;
 std::map<void*, size_t> sizes;
 std::atomic<uint64_t> live{0}, peak{0};
+// calls of hipMalloc / hipFree made through here and the host time they took (nts_alloc_stats: what a cold call spends allocating)
+std::atomic<uint64_t> alloc_calls{0}, alloc_ns{0};
+struct AllocClock
+{
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~AllocClock()
+  {
+    alloc_calls.fetch_add(1);
+    alloc_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
 
 inline hipError_t dev_malloc(void** p, size_t n)
 {
+  AllocClock clk;
   const hipError_t e = ::hipMalloc(p, n);
   if (e == hipSuccess && *p) {
     {
@@ -74,6 +87,7 @@ inline hipError_t dev_malloc(T** p, size_t n)
 // the same with allocation flags (hipDeviceMallocUncached / hipDeviceMallocFinegrained: how the L2 treats the memory)
 inline hipError_t dev_malloc_flags(void** p, size_t n, unsigned flags)
 {
+  AllocClock clk;
   const hipError_t e = ::hipExtMallocWithFlags(p, n, flags);
   if (e == hipSuccess && *p) {
     {
@@ -98,6 +112,7 @@ inline hipError_t dev_free(void* p)
       sizes.erase(it);
     }
   }
+  AllocClock clk;
   return ::hipFree(p);
 }
 } // namespace nts_mem
@@ -186,6 +201,10 @@ struct nts_ctx
   int summary_mode = 0; // 0 auto, 1 never (tests)
   uint32_t last_summary = 0;
   // tiered selection (nts_tiers.inc): 0 auto, 1 never, 2 wherever it applies; figures of the last call that went that way
+  uint64_t comm_piece = 0;        // bytes per piece of exchange 1's reduce-scatter (0: 256 MiB; NTS_COMM_PIECE at nts_init)
+  int comm_sparse_mode = 0;       // 1: never gather set-bit indices (experiments build: NTS_COMM_SPARSE=0)
+  uint64_t comm_sparse_below = 0; // gather indices when the fullest chunk holds at most this many bits (0: chunk bytes / 128)
+  unsigned io_threads = 8;        // host threads of a FASTA upload (NTS_IO_THREADS at nts_init)
   int tier_mode = 0;
   double tier_x0 = 0;       // accepted k-mers per window the first tier aims at (0: the default)
   uint32_t tier_half = 0;   // 1: tiers in steps of 1.5 / 1.33 instead of 2
@@ -1527,7 +1546,7 @@ FastMod make_fastmod(uint64_t m)
   fm.m_lo = (uint32_t)m;
   fm.m_hi = (uint32_t)(m >> 32);
   fm.form = (fm.inv >> 32) ? 0u : ((m >> 38) ? 1u : 2u);
-  if (const char* e = getenv("NTS_FASTMOD_FORM")) fm.form = std::min<uint32_t>(fm.form, (uint32_t)atoi(e)); // (tests: the longer forms)
+  if (const char* e = NTS_KNOB("NTS_FASTMOD_FORM")) fm.form = std::min<uint32_t>(fm.form, (uint32_t)atoi(e)); // (tests: the longer forms)
   return fm;
 }
 
@@ -1830,6 +1849,11 @@ int nts_init(int device, nts_ctx** out)
     nts_destroy(ctx);
     return NTS_EHIP;
   }
+  // what a context reads from the environment, once (nts_knobs.h)
+  if (const char* v = getenv("NTS_COMM_PIECE")) ctx->comm_piece = strtoull(v, nullptr, 10);
+  if (const char* v = getenv("NTS_IO_THREADS")) ctx->io_threads = (unsigned)std::max(1, std::min(32, atoi(v)));
+  if (const char* v = NTS_KNOB("NTS_COMM_SPARSE")) ctx->comm_sparse_mode = atoi(v) == 0 ? 1 : 0;
+  if (const char* v = NTS_KNOB("NTS_COMM_SPARSE_BELOW")) ctx->comm_sparse_below = strtoull(v, nullptr, 10);
   *out = ctx;
   return NTS_OK;
 }
@@ -1890,6 +1914,14 @@ int nts_mem_stats(nts_ctx* ctx, uint64_t* live_bytes, uint64_t* peak_bytes, uint
   }
   if (device_used_bytes) *device_used_bytes = tot - fr;
   if (device_total_bytes) *device_total_bytes = tot;
+  return NTS_OK;
+}
+
+// hipMalloc / hipFree calls the library has made in this process and the host time spent in them (a cold call's allocation share)
+int nts_alloc_stats(uint64_t* calls, double* ms)
+{
+  if (calls) *calls = nts_mem::alloc_calls.load();
+  if (ms) *ms = (double)nts_mem::alloc_ns.load() * 1e-6;
   return NTS_OK;
 }
 
@@ -2330,7 +2362,7 @@ static int bf_create_alloc(nts_ctx* ctx, uint64_t bytes, uint64_t alloc, nts_bf*
   // NTS_BF_MEM=uncached | finegrained: the filter in memory the L2 does not cache / keeps coherent (an experiment: does a random
   // 4-byte probe then move less than a 128-byte line?  DESIGN.md 4.2)
   hipError_t e;
-  const char* kind = getenv("NTS_BF_MEM");
+  const char* kind = NTS_KNOB("NTS_BF_MEM");
   if (kind && !strcmp(kind, "uncached"))
     e = dev_malloc_flags((void**)&bf->d_words, alloc, hipDeviceMallocUncached);
   else if (kind && !strcmp(kind, "finegrained"))
@@ -2497,7 +2529,7 @@ int nts_bf_insert_and(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, uint32_t k
   ++acc->version;
   // (a running filter known to hold fewer than one bit per 2^12: most 64 KiB slices are empty, k_bin3 looks before it reads residues)
   const bool sparse = pop_before >= 0 && (uint64_t)pop_before < ((acc->bytes * 8) >> 12);
-  const bool fused_ok = ctx->bf_build_mode != 1 && !(getenv("NTS_BIN_FUSED_AND") && atoi(getenv("NTS_BIN_FUSED_AND")) == 0);
+  const bool fused_ok = ctx->bf_build_mode != 1 && !(NTS_KNOB("NTS_BIN_FUSED_AND") && atoi(NTS_KNOB("NTS_BIN_FUSED_AND")) == 0);
   rc = fused_ok ? bf_insert_binned(ctx, acc, g, *T, k, ctx->bf_build_mode == 2, false, sparse ? 2 : 1, late_ctl) : 1;
   if (rc != 0 && rc != 1) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -3159,7 +3191,10 @@ int ensure_pack(nts_ctx* ctx, const nts_genome* g)
   uint32_t* p = nullptr;
   // (320 more words that nothing looks at: k_hash_select_hi stages 272 words from the word of a tile's first base on)
   HIP_TRY(ctx, dev_malloc((void**)&p, (n_words + 320) * 4));
-  if (n_words) hipLaunchKernelGGL(k_pack2, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, g->d_code + PAD, n_words, p);
+  {
+    ScopedTimer t(ctx, "pack_image");
+    if (n_words) hipLaunchKernelGGL(k_pack2, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, g->d_code + PAD, n_words, p);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     dev_free(p);
@@ -3231,7 +3266,7 @@ int bf_make_summary(nts_ctx* ctx, const nts_bf* filter, uint32_t shift)
 // (bf_level_sparse).
 int launch_accept(nts_ctx* ctx, const nts_genome* g, uint32_t k, const AcceptParams& A, const uint32_t* fold, uint64_t n_kt)
 {
-  if (fold && k <= 32 && !(getenv("NTS_ACCEPT_REG") && atoi(getenv("NTS_ACCEPT_REG")) == 0)) {
+  if (fold && k <= 32 && !(NTS_KNOB("NTS_ACCEPT_REG") && atoi(NTS_KNOB("NTS_ACCEPT_REG")) == 0)) {
     // bases from the 2-bit image in registers (k_hash_accept4r); NTS_ACCEPT_REG=0: the LDS-staged kernel (tests)
     if (int rc_pk = ensure_pack(ctx, g)) return rc_pk;
     if (!ctx->acc4r_lds_set) {
@@ -3245,10 +3280,10 @@ int launch_accept(nts_ctx* ctx, const nts_genome* g, uint32_t k, const AcceptPar
     }
     // (persistent workgroups, one per CU -- 128 KiB of LDS each --, each loops over groups of four tiles; NTS_ACC4R_WGS overrides)
     const uint64_t groups4 = (n_kt + 3) / 4;
-    const uint64_t wgs = getenv("NTS_ACC4R_WGS") ? (uint64_t)std::max(1, atoi(getenv("NTS_ACC4R_WGS"))) : 256ull;
+    const uint64_t wgs = NTS_KNOB("NTS_ACC4R_WGS") ? (uint64_t)std::max(1, atoi(NTS_KNOB("NTS_ACC4R_WGS"))) : 256ull;
     const dim3 grid4((uint32_t)std::min<uint64_t>(groups4, wgs));
 #define ACC4R_RUN(B, F) hipLaunchKernelGGL((k_hash_accept4r<B, F>), grid4, dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A, g->d_pack, fold, n_kt)
-    if (getenv("NTS_ACC4R_BLOCK") && atoi(getenv("NTS_ACC4R_BLOCK")) == 4)
+    if (NTS_KNOB("NTS_ACC4R_BLOCK") && atoi(NTS_KNOB("NTS_ACC4R_BLOCK")) == 4)
       ACC4R_RUN(4, -1); // (blocks of four, the modulus form read at run time: the kernel as it was, for comparisons)
     else if (A.fm.form == 2)
       ACC4R_RUN(8, 2);
@@ -3280,12 +3315,12 @@ int bf_level_sparse(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, const Genome
   ctx->last_bf_sparse_accepted = 0;
   // (a build mode forced by the caller -- tests -- means the build: only the automatic choice comes here)
   if (pop_before < 0 || !acc->owned || ctx->summary_mode != 0 || ctx->bf_build_mode != 0) return 1;
-  if (getenv("NTS_BF_SPARSE_LEVEL") && atoi(getenv("NTS_BF_SPARSE_LEVEL")) == 0) return 1;
+  if (NTS_KNOB("NTS_BF_SPARSE_LEVEL") && atoi(NTS_KNOB("NTS_BF_SPARSE_LEVEL")) == 0) return 1;
   const uint64_t V = T.rt.n_valid;
   if (V == 0 || pop_before == 0) return 1; // (nothing to look up / nothing to keep: the build's own finish handles both)
   const double bits = (double)acc->bytes * 8.0;
   uint32_t shift = 7;
-  const uint32_t sum_log2 = getenv("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(getenv("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
+  const uint32_t sum_log2 = NTS_KNOB("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(NTS_KNOB("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
   while ((bits / (double)(1ull << shift)) > (double)(1ull << sum_log2) && shift < 30) ++shift; // (the sketch's choice: nts_sketch_ex)
   // the sketch's own criterion for "sparse" (a summary bit set with probability < 0.3) -- and the level must beat the build, which
   // with a sparse running filter (k_bin3 skips the residues of empty slices) takes 20-21 ms per 3 Gbp.  Measured level by level on BASELINE configs[3] (scripts/c4_levels.py, profiles/r04_c4_levels.json): through the summary
@@ -3295,8 +3330,8 @@ int bf_level_sparse(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, const Genome
   // (tests and measurements: every accept kernel at any occupancy).
   const double occ = (double)pop_before / bits;
   const bool fold_fits = bits >= (double)(1u << FOLD_BITS_LOG2) && (double)pop_before < 1.2 * (double)(1u << FOLD_BITS_LOG2);
-  if (getenv("NTS_BF_SPARSE_MAX_OCC")) {
-    if (occ >= atof(getenv("NTS_BF_SPARSE_MAX_OCC"))) return 1;
+  if (NTS_KNOB("NTS_BF_SPARSE_MAX_OCC")) {
+    if (occ >= atof(NTS_KNOB("NTS_BF_SPARSE_MAX_OCC"))) return 1;
   } else if (occ >= 0.3 / (double)(1ull << shift) || !fold_fits || ctx->fold_mode != 0) {
     return 1;
   }
@@ -3401,7 +3436,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   // (listed k-mers per tile: mean 4096 c/w, spread ~ its square root; a tile with more than a round holds takes the slow path.
   // Margins measured at 3 Gbp, pairs at 2-8 % divergence: two per lane up to a mean of 107 (c = 22: select 1.79 ms against 2.00
   // with four per lane), four per lane up to 223 (c = 53: 4.32 ms against 4.79 for k_hash_select); NTS_HI_M2 / NTS_HI_M4 override)
-  const double hi_m4 = getenv("NTS_HI_M4") ? atof(getenv("NTS_HI_M4")) : 1.15, hi_m2 = getenv("NTS_HI_M2") ? atof(getenv("NTS_HI_M2")) : 1.2;
+  const double hi_m4 = NTS_KNOB("NTS_HI_M4") ? atof(NTS_KNOB("NTS_HI_M4")) : 1.15, hi_m2 = NTS_KNOB("NTS_HI_M2") ? atof(NTS_KNOB("NTS_HI_M2")) : 1.2;
   const bool sel_hi = !accept_all && !tp && ctx->select_impl != 1 && k <= HI_K_MAX && 4096.0 * prune_c / w * hi_m4 <= 256.0 &&
                       (ctx->select_impl == 2 || 2ull * T.n_runs <= (V + HIW_TILE - 1) / HIW_TILE + 64);
   const uint32_t hi_per = 4096.0 * prune_c / w * hi_m2 <= 128.0 ? 2u : 4u; // listed k-mers per lane and round
@@ -3435,7 +3470,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   // the upper-halves kernel drops about 70 % of the accepted k-mers again (those that cannot win a window) -- where its tiles lie inside
   // one run; the window and gather kernels are launched over the capacity, so half of it is what they get until a call has
   // needed more (an assembly in pieces: the retry below, once per context)
-  const bool elim_on = sel_hi && !(getenv("NTS_SELECT_ELIM") && atoi(getenv("NTS_SELECT_ELIM")) == 0);
+  const bool elim_on = sel_hi && !(NTS_KNOB("NTS_SELECT_ELIM") && atoi(NTS_KNOB("NTS_SELECT_ELIM")) == 0);
   if (elim_on && !ctx->elim_needs_full_cap) cseg_cap = cseg_cap / 2 + 8192;
   unsigned long long ctl[N_SEG + 1];
   std::vector<uint64_t> glo(GAP_PEEK), ghi(GAP_PEEK);
@@ -3479,7 +3514,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     S.tile_cnt = d_tcnt;
     S.tile_ordered = d_tord;
     // k_hash_select_hi drops accepted k-mers that cannot be a window's minimum (NTS_SELECT_ELIM=0: keeps them all; same result)
-    S.w_elim = (getenv("NTS_SELECT_ELIM") && atoi(getenv("NTS_SELECT_ELIM")) == 0) ? 0u : w;
+    S.w_elim = (NTS_KNOB("NTS_SELECT_ELIM") && atoi(NTS_KNOB("NTS_SELECT_ELIM")) == 0) ? 0u : w;
     if (tp) {
       PR_WS(d_dir, uint32_t*, "tier_dir", n_kt * 12);
       PR_WS(d_tstats, unsigned long long*, "tier_stats", 16);
@@ -3529,11 +3564,13 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       A.summary = ctx->cur_summary;
       A.shift = ctx->cur_summary_shift;
       A.probe_mask = ~0u;
-      if (getenv("NTS_ACC_NO_LOOKUP") && atoi(getenv("NTS_ACC_NO_LOOKUP"))) { // a measurement switch that changes the RESULT: never silently
+#ifdef NTS_EXPERIMENTS
+      if (NTS_KNOB("NTS_ACC_NO_LOOKUP") && atoi(NTS_KNOB("NTS_ACC_NO_LOOKUP"))) { // a measurement switch that changes the RESULT: never silently, never in the product build
         A.probe_mask = 0u;
         static std::once_flag warned;
         std::call_once(warned, [] { fprintf(stderr, "[ntsynt_hip] NTS_ACC_NO_LOOKUP is set: sparse-filter sketches return WRONG results (timing experiment only)\n"); });
       }
+#endif
       A.seg_j = d_sj;
       A.seg_key = d_sk;
       A.seg_cap = cseg_cap;
@@ -3558,7 +3595,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
         // tiles per wave: enough to amortise the table load and to overlap probes with rolling, not so many that a small genome leaves CUs idle
         const uint64_t waves_wanted = 256ull * 32ull * 2ull;
         uint32_t tpw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, n_kt / waves_wanted)); // (3 Gbp: 4 / 8 / 16 / 32 -> 1430 / 1460 / 1487 / 1404 Gbases/s)
-        if (const char* e = getenv("NTS_HI_TPW")) tpw = (uint32_t)std::max(1, std::min(64, atoi(e))); // (tests: small inputs through the multi-tile loop)
+        if (const char* e = NTS_KNOB("NTS_HI_TPW")) tpw = (uint32_t)std::max(1, std::min(64, atoi(e))); // (tests: small inputs through the multi-tile loop)
         const uint64_t per_wg = (uint64_t)HIW_WAVES * tpw;
         const dim3 grid((uint32_t)((n_kt + per_wg - 1) / per_wg));
         if (filter && hi_per == 2)
@@ -3972,7 +4009,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     SK_TRY(nts_bf_popcount(ctx, filter, &pc));
     const double bits = (double)filter->bytes * 8.0;
     uint32_t shift = 7;
-    const uint32_t sum_log2 = getenv("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(getenv("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
+    const uint32_t sum_log2 = NTS_KNOB("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(NTS_KNOB("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
     while ((bits / (double)(1ull << shift)) > (double)(1ull << sum_log2) && shift < 30) ++shift; // summary <= 2^sum_log2 bits
     if ((double)pc / bits * (double)(1ull << shift) < 0.3) {
       SK_TRY(bf_make_summary(ctx, filter, shift));

@@ -21,8 +21,9 @@ class NtsError(RuntimeError):
 class Context:
     """One per GPU (owns a HIP stream)."""
 
-    def __init__(self, device=0):
-        self.lib = _lib.load()
+    def __init__(self, device=0, variant=None):
+        "variant: None = the product build of the library; 'experiments' = the build with the experiment switches (tests, measurements)"
+        self.lib = _lib.load(variant)
         h = c_vp()
         rc = self.lib.nts_init(int(device), ctypes.byref(h))
         if rc != 0:
@@ -128,6 +129,12 @@ class Context:
         a, b, c, d = u64(), u64(), u64(), u64()
         self.check(self.lib.nts_mem_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)), "nts_mem_stats")
         return {"live": a.value, "peak": b.value, "device_used": c.value, "device_total": d.value}
+
+    def alloc_stats(self):
+        "(hipMalloc / hipFree calls the library has made in this process, host milliseconds spent in them): nts_alloc_stats"
+        n, ms = u64(), ctypes.c_double()
+        self.lib.nts_alloc_stats(ctypes.byref(n), ctypes.byref(ms))
+        return n.value, ms.value
 
     def mem_reset_peak(self):
         self.lib.nts_mem_reset_peak()
@@ -425,13 +432,28 @@ class Comm:
         arr = (ctypes.c_int32 * self.world)(*[int(g) for g in group_of])
         self.ctx.check(self.ctx.lib.nts_bf_allreduce_groups(self.ctx.h, bf.h, self.h, arr, max(group_of) + 1), "nts_bf_allreduce_groups")
 
+    def allreduce_parts(self, filters, slot_group, n_slots, n_groups):
+        """exchange 1 with a family's records shared out by bases (pipeline.partition_plan): this rank's `filters` (one per genome its
+        range touches, all from BloomFilter(..., world=N); filters[0] receives the result; a rank without records passes one filter),
+        slot_group[r][s] = genome of rank r's s-th filter or -1 (nts_bf_allreduce_parts)"""
+        flat = [int(g) for row in slot_group for g in (list(row) + [-1] * (n_slots - len(row)))]
+        arr = (ctypes.c_int32 * len(flat))(*flat)
+        hs = (c_vp * len(filters))(*[f.h for f in filters])
+        self.ctx.check(self.ctx.lib.nts_bf_allreduce_parts(self.ctx.h, hs, len(filters), self.h, int(n_slots), arr, int(n_groups)),
+                       "nts_bf_allreduce_parts")
+
+    def rccl_ranks(self):
+        "ranks of the communicator as the library sees it (nts_comm_world)"
+        return int(self.ctx.lib.nts_comm_world(self.h))
+
     def last_sparse(self):
         "True if the last all-reduce gathered set-bit indices instead of the reduced chunks"
         return bool(self.ctx.lib.nts_comm_last_sparse(self.ctx.h))
 
-    def allgather_minimizers(self, local, local_ids, n_total):
-        "exchange 2: the ranks' Minimizers -> [Minimizers of genome g for g in range(n_total)], resident in HBM"
-        return allgather_minimizers(self.ctx, self, local, local_ids, n_total)
+    def allgather_minimizers(self, local, local_ids, n_total, slots=0):
+        """exchange 2: the ranks' Minimizers -> [Minimizers of list g for g in range(n_total)], resident in HBM; slots: lists a rank may
+        hold (0: ceil(n_total / world))"""
+        return allgather_minimizers(self.ctx, self, local, local_ids, n_total, slots)
 
     def close(self):
         if self.h:
@@ -445,13 +467,13 @@ class Comm:
             pass
 
 
-def allgather_minimizers(ctx, comm, local, local_ids, n_total):
-    "nts_mx_allgather; comm None = one rank (the lists are copied into fresh handles)"
+def allgather_minimizers(ctx, comm, local, local_ids, n_total, slots=0):
+    "nts_mx_allgather_ex; comm None = one rank (the lists are copied into fresh handles)"
     n = len(local)
     arr = (c_vp * max(n, 1))(*[m.h for m in local])
     ids = (ctypes.c_uint32 * max(n, 1))(*[int(i) for i in local_ids])
     out = (c_vp * int(n_total))()
-    ctx.check(ctx.lib.nts_mx_allgather(ctx.h, comm.h if comm is not None else None, n, arr, ids, int(n_total), out),
+    ctx.check(ctx.lib.nts_mx_allgather_ex(ctx.h, comm.h if comm is not None else None, n, arr, ids, int(n_total), int(slots), out),
               "nts_mx_allgather")
     return [Minimizers(ctx, c_vp(out[g])) for g in range(int(n_total))]
 

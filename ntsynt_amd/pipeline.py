@@ -330,6 +330,58 @@ def shard_plan(rec_lens, world):
     return group_of, ranges
 
 
+def partition_plan(rec_lens, world):
+    """A family's records shared out over the ranks by BASES, across genome boundaries: the records of all genomes in
+    family order are cut into `world` consecutive ranges at the record boundaries nearest to the multiples of total / world -- three
+    3 Gbp genomes on eight GPUs are eight ranges of ~1.125 Gbp, not 3 / 3 / 2 ranks per genome.  Records are the unit (windows never cross
+    them, and records are what the reference parallelises over, src/ntsynt_make_common_bf.cpp:128-131,145-153).  rec_lens[g]: record
+    lengths of genome g.  Returns parts[rank] = [(genome, rec0, rec1), ...] in family order: every record in exactly one part, a
+    rank's parts belong to different genomes; a rank may be left without any (more ranks than records)."""
+    n_rec = [len(x) for x in rec_lens]
+    flat = np.concatenate([np.asarray(x, dtype=np.float64) for x in rec_lens]) if sum(n_rec) else np.zeros(0)
+    cum = np.concatenate(([0.0], np.cumsum(flat)))
+    cuts = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        at = int(np.searchsorted(cum, target, side="left"))
+        if at > 0 and (at >= cum.size or target - cum[at - 1] <= cum[at] - target):
+            at -= 1                                              # the boundary before the target is the nearer one
+        cuts.append(min(max(at, cuts[-1]), flat.size))
+    cuts.append(flat.size)
+    g_start = np.concatenate(([0], np.cumsum(n_rec))).astype(np.int64)
+    parts = []
+    for r in range(world):
+        mine = []
+        for g in range(len(rec_lens)):
+            lo, hi = max(cuts[r], int(g_start[g])), min(cuts[r + 1], int(g_start[g + 1]))
+            if lo < hi:
+                mine.append((g, lo - int(g_start[g]), hi - int(g_start[g])))
+        parts.append(mine)
+    return parts
+
+
+def partition_groups(parts, n_rec):
+    """The filters of exchange 1 under partition_plan.  A rank builds ONE filter for the genomes it holds whole (their cascade is local:
+    insert, then insert_and) and one per genome it holds a part of.  Returns (filters_of[rank] = [(group label, [part indices])], slot_group[rank] =
+    [dense group numbers], n_groups): a genome in parts is a group (OR over its parts' filters), a rank's whole genomes together are a
+    group of their own; the common filter is the AND over the groups (nts_bf_allreduce_parts)."""
+    filters_of, labels = [], []
+    for r, mine in enumerate(parts):
+        whole = [i for i, (g, a, b) in enumerate(mine) if a == 0 and b == n_rec[g]]
+        fs = []
+        if whole:
+            fs.append((("whole", r), whole))
+        for i, (g, a, b) in enumerate(mine):
+            if i not in whole:
+                fs.append((("genome", g), [i]))
+        filters_of.append(fs)
+        for lab, _ in fs:
+            if lab not in labels:
+                labels.append(lab)
+    dense = {lab: i for i, lab in enumerate(labels)}
+    return filters_of, [[dense[lab] for lab, _ in fs] for fs in filters_of], len(labels)
+
+
 def shard_masks(masks, rec0, rec1):
     "the hard-mask intervals of a genome that fall into records [rec0, rec1), renumbered for the slice (nts_interval arrays or (rec, start, end) tuples)"
     if masks is None:
@@ -440,11 +492,15 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         backend.init_comm()
     owner = {p: i % world for i, p in enumerate(fastas)}
     mine = [p for p in fastas if owner[p] == rank]
-    # fewer genomes than GPUs: every genome is shared out by records over a group of ranks (shard_plan); the device engine only
-    shard_mode = (world > len(fastas) and isinstance(backend, GpuBackend) and engine != "host"
+    # genomes that do not deal out evenly over the GPUs (three on eight, three on two): the family's records are shared out by bases,
+    # across genome boundaries (partition_plan); the device engine only
+    shard_mode = (world > 1 and len(fastas) % world != 0 and isinstance(backend, GpuBackend) and engine != "host"
                   and mx_tsvs is None and not repeat and os.environ.get("NTS_SHARD_RECORDS", "1") != "0")
     if shard_mode:
-        mine = [fastas[rank % len(fastas)]]                     # the genome of this rank's group (loaded whole, cut below)
+        # before the plan exists (it needs every genome's record lengths) a rank loads the genome its range most likely starts in;
+        # with more genomes than ranks, a consecutive block of them -- every genome is loaded somewhere
+        G_ = len(fastas)
+        mine = [fastas[(rank * G_) // world]] if world >= G_ else [p for i, p in enumerate(fastas) if (i * world) // G_ == rank]
 
     # limits of this implementation, checked before anything is written (the reference has none of them)
     for ww in [w] + list(w_rounds):
@@ -459,7 +515,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         if len(g.names) >= MAX_RECORDS or (rl is not None and len(rl) and int(np.max(rl)) >= MAX_RECORD_BP):
             raise ValueError(f"{p}: more than 2^22 records or a record of 2^40 bases or more "
                              "(limits of the refinement rounds' composite interval keys)")
-        if write_fai and (not shard_mode or rank < len(fastas)):            # (shard mode: the first rank of a genome's group writes for it)
+        if write_fai and not shard_mode:                                    # (shard mode: the first rank that holds records of a genome writes for it, below)
             fa.write_fai(f"{fa.basename(p)}.fai", g.recs)
 
     # stage 3's initial round alone needs no sequence: record ids come from the minimizer files
@@ -500,13 +556,37 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         meta = {p: v for part in gathered for p, v in part.items()}
     shard = None
     if shard_mode:
-        group_of, ranges = shard_plan([meta[p][2] for p in fastas], world)
-        gi, si, rec0, rec1 = ranges[rank]
-        whole = genomes[fastas[gi]]
-        shard = {"genome": gi, "number": si, "rec0": rec0, "rec1": rec1, "group_of": group_of, "ranges": ranges,
-                 "sub": whole.slice(rec0, rec1, backend.ctx), "leader": si == 0}
-        if not shard["leader"]:                                # only a group's first rank keeps the whole genome (k-mer text of the TSV)
-            whole.free()
+        n_rec = [len(meta[p][2]) for p in fastas]
+        plan = partition_plan([meta[p][2] for p in fastas], world)
+        filters_of, slot_group, n_groups = partition_groups(plan, n_rec)
+        my_parts = plan[rank]
+        leader_of = {}                                          # genome -> the first rank that holds records of it: keeps the whole genome
+        for r_, ps in enumerate(plan):                          # (k-mer text of the minimizer TSV) and writes the genome's files
+            for g_, _, _ in ps:
+                leader_of.setdefault(g_, r_)
+        need = {g_ for g_, _, _ in my_parts}
+        for g_ in sorted(need):                                 # what the first guess did not bring
+            if fastas[g_] not in genomes:
+                genomes.update(load_genomes(backend, [fastas[g_]]))
+                arrived(fastas[g_], genomes[fastas[g_]])
+        subs = []
+        for g_, a, b in my_parts:
+            whole_g = genomes[fastas[g_]]
+            subs.append(whole_g if (a == 0 and b == n_rec[g_]) else whole_g.slice(a, b, backend.ctx))
+        for p in list(genomes):                                 # a genome stays whole only with its leader or where a part is the whole of it
+            g_ = fastas.index(p)
+            keep = leader_of.get(g_) == rank or any(sub is genomes[p] for sub in subs)
+            if not keep:
+                genomes.pop(p).free()
+        if write_fai:
+            for g_, r_ in leader_of.items():
+                if r_ == rank:
+                    fa.write_fai(f"{fa.basename(fastas[g_])}.fai", genomes[fastas[g_]].recs)
+        # exchange 2 numbers the parts of all ranks in family order
+        part_base = int(sum(len(ps) for ps in plan[:rank]))
+        shard = {"parts": my_parts, "subs": subs, "plan": plan, "filters_of": filters_of, "slot_group": slot_group, "n_groups": n_groups,
+                 "n_slots": max(1, max(len(fs) for fs in filters_of)), "list_slots": max(1, max(len(ps) for ps in plan)),
+                 "part_base": part_base, "n_parts": int(sum(len(ps) for ps in plan)), "leader_of": leader_of}
         st.mark("shard_resident")
     st.stop()
 
@@ -545,8 +625,17 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         my_sorted = [p for p in ordered if owner[p] == rank] if not shard_mode else []
         bf = backend.bf_new(nbytes, k, world, ones=(world > 1 and not my_sorted and not shard_mode))
         st.mark("bf_allocated")
+        part_filters = [bf]
         if shard_mode:
-            backend.bf_insert(bf, shard["sub"])                 # the shard's k-mers: OR-ed with the group's other shards in the exchange
+            # one filter for the genomes this rank holds whole (their cascade is local), one per genome it holds a part of: a part's
+            # k-mers are OR-ed with the genome's other parts in the exchange, the genomes AND-ed (nts_bf_allreduce_parts)
+            for fi, (_, idxs) in enumerate(shard["filters_of"][rank]):
+                f_ = bf if fi == 0 else backend.bf_new(nbytes, k, world)
+                if fi:
+                    part_filters.append(f_)
+                backend.bf_insert(f_, shard["subs"][idxs[0]])
+                for i_ in idxs[1:]:
+                    backend.bf_insert_and(f_, shard["subs"][i_])
         if my_sorted:
             backend.bf_insert(bf, genomes[my_sorted[0]])
             st.mark("bf_first_insert")
@@ -570,7 +659,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         if world > 1:
             if shard_mode:
                 backend.ctx.sync()
-                backend.comm.allreduce_groups(bf, shard["group_of"])
+                backend.comm.allreduce_parts(part_filters, shard["slot_group"], shard["n_slots"], shard["n_groups"])
+                for f_ in part_filters[1:]:
+                    f_.free()
             else:
                 backend.allreduce_and(bf)                      # GpuBackend: nts_bf_allreduce_and; test doubles bring their own
         log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
@@ -642,22 +733,30 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         from .synteny_device import DeviceSyntenyEngine
         mine_idx = [i for i, p in enumerate(fastas) if owner[p] == rank]
         if shard_mode:
-            mine_idx = [shard["genome"]] if shard["leader"] else []          # (the genomes whose minimizer TSV this rank writes)
+            mine_idx = sorted(g_ for g_, r_ in shard["leader_of"].items() if r_ == rank)      # (the genomes whose minimizer TSV this rank writes)
 
         def sketch_dev_round(masks_by_asm, new_w):
             "device lists of all assemblies: every rank sketches its own genomes (one batch when they are small), one all-gather"
             if shard_mode:
-                # this rank's records of its genome; the all-gather hands every rank every shard's list (shard = rank number), the
-                # shards of a genome are strung together in record order
+                # this rank's parts; the all-gather hands every rank every part's list (numbered in family order), the parts of a
+                # genome are strung together in record order
                 from .device import Minimizers
-                ms = shard_masks(masks_by_asm[shard["genome"]], shard["rec0"], shard["rec1"]) if masks_by_asm is not None else None
-                part = backend.sketch_dev([shard["sub"]], k, new_w, bf, [ms] if ms is not None else None)[0]
-                parts = backend.exchange_dev({rank: part}, world)
-                part.free()
-                out = {}
+                ms = None
+                if masks_by_asm is not None:
+                    ms = [shard_masks(masks_by_asm[g_], a, b) for g_, a, b in shard["parts"]]
+                mine_l = backend.sketch_dev(shard["subs"], k, new_w, bf, ms) if shard["subs"] else []
+                ids = [shard["part_base"] + i for i in range(len(mine_l))]
+                parts = backend.comm.allgather_minimizers(mine_l, ids, shard["n_parts"], shard["list_slots"])
+                for m_ in mine_l:
+                    m_.free()
+                out, at = {}, 0
+                by_genome = {}
+                for ps in shard["plan"]:
+                    for g_, a, b in ps:
+                        by_genome.setdefault(g_, []).append((parts[at], a))
+                        at += 1
                 for g_ in range(len(fastas)):
-                    rs = [r for r in range(world) if shard["ranges"][r][0] == g_]
-                    out[g_] = Minimizers.concat(backend.ctx, [parts[r] for r in rs], [shard["ranges"][r][2] for r in rs])
+                    out[g_] = Minimizers.concat(backend.ctx, [m_ for m_, _ in by_genome[g_]], [a for _, a in by_genome[g_]])
                 for m_ in parts:
                     m_.free()
                 return out
@@ -801,7 +900,9 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         if hasattr(g, "free"):
             g.free()
     if shard is not None:
-        shard["sub"].free()
+        for sub in shard["subs"]:
+            if not any(sub is g for g in genomes.values()):
+                sub.free()
     if bf is not None and hasattr(bf, "free"):
         bf.free()
     if own_backend:

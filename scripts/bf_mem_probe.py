@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def one():
     from ntsynt_amd.device import BloomFilter, Context, Genome, bf_size_bytes, sketch
-    ctx = Context(0)
+    ctx = Context(0, variant="experiments")        # (the environment switches this script sets exist in that build only: csrc/nts_knobs.h)
     g = Genome.synth(ctx, 3_000_000_000, 24, 20240207, 1000, 0.005)
     r = Genome.synth(ctx, 3_000_000_000, 24, 20240207, 1001, 0.005)
     _, nb = bf_size_bytes(g.total_bp, 0.025)

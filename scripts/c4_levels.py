@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--force-from", type=int, default=3, help="the forced run takes the literal level from this level on")
     ap.add_argument("--modes", default="build,auto,forced,auto again", help="which runs (comma separated; under rocprofv3: one)")
     a = ap.parse_args()
-    ctx = Context(0)
+    ctx = Context(0, variant="experiments")        # (the environment switches this script sets exist in that build only: csrc/nts_knobs.h)
     args = argparse.Namespace(family="structural", substitutions_only=False, k=24, w=1000, fpr=0.025)
     total = int(a.mbp * 1e6)
     fam = [bench.family_genome(ctx, args, total, a.contigs, j, a.divergence / 2.0) for j in range(a.genomes)]

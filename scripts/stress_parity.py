@@ -20,7 +20,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args(argv)
     from ntsynt_amd.device import BloomFilter, Context, Genome, sketch
-    ctx = Context(0)
+    ctx = Context(0, variant="experiments")        # (the environment switches this script sets exist in that build only: csrc/nts_knobs.h)
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
     n_cases = n_sketches = n_literal = n_levels = 0

@@ -27,3 +27,14 @@ def in_tmp_cwd(tmp_path):
         yield tmp_path
     finally:
         os.chdir(old)
+
+
+@pytest.fixture(scope="session")
+def ctx_x():
+    """A context on the EXPERIMENTS build of the library (ntsynt_amd/libntsynt_hip_exp.so, csrc/nts_knobs.h): the tests that pick a kernel
+    variant, force a fallback or cut a list short through an environment switch run on it; everything else runs on the product build,
+    which does not contain those switches."""
+    from ntsynt_amd.device import Context
+    c = Context(0, variant="experiments")
+    yield c
+    c.close()

@@ -117,6 +117,58 @@ def main():
                 raise
             out["rejects_empty_group"] = True
         bf.free()
+    elif case == "parts":
+        # a family's records shared out by bases across genome boundaries (pipeline.partition_plan): a rank holds a filter per genome its
+        # range touches -- two here where a range crosses a boundary, none for a rank without records; lists likewise, several per rank
+        plans = {2: [[0, 1], [1, 2]], 3: [[0], [0, 1], [1]], 4: [[0, 1], [1], [1, 2], []]}
+        slot_group = plans[world]
+        n_slots = max(1, max(len(x) for x in slot_group))
+        n_groups = 1 + max(g for row in slot_group for g in row)
+        modes = []
+        for nbytes, density in ((1000, 0.5), (123_456 + 8 * world, 0.4), (3_000_008, 0.3), (3_000_008, 0.0008)):
+            mine = [BloomFilter(ctx, nbytes, 24, world=world) for _ in range(max(1, len(slot_group[rank])))]
+            for s_, f in enumerate(mine[:len(slot_group[rank])]):
+                f.from_numpy(filter_bytes(10 * rank + s_, nbytes, density))
+            comm.allreduce_parts(mine, slot_group, n_slots, n_groups)
+            expect = np.full(nbytes, 0xFF, dtype=np.uint8)
+            for g in range(n_groups):
+                union = np.zeros(nbytes, dtype=np.uint8)
+                for r, row in enumerate(slot_group):
+                    for s_, gg in enumerate(row):
+                        if gg == g:
+                            union |= filter_bytes(10 * r + s_, nbytes, density)
+                expect &= union
+            got = mine[0].to_numpy()
+            assert got.size == nbytes and np.array_equal(got, expect), f"all-reduce over parts differs at {nbytes} bytes, density {density}"
+            assert mine[0].popcount() == int(np.unpackbits(expect).sum())
+            modes.append(bool(comm.last_sparse()))
+            for f in mine:
+                f.free()
+        out["sparse"] = modes
+        # a plan whose contributions are not a rank's first slots is refused, before anything is sent
+        bf = BloomFilter(ctx, 1000, 24, world=world)
+        try:
+            comm.allreduce_parts([bf], [[-1, 0]] + [[0, -1]] * (world - 1), 2, 1)
+            raise AssertionError("a gap in a rank's slots was accepted")
+        except Exception as exc:                  # noqa: BLE001
+            if isinstance(exc, AssertionError):
+                raise
+            out["rejects_gaps"] = True
+        bf.free()
+        # exchange 2 with several lists per rank: list numbers in family order, the slot count said by the caller
+        n_lists = sum(len(x) for x in slot_group)
+        base = sum(len(x) for x in slot_group[:rank])
+        ids = [base + i for i in range(len(slot_group[rank]))]
+        sizes = [37 * (g + 1) % 101 for g in range(n_lists)]
+        local = [Minimizers.from_numpy(ctx, *list_of(g, sizes[g])) for g in ids]
+        everything = comm.allgather_minimizers(local, ids, n_lists, n_slots)
+        for g, mx in enumerate(everything):
+            h1, rec, pos = mx.to_numpy()
+            eh, er, ep = list_of(g, sizes[g])
+            assert np.array_equal(h1, eh) and np.array_equal(rec, er) and np.array_equal(pos, ep), f"list {g} of {n_lists}"
+            mx.free()
+        for mx in local:
+            mx.free()
     elif case == "allgather":
         # n_total lists, genome g on rank g mod world: uneven shares, an empty list, a rank that holds fewer than the others
         for n_total, sizes in ((5, [1000, 0, 37, 4099, 1]), (world, [3] * world), (2 * world + 1, [11 * (g + 1) for g in range(2 * world + 1)])):

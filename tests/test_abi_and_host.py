@@ -309,6 +309,40 @@ def test_shard_plan_and_mask_renumbering():
     assert shard_masks([(0, 1, 2), (4, 3, 9)], 3, 6) == [(1, 3, 9)] and shard_masks(None, 0, 1) is None
 
 
+def test_partition_plan_balances_by_bases_across_genome_boundaries():
+    """genomes that do not deal out evenly over the GPUs: the family's records cut into `world` consecutive ranges at record
+    boundaries (records are the parallel unit of src/ntsynt_make_common_bf.cpp:128-131,145-153)"""
+    from ntsynt_amd import synth
+    from ntsynt_amd.pipeline import partition_groups, partition_plan
+    # BASELINE configs[2] as bench.py builds it: three 3 Gbp genomes of 24 contigs each, on 8 / 4 / 2 GPUs
+    rec_lens = [synth.structural_plan(24, 3_000_000_000 // 24, j, 20240207)[0] for j in range(3)]
+    total = sum(int(x.sum()) for x in rec_lens)
+    for world in (2, 4, 8):
+        parts = partition_plan(rec_lens, world)
+        bases = [sum(int(rec_lens[g][a:b].sum()) for g, a, b in ps) for ps in parts]
+        assert sum(bases) == total
+        assert max(bases) / (total / world) <= 1.05, (world, bases)        # the heaviest rank within 5 % of the mean (3 / 3 / 2 ranks per genome: 1.5)
+        seen = [(g, r) for ps in parts for g, a, b in ps for r in range(a, b)]
+        assert seen == [(g, r) for g in range(3) for r in range(24)]        # every record once, in family order
+        assert all(len({g for g, _, _ in ps}) == len(ps) for ps in parts)  # a rank's parts belong to different genomes
+        filters_of, slot_group, n_groups = partition_groups(parts, [24, 24, 24])
+        assert sorted({g for row in slot_group for g in row}) == list(range(n_groups))
+        assert [len(f) for f in filters_of] == [len(r) for r in slot_group]
+    # ragged: a genome of one record, a tiny genome swallowed whole by one rank next to parts of its neighbours, ranks without records
+    parts = partition_plan([[100, 100, 100, 100], [400], [10], [10, 10, 300, 10, 10, 60]], 3)
+    assert sum(b - a for ps in parts for _, a, b in ps) == 12
+    filters_of, slot_group, n_groups = partition_groups(parts, [4, 1, 1, 6])
+    for r, fs in enumerate(filters_of):
+        whole = [lab for lab, _ in fs if lab[0] == "whole"]
+        assert len(whole) <= 1 and all(lab == ("whole", r) for lab in whole)   # a rank's whole genomes share one filter
+    covered = sorted(i for _, idx in filters_of[0] for i in idx)
+    assert covered == list(range(len(parts[0])))
+    parts = partition_plan([[5], [7]], 5)
+    assert [len(ps) for ps in parts].count(0) == 3 and sum(len(ps) for ps in parts) == 2
+    # one rank: everything, as whole genomes
+    assert partition_plan([[1, 2], [3]], 1) == [[(0, 0, 2), (1, 0, 1)]]
+
+
 def test_bf_file_layout_round_trip_and_rejections(tmp_path):
     """The `{prefix}.common.bf` layout (header table, keys, [HeaderEnd], raw bits: src/ntsynt_make_common_bf.cpp:164 -> btllib's
     save, as recalled -- DESIGN.md 2, u1/u2): what write_bf writes, read_bf reads back bit for bit; files that are not in that

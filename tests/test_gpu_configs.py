@@ -242,8 +242,9 @@ def test_c4_one_gpu_share_of_eight_divergent_3gbp_genomes(ctx):
     common.free()
 
 
-def test_sparse_filter_summary_path_matches_oracle(ctx, monkeypatch):
+def test_sparse_filter_summary_path_matches_oracle(ctx_x, monkeypatch):
     "the summary-first dense pass (csrc: k_hash_keys_sparse) on ragged records with N runs, against the plain pass and the oracle"
+    ctx = ctx_x            # (environment switches of the experiments build: tests/conftest.py)
     from ntsynt_amd import synth
     from ntsynt_amd.device import BloomFilter, bf_size_bytes, sketch
     from tests.helpers import oracle_flat, to_device

@@ -80,8 +80,19 @@ def test_bf_allreduce_groups_between_ranks(world, tmp_path):
     for o in outs:
         assert o["sparse"] == [False, False, False, True, True] and o["rejects_empty_group"]
     os.remove(tmp_path / f"id_groups_{world}")                           # (a second communicator: a second id)
-    outs = _ranks(world, "groups", tmp_path, NTS_COMM_SPARSE="0")        # the same through the dense all-gather only
+    # the same through the dense all-gather only: a switch of the experiments build of the library (csrc/nts_knobs.h)
+    outs = _ranks(world, "groups", tmp_path, NTS_COMM_SPARSE="0", NTS_LIB_VARIANT="experiments")
     assert all(o["sparse"] == [False] * 5 for o in outs)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_bf_allreduce_parts_between_ranks(world, tmp_path):
+    """exchange 1 with a family's records shared out by bases across genome boundaries (nts_bf_allreduce_parts): a rank holds one filter
+    per genome its range touches (two where the range crosses a boundary, none when it has no record); AND over genomes of the OR over a
+    genome's parts; pieces forced small; the lists of exchange 2 likewise several per rank (nts_mx_allgather_ex)"""
+    outs = _ranks(world, "parts", tmp_path, NTS_COMM_PIECE="65536")
+    for o in outs:
+        assert o["sparse"] == [False, False, False, True] and o["rejects_gaps"]
 
 
 def test_genome_slice_and_list_concat_on_one_rank(tmp_path):
@@ -139,37 +150,57 @@ def test_bench_two_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and out["steps"] == 2
     assert out["config"]["genomes_on_rank0"] == 2 and "c4: 4 synthetic" in out["config"]["workload"]
-    assert out["config"]["exchanges"].startswith("libntsynt_hip.so (nts_bf_allreduce_and, nts_mx_allgather)")
+    assert out["config"]["exchanges"].startswith("libntsynt_hip.so (nts_bf_allreduce_and")
+    assert out["config"]["rccl_ranks"] == 2 and out["config"]["rccl_library"] == STANDIN
     assert out["bloom"]["allreduce_and_s"] > 0
     assert "e2e" not in out and "cpu_baseline" not in out          # single-GPU legs only
 
 
-def test_bench_headline_workload_on_more_gpus_than_genomes(tmp_path):
-    "bench.py --gpus 4 --workload c3 (three genomes): records sharded over the groups' ranks instead of an exit"
-    r = _torchrun(4, [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--workload", "c3", "--mbp", "8", "--contigs", "4"],
-                  {"NTS_BENCH_BACKEND": "gloo"}, tmp_path)
+def _bench_line(cmd, env, cwd):
+    r = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_and_keeps_one_workload_along_the_curve(tmp_path):
+    """`python bench.py --gpus 4 --steps 2` -- plain, no torchrun, the driver's command form -- starts four ranks itself and reports
+    n_gpus 4 with rccl_ranks 4 on the SAME workload as N = 1 (c3: three genomes, their records shared out by bases across genome
+    boundaries), config 4 as the `c4` leg of the same line at both N; a launcher whose WORLD_SIZE disagrees with --gpus is refused"""
+    small = ["--steps", "2", "--warmup", "1", "--mbp", "8", "--contigs", "4"]
+    env = _env(NTS_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"] + small, env, tmp_path)
     assert out["n_gpus"] == 4 and out["value"] > 0 and "c3: 3 synthetic" in out["config"]["workload"]
+    assert out["config"]["rccl_ranks"] == 4 and out["config"]["rccl_library"] == STANDIN and out["config"]["library"].endswith("libntsynt_hip.so")
     assert "3 genomes over 4 GPUs" in out["config"]["parallelism"] and out["bloom"]["allreduce_and_s"] > 0
-    assert out["config"]["exchanges"].startswith("libntsynt_hip.so")
-    # the same family on one rank: the same number of minimizers per step
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "c3", "--mbp", "8", "--contigs", "4",
-                          "--no-e2e", "--no-cpu-baseline", "--no-dense-leg", "--no-cold-leg", "--no-c4-leg", "--no-nruns-leg", "--no-c5-leg"],
-                         cwd=tmp_path, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600)
-    assert one.returncode == 0, one.stderr[-2000:]
-    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["config"]["balance"]["max_over_mean"] <= 1.35           # (12 records of ~2 Mbp on 4 ranks: 3 each)
+    assert out["c4"]["n_gpus"] == 4 and out["c4"]["value_Gbases_s"] > 0 and out["c4"]["allreduce_and_s"] > 0
+    # the same family on one rank: the same workload key, the same number of minimizers per step, in both the headline and the c4 leg
+    ref = _bench_line([sys.executable, os.path.join(ROOT, "bench.py")] + small +
+                      ["--no-e2e", "--no-cpu-baseline", "--no-dense-leg", "--no-cold-leg", "--no-nruns-leg", "--no-c5-leg", "--no-valley-leg"],
+                      dict(os.environ, PYTHONPATH=ROOT), tmp_path)
+    assert ref["n_gpus"] == 1 and ref["config"]["workload"].split(",")[0] == out["config"]["workload"].split(",")[0]
     assert ref["config"]["bases_per_step"] == out["config"]["bases_per_step"]
     assert out["config"]["minimizers_per_step_all_genomes"] == ref["config"]["minimizers_per_step_rank0"]
+    assert ref["c4"]["n_gpus"] == 1 and ref["c4"]["minimizers_per_step_all_genomes"] == out["c4"]["minimizers_per_step_all_genomes"]
+    assert abs(ref["c4"]["common_filter_occupancy"] - out["c4"]["common_filter_occupancy"]) < 1e-15
+    # a launcher that started another number of ranks than --gpus says: refused, no line
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "4"] + small, {"NTS_BENCH_BACKEND": "gloo"}, tmp_path)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "refusing" in r.stderr
 
 
-@pytest.mark.parametrize("world,n_genomes,contigs,extra", [(4, 3, 3, []), (5, 2, 2, []), (3, 2, 1, []), (4, 3, 2, ["--no-common", "--no-simplify-graph"])])
-def test_pipeline_with_fewer_genomes_than_ranks_matches_single_rank(world, n_genomes, contigs, extra, tmp_path):
-    """bin/ntSynt under torchrun with MORE ranks than genomes: every genome's records are shared out over the ranks of its group
-    (pipeline.shard_plan), the shards' filters are OR-ed inside the group and AND-ed across groups in one exchange
-    (nts_bf_allreduce_groups), every round's shard lists are gathered and strung together per genome (nts_mx_concat) -- byte for
-    byte what one rank writes, filter file and minimizer TSVs included.  (5 ranks on 2 genomes of 2 records: a rank with no
-    record at all; 3 ranks on 2 single-record genomes: likewise.)"""
+@pytest.mark.parametrize("world,n_genomes,contigs,extra", [(4, 3, 3, []), (5, 2, 2, []), (3, 2, 1, []), (2, 3, 3, []), (3, 5, 2, []),
+                                                           (4, 3, 2, ["--no-common", "--no-simplify-graph"])])
+def test_pipeline_with_genomes_that_do_not_deal_out_evenly_matches_single_rank(world, n_genomes, contigs, extra, tmp_path):
+    """bin/ntSynt under torchrun with a number of genomes that is no multiple of the ranks (more ranks than genomes, or three genomes
+    on two ranks, five on three): the family's records are shared out over the ranks by bases, across genome boundaries
+    (pipeline.partition_plan); a rank builds a filter per genome its range touches, OR-ed over a genome's parts and AND-ed across
+    genomes in one exchange (nts_bf_allreduce_parts); every round's part lists are gathered and strung together per genome
+    (nts_mx_concat) -- byte for byte what one rank writes, filter file and minimizer TSVs included.  (5 ranks on 2 genomes of 2 records:
+    a rank with no record at all; 3 ranks on 2 single-record genomes: likewise.)"""
     from ntsynt_amd import synth
     paths = synth.make_family(str(tmp_path), n_genomes, 1_500_000, contigs, 0.01, seed=45, micro=6, n_runs=True)
     one = tmp_path / "one"

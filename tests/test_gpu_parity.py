@@ -95,11 +95,12 @@ def test_bloom_insert_cascade_and(ctx, k):
 
 
 @pytest.mark.parametrize("nbytes", [3 << 20, 100 << 20])   # 24 final buckets (one partition level) / 800 (two levels)
-def test_bloom_binned_build_equals_atomic_and_oracle(ctx, nbytes, monkeypatch):
+def test_bloom_binned_build_equals_atomic_and_oracle(ctx_x, nbytes, monkeypatch):
     """nts_bf_insert's partitioned build (hash -> bucket passes -> LDS bitmaps) sets the same bits as one atomic OR
     per k-mer and as the oracle: random records with N runs (tiles that cross run boundaries take the direct path),
     a repeat that piles 300k copies of a handful of k-mers into a few buckets (capacity overflow -> direct atomics),
     and inserting into a filter that already holds bits."""
+    ctx = ctx_x            # (environment switches of the experiments build: tests/conftest.py)
     from ntsynt_amd.device import BloomFilter
     k = 24
     names, seqs = _family(77, lengths=[400000, 0, 30, 250000, 12000, 90001], n_frac=0.0002)
@@ -141,12 +142,13 @@ def test_bloom_binned_build_equals_atomic_and_oracle(ctx, nbytes, monkeypatch):
 
 
 @pytest.mark.parametrize("nbytes", [3 << 20, 100 << 20])   # 24 final buckets (one partition level) / 800 (two levels)
-def test_bloom_fused_and_equals_insert_then_and_and_the_oracle_cascade(ctx, nbytes, monkeypatch):
+def test_bloom_fused_and_equals_insert_then_and_and_the_oracle_cascade(ctx_x, nbytes, monkeypatch):
     """nts_bf_insert_and (the cascade level of cpp:134-160 as acc &= G inside the partitioned build's last pass) against insert
     into a second filter + nts_bf_and, against the literal cascade kernel and against the oracle's cascade -- on records whose
     repeats overflow their buckets (the copies of a k-mer park ONE index and the bit comes back after the AND), with tiles in
     pieces, with the parking list cut short (the device gives up, restores the running filter, the level is redone the plain
     way), on a running filter so sparse that slices are skipped, and on all-ones / all-zero running filters."""
+    ctx = ctx_x            # (environment switches of the experiments build: tests/conftest.py)
     from ntsynt_amd.device import BloomFilter
     k = 24
     rng = np.random.default_rng(2024)
@@ -218,13 +220,14 @@ def _diverged(rng, seqs, d):
 
 
 @pytest.mark.parametrize("variant", ["auto", "LDS-staged accept kernel", "summary only", "forced from level 1", "k=40", "repeats"])
-def test_bloom_sparse_level_equals_the_build_and_the_oracle_cascade(ctx, variant, monkeypatch):
+def test_bloom_sparse_level_equals_the_build_and_the_oracle_cascade(ctx_x, variant, monkeypatch):
     """A cascade level over a running filter that is all but empty goes the reference's literal way (cpp:134-160: every k-mer of
     the genome looked up, the bits that were hit kept -- bf_level_sparse) instead of through a whole partitioned build: same bits as
     the build with the AND in its last pass, as the oracle's cascade, same popcount, through each of the three accept kernels, from
     the first level on when forced, with k > 32, and with repeats whose copies overflow the accept lists (the level then falls
     back to the build, the running filter untouched).  The summary and folded tables the level leaves behind are the ones the
     sketch uses next: minimizers with the final filter == oracle."""
+    ctx = ctx_x            # (environment switches of the experiments build: tests/conftest.py)
     from ntsynt_amd.device import BloomFilter, sketch
     k = 40 if variant == "k=40" else 24
     w = 50
@@ -598,12 +601,13 @@ def test_long_and_degenerate_k_end_to_end(ctx, k):
 
 @pytest.mark.parametrize("tpw", ["1", "3"])
 @pytest.mark.parametrize("k,w,c", [(24, 1000, 16), (20, 700, 12), (32, 400, 6), (24, 250, 9), (31, 1000, 40), (33, 1000, 16)])
-def test_select_kernels_agree(ctx, monkeypatch, k, w, c, tpw):
+def test_select_kernels_agree(ctx_x, monkeypatch, k, w, c, tpw):
     """The two candidate-selection kernels of the pruned sketch (k_hash_select_hi: upper halves rolled, listed k-mers hashed in
     full, probes overlapped with the next tile; k_hash_select: full-width rolling) and the dense path give the oracle's list:
     fragmented records with N runs (tiles that span runs), a satellite repeat (tiles that list more k-mers than a round
     holds), records shorter than k, with and without a filter, one and several tiles per wave (NTS_HI_TPW), both list
     widths (c/w below and above 1/42), k on either side of the kernel's limit (k = 33: full-width kernel in both settings)."""
+    ctx = ctx_x            # (environment switches of the experiments build: tests/conftest.py)
     from ntsynt_amd.device import BloomFilter, sketch
     monkeypatch.setenv("NTS_HI_TPW", tpw)
     rng = np.random.default_rng(1234 + k)

@@ -61,9 +61,10 @@ def test_rejects_a_plan_that_does_not_tile(ctx):
 
 
 @pytest.mark.parametrize("erode_on_host", [False, True])
-def test_pipeline_on_a_structural_family_matches_the_oracle(ctx, tmp_path, monkeypatch, erode_on_host):
+def test_pipeline_on_a_structural_family_matches_the_oracle(ctx_x, tmp_path, monkeypatch, erode_on_host):
     """three genomes with inversions, translocations, indels and soft-masked stretches, written to FASTA from HBM like
     bench.py's e2e leg does; both synteny TSVs byte-identical to the oracle pipeline's, and the rules have fired"""
+    ctx = ctx_x            # (environment switches of the experiments build: tests/conftest.py)
     import bench
     from ntsynt_amd import pipeline
     from ntsynt_amd.device import Genome
