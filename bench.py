@@ -576,6 +576,7 @@ class Rig:
             self.genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in self.mine]
             per_rank = [sum(self.fam_bases[g] for g in range(n_fam) if g % world == r) for r in range(world)]
             self.balance = {"bases_per_rank": per_rank, "max_over_mean": round(max(per_rank) / (sum(per_rank) / world), 4)}
+        ctx.sync()                                   # (the generators are kernels: what follows must not be charged for them)
         self.t_synth = time.time() - t0
         self.bases = sum(g.total_bp for g in self.genomes)
         batch = name == "c2" and not args.no_batch and len(self.genomes) > 1 and world == 1

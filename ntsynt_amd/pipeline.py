@@ -707,9 +707,14 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     # (ntsynt_amd/synteny.py, the class the device engine derives from) for a whole run -- an argument of this function that the
     # lockstep tests and the CPU test doubles use, not a switch a user of the command line has.
     device_engine = isinstance(backend, GpuBackend) and engine != "host"
+    if not device_engine and (mx_tsvs is not None or initial_only):
+        raise ValueError("minimizer TSVs as input (stage 3 on its own) and initial_only are served by the device engine only")
     if rep_bf is not None and not device_engine:
         raise ValueError("the repeat filter is served by the device engine only")
     tsv_names = [f"{fa.basename(p)}.k{k}.w{w}.tsv" for p in fastas]
+    # stage 3 on given minimizer files: the engine orders the assemblies -- and names them in the output -- by the paths the caller
+    # passed, as the reference does (sorted(self.args.FILES, reverse=True), bin/ntsynt_synteny.py:34; synteny_block.py:14,76-77)
+    engine_files = list(mx_tsvs) if mx_tsvs is not None else tsv_names
     if rank != 0:                       # replicas compute, only rank 0 leaves files behind
         scratch = os.path.join(os.getcwd(), f".ntsynt_rank{rank}")
         os.makedirs(scratch, exist_ok=True)
@@ -807,7 +812,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         st.stop()
         st.mark("sketches_done")
         st.start("ntsynt_synteny")
-        eng = DeviceSyntenyEngine(backend.ctx, tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size,
+        eng = DeviceSyntenyEngine(backend.ctx, engine_files, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size,
                                   out_prefix, sketch_dev_round, simplify=simplify, log=log, dev=dev, interarrivals=interarrivals, m=m, n=n)
         if initial_only:
             eng.initial_only = True
@@ -855,7 +860,8 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         sketch_fn.all_at_once = sketch_round
 
         eng = SyntenyEngine(tsv_names, [meta[p][0] for p in fastas], k, w, w_rounds, indel, merge, block_size, out_prefix,
-                            backend.graph, sketch_fn, backend.walk, simplify=simplify, log=log, degree_fn=edge_degrees, dev=dev, interarrivals=interarrivals)
+                            backend.graph, sketch_fn, backend.walk, simplify=simplify, log=log, degree_fn=edge_degrees, dev=dev, interarrivals=interarrivals,
+                            m=m, n=n)
         first = initial
     try:
         eng.run(first)

@@ -58,18 +58,19 @@ def make_common_bf(argv=None):
         nbytes = {"up": (approx + 7) // 8 * 8, "down": approx // 8 * 8, "none": approx}[args.bf_rounding]      # btllib's constructor (u1)
     else:
         print("Calculating BF size based on input genome size")
+        print(f"Genome size (bp): {first.total_bp}")              # approximate_bf_size, src/ntsynt_make_common_bf.cpp:37
         approx, nbytes = bf_size_bytes(first.total_bp, args.fpr, args.bf_rounding)
     print(f"BF size (bytes): {approx}", flush=True)
     bf = BloomFilter(ctx, nbytes, args.k)
     bf.insert(first)
     first.free()
-    print(f"Bloom filter FPR: {bf.get_fpr()}", flush=True)
+    print(f"Bloom filter FPR: {bf.get_fpr():g}", flush=True)       # (a double through operator<<: six significant digits)
     for f in files[1:]:
         g, _ = fa.read_fasta_device(ctx, f)
         bf.insert_and(g)                                       # one cascade level (cpp:134-160)
         g.free()
-        print(f"Bloom filter FPR: {bf.get_fpr()}", flush=True)
-    print(f"Final Bloom filter FPR: {bf.get_fpr()}", flush=True)
+        print(f"Bloom filter FPR: {bf.get_fpr():g}", flush=True)       # (a double through operator<<: six significant digits)
+    print(f"Final Bloom filter FPR: {bf.get_fpr():g}", flush=True)
     bf.save(f"{args.p}.bf", pipeline.bf_header(nbytes, args.k, signature=args.bf_signature or pipeline.BF_SIGNATURE))
     bf.free()
     ctx.close()

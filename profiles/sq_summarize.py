@@ -17,7 +17,7 @@ import re
 import sys
 
 KEEP = ["k_hash_select", "k_hash_select_hi", "k_sparse_win", "k_cand_compact", "k_cand_compact_slots", "k_bin1", "k_bin2", "k_bin3", "k_hash<0>", "k_window_min",
-        "k_hash_accept4r", "k_hash_accept4", "k_hash_accept"]
+        "k_hash_accept4r", "k_hash_accept4", "k_hash_accept", "k_hash_tiers"]
 import os
 
 # k-mers per launch: NTS_PROF_KMERS for the bench command's genomes (round 2: 3 Gbp genomes, one launch sequence each);
