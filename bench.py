@@ -1217,8 +1217,7 @@ def bloom_roofline(total_bp, insert_ms):
     out = {"bound": "hbm", "formulation_bytes_per_kmer": 19.0, "achieved": round(alg / (insert_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(alg / (insert_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
            "limiter": "k_bin1 (half of the build's time) is co-limited by VALU issue and the LDS pipe, k_bin2 / k_bin3 stream at 4.4-5.5 TB/s (DESIGN.md 4.3)"}
-    for rnd in (5, 4):
-        path = os.path.join(ROOT, "profiles", f"r0{rnd}_pmc_traffic.json")
+    for path in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_bloom_pmc_traffic.json", "r04_pmc_traffic.json")):
         try:
             kern = json.load(open(path))["kernels"]
             tot = 0

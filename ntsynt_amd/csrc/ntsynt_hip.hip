@@ -3957,8 +3957,13 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     // Measured at 3 x 3 Gbp, w = 1000, p = 0.70, with k_hash_select_hi and the uncovered ranges probed only where a window
     // reads them: c = 12 / 13 / 14 / 15 / 16 -> 1021 / 1085 / 1124 / 1134 / 1124 Gbases/s; with k_hash_select, whose rolling
     // cost twice as much per k-mer, and whole key tiles probed around every range, the optimum was c = 18, cp = 12.)
-    const double cp = 11.0; // (round 3, with the select kernel dropping hopeless candidates and a family with insertions: c = 13 .. 17 ->
-                            //  1280 / 1397 / 1420 / 1476 / 1413 Gbases/s; c = 16 at p = 0.70)
+    // (round 3, with the select kernel dropping hopeless candidates and a family with insertions: c = 13 .. 17 ->
+    //  1280 / 1397 / 1420 / 1476 / 1413 Gbases/s; c = 16 at p = 0.70.  Round 5, same family: c = 12 .. 17 -> 1118 / 1250 / 1432 / 1468 /
+    //  1522 / 1516.)  An assembly in thousands of pieces (more than one run of valid bases per 2^20 k-mers) has its uncovered
+    //  ranges whatever c is -- scaffold ends, gaps, repeats -- and a listing cost that rises faster with c (tiles that list more than
+    //  their slots hold): the assembly-like family at 3 x 3 Gbp, p = 0.55: c = 14 / 16 / 18 / 21 -> 986 / 1134 / 1121 / 1070 Gbases/s.
+    const bool in_pieces = (uint64_t)T->n_runs > (rt.n_valid >> 20) + 64;
+    const double cp = in_pieces ? 9.5 : 11.0;
     const double want = std::max(8.0, std::ceil(cp / std::max(p, 1e-4)));
     // (measured: at a quarter of the k-mers as candidates the pruned pass is still twice as fast as the dense one;
     // at 40 % single lanes run out of slots in most tiles and it is half as fast)

@@ -31,7 +31,7 @@ def short(n):
     m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", n)
     if not m or "rocprim" in n:
         return None
-    return m.group(1) if m.group(1) in ("k_hash_select", "k_hash_select_hi", "k_hash_accept4r") else m.group(0)   # (template variants: one row)
+    return m.group(1) if m.group(1) in ("k_hash_select", "k_hash_select_hi", "k_hash_accept4r", "k_bin1") else m.group(0)   # (template variants: one row)
 
 
 def main():
