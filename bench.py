@@ -583,6 +583,7 @@ class Rig:
         self.units = [Genome.concat(ctx, self.genomes)] if batch else self.genomes
         self.common = None
         self.n_all = None
+        self.t_sketch = 0.0                          # seconds spent in the sketch calls of step() (reset by the caller around a timed region)
 
     def build_filter(self, again=False, levels=False):
         "per-genome filters, local cascade, exchange 1; returns the timings"
@@ -645,6 +646,7 @@ class Rig:
         from ntsynt_amd.device import Minimizers, sketch
         ctx, comm, world, k, w = self.ctx, self.comm, self.world, self.args.k, self.args.w
         held, n = [], 0
+        t0 = time.time()
         if pool is not None:
             held = pool.sketch(self.units, k, w, self.common)
             n = sum(len(mx) for mx in held)
@@ -653,6 +655,7 @@ class Rig:
                 mx = sketch(ctx, g, k, w, self.common)
                 n += len(mx)
                 held.append(mx)
+        self.t_sketch += time.time() - t0                           # (a sketch call returns when its list's length is known: the kernels are through)
         if world > 1:                                               # exchange 2: every rank receives every list
             if self.plan is not None:
                 parts = comm.allgather_minimizers(held, self.mine, self.n_parts, self.list_slots)
@@ -908,7 +911,15 @@ def main():
             el = float(t.item())
         return el, n_mx
 
-    dt, n_mx = timed(args.warmup, args.steps)
+    for _ in range(args.warmup):
+        step()
+    rig.t_sketch = 0.0
+    dt, n_mx = timed(0, args.steps)
+    t_sk = rig.t_sketch
+    if world > 1:                                                   # the slowest rank's sketch time
+        tt = torch.tensor([t_sk], dtype=torch.float64, device=pg_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_sk = float(tt.item())
     tm = {n: timing_of(n) for n in SKETCH_KERNELS}
     # the other kernels of the call: one more pass, untimed, with every kernel group bracketed by events
     all_ctx(lambda c: c.profile(1))
@@ -1090,6 +1101,10 @@ def main():
                                         f"(rank 0: {', '.join(f'records {a}..{b} of genome {g}' for g, a, b in rig.parts) or 'none'})") if shard is not None else
                                        f"genomes dealt out whole over {world} GPU(s)") + (f"; the {n_at_once} genomes of a GPU sketched at once, a stream each" if n_at_once > 1 else ""),
                        "balance": rig.balance,
+                       # `value` times the whole step (sketch + exchange 2: the all-gather of the lists the replicated graph stage reads); the
+                       # sketch calls alone, slowest rank:
+                       "sketch_only_Gbases_s": round(sum(fam_bases) * args.steps / t_sk / 1e9, 3) if t_sk > 0 else None,
+                       "exchange2_share_of_step": round(max(0.0, 1.0 - t_sk / dt), 4) if world > 1 else 0.0,
                        # did RCCL see N ranks, and which library served the exchanges
                        "rccl_ranks": rccl_ranks, "rccl_library": served_by, "library": ctx.lib._name,
                        "scaling_base": "c3 (BASELINE configs[2], the metric's configuration) is `value` at every N; c4 (configs[3]) is the `c4` leg of the same line at every N",

@@ -23,7 +23,7 @@ def main(argv=None):
     ctx = Context(0, variant="experiments")        # (the environment switches this script sets exist in that build only: csrc/nts_knobs.h)
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
-    n_cases = n_sketches = n_literal = n_levels = 0
+    n_cases = n_sketches = n_literal = n_levels = n_tiered = 0
     while time.time() < t_end:
         k = int(rng.choice([16, 20, 24, 31, 32, 40, 64, 100]))
         style = rng.choice(["few", "many", "tiny", "mixed"])
@@ -94,8 +94,14 @@ def main(argv=None):
             ctx.sketch_mode(mode, c)
             ctx.sketch_select(str(rng.choice(["auto", "hi", "hi", "full"])))      # both candidate-selection kernels
             os.environ["NTS_HI_TPW"] = str(int(rng.choice([1, 2, 5])))            # one and several tiles per wave
+            # (round 5) the tiered selection: by the library's own choice, forced wherever it applies, or forbidden; any schedule
+            ctx.sketch_tiers(str(rng.choice(["auto", "auto", "always", "always", "never"])), x0=float(rng.choice([0.0, 0.0, 0.3, 1.0, 2.4, 6.0])),
+                             half_steps=bool(rng.random() < 0.3))
             exp = [oracle_flat(O.minimize(o, k, w, want if use_bf else None)) for o in (og, og2)]
-            got = [sketch(ctx, d, k, w, bf if use_bf else None).to_numpy() for d in (dg, dg2)]
+            got = []
+            for d in (dg, dg2):
+                got.append(sketch(ctx, d, k, w, bf if use_bf else None).to_numpy())
+                n_tiered += ctx.sketch_tiers()[2] > 0
             bmx = sketch(ctx, batch, k, w, bf if use_bf else None)
             parts = batch.split_minimizers(*bmx.to_numpy())
             dev_parts = bmx.split(batch.rec_base)                  # the same split on the device
@@ -114,6 +120,7 @@ def main(argv=None):
                         sys.exit(1)
         ctx.sketch_mode("auto", 0)
         ctx.sketch_select("auto")
+        ctx.sketch_tiers("auto")
         # (round 4) a cascade of several relatives: once the running filter is all but empty the level goes the literal way
         # (bf_level_sparse) -- by the library's own choice, or forced at any occupancy, through each of the accept kernels; every
         # level against the oracle's cascade, and a sketch with the tables the last level left behind
@@ -202,7 +209,7 @@ def main(argv=None):
         dg2.free()
         n_cases += 1
     print(f"ok: {n_cases} genomes pairs, {n_sketches} sketches, {2 * n_cases} filter builds x 2 modes, {n_levels} further cascade levels "
-          f"({n_literal} of them the literal way), seed {args.seed}")
+          f"({n_literal} of them the literal way), {n_tiered} sketches through the tiered selection, seed {args.seed}")
 
 
 if __name__ == "__main__":
