@@ -205,6 +205,7 @@ struct nts_ctx
   int comm_sparse_mode = 0;       // 1: never gather set-bit indices (experiments build: NTS_COMM_SPARSE=0)
   uint64_t comm_sparse_below = 0; // gather indices when the fullest chunk holds at most this many bits (0: chunk bytes / 128)
   unsigned io_threads = 8;        // host threads of a FASTA upload (NTS_IO_THREADS at nts_init)
+  int gap_tiers_off = 0;          // 1: the uncovered ranges of the one-threshold selection go to the dense kernels (nts_sketch_tiers mode 1)
   int tier_mode = 0;
   double tier_x0 = 0;       // accepted k-mers per window the first tier aims at (0: the default)
   uint32_t tier_half = 0;   // 1: tiers in steps of 1.5 / 1.33 instead of 2
@@ -3423,6 +3424,165 @@ struct TierPlan
   double c0 = 0;
 };
 
+__global__ void k_gap_tiers_ctl(const uint64_t* __restrict__ blk_scan_last, const uint64_t* __restrict__ blk_cnt_last, uint64_t n_sparse,
+                                const unsigned long long* __restrict__ overflow, uint64_t* __restrict__ ctl)
+{
+  const uint64_t n = *blk_scan_last + *blk_cnt_last;
+  const bool bad = *overflow != 0ULL;
+  ctl[0] = bad ? 0 : n;
+  ctl[1] = n_sparse + (bad ? 0 : n);
+  ctl[2] = bad ? 1 : 0;
+}
+
+// The uncovered ranges of the one-threshold selection through the tiered selection (nts_tiers.inc, gap mode) instead of a probe of
+// every k-mer in them: the ranges as tiles (position 0 = the range's first index, both ends closed; ranges longer than a tile cut into
+// tiles with halos), the thresholds going on from tau; the accepted k-mers found, in index order, are put to the window decision with
+// the ranges as records (k_sparse_win: a window lies inside its range), and the winners come back as the second list k_finalize
+// merges into the first -- what run_dense_sorted's few-ranges path hands back, in its format (ctl[0] winners, ctl[1] total, ctl[2] gave up).
+// Returns NTS_OK with res.d_ctl == nullptr when the path does not apply (the caller goes the dense way).
+int run_gap_tiers(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter, uint64_t tau, uint32_t prune_c,
+                  const std::vector<uint64_t>& pv, const std::vector<uint64_t>& pn, uint64_t covered, const SortedOut& sparse, SortedOut& res)
+{
+  res = SortedOut();
+  if (!filter || k > FAST_K_MAX || w < 64 || w > 4097 || pv.empty() || ctx->gap_tiers_off) return NTS_OK;
+  const uint32_t halo = ((w - 1 + 63) / 64) * 64, core = TR_EXT - 2 * halo;
+  std::vector<TierTile> tiles;
+  for (size_t i = 0; i < pv.size(); ++i) {
+    const uint64_t a = pv[i], n = pn[i];
+    if (n <= TR_EXT) {
+      TierTile t = {};
+      t.e0 = (int64_t)a;
+      t.n = (uint32_t)n;
+      t.c0 = 0;
+      t.c1 = (uint32_t)n;
+      t.flags = 3;
+      tiles.push_back(t);
+      continue;
+    }
+    for (uint64_t c_lo = 0; c_lo < n; c_lo += core) {
+      const uint64_t e_lo = c_lo >= halo ? c_lo - halo : 0, e_hi = std::min<uint64_t>(n, c_lo + core + halo); // [e_lo, e_hi) inside the range
+      TierTile t = {};
+      t.e0 = (int64_t)(a + e_lo);
+      t.n = (uint32_t)(e_hi - e_lo);
+      t.c0 = (uint32_t)(c_lo - e_lo);
+      t.c1 = (uint32_t)(std::min<uint64_t>(n, c_lo + core) - e_lo);
+      t.flags = (e_lo == 0 ? 1u : 0u) | (e_hi == n ? 2u : 0u);
+      tiles.push_back(t);
+    }
+  }
+  const uint64_t n_gt = tiles.size();
+  if (n_gt > (1u << 20)) return NTS_OK;
+#define GT_WS(ptr, type, name, bytes)                                                               \
+  type ptr = (type)ws_get(ctx, name, bytes);                                                        \
+  if (!ptr) return NTS_ENOMEM
+  void* dev[3];
+  if (int rc = upload_packed(ctx, "gt_tables", { { tiles.data(), tiles.size() * sizeof(TierTile) }, { pv.data(), pv.size() * 8 }, { pn.data(), pn.size() * 8 } }, dev))
+    return rc;
+  const TierTile* d_tiles = (const TierTile*)dev[0];
+  const uint64_t *d_vs = (const uint64_t*)dev[1], *d_nv = (const uint64_t*)dev[2];
+  GT_WS(d_dir, uint32_t*, "gt_dir", n_gt * 12);
+  GT_WS(d_toff, uint64_t*, "gt_tile_off", n_gt * 8);
+  GT_WS(d_tcnt, uint32_t*, "gt_tile_cnt", n_gt * 4 + 8);
+  GT_WS(d_tord, uint8_t*, "gt_tile_ord", n_gt);
+  GT_WS(d_tscan, uint64_t*, "gt_tile_scan", n_gt * 8);
+  GT_WS(d_ctl, unsigned long long*, "gt_ctl", (N_SEG + 4) * 8); // [0..63] segment counters, [64] ranges (unused), [65] overflow, [66..67] tier statistics
+  // the accepted k-mers of the ranges: a few per window at most where the filter accepts anything at all (the ranges are what the
+  // other genomes do not share); a list that does not fit raises the flag and the call is repeated the dense way
+  const uint64_t seg_cap = (uint64_t)((double)covered * 0.05 / N_SEG) + 2048;
+  const uint64_t m_max = seg_cap * N_SEG, n_blk = (m_max + SPARSE_BLOCK - 1) / SPARSE_BLOCK;
+  GT_WS(d_sj, uint64_t*, "gt_seg_j", m_max * 8);
+  GT_WS(d_sk, uint64_t*, "gt_seg_key", m_max * 8);
+  GT_WS(d_pj, uint64_t*, "gt_cand_j", m_max * 8);
+  GT_WS(d_pk, uint64_t*, "gt_cand_key", m_max * 8);
+  GT_WS(d_stj, uint64_t*, "gt_stage_j", n_blk * SPARSE_BLOCK * 8);
+  GT_WS(d_stk, uint64_t*, "gt_stage_k", n_blk * SPARSE_BLOCK * 8);
+  GT_WS(d_bcnt, uint64_t*, "gt_blk_cnt", n_blk * 8);
+  GT_WS(d_bscan, uint64_t*, "gt_blk_scan", n_blk * 8);
+  GT_WS(d_gj, uint64_t*, "gt_win_j", n_blk * SPARSE_BLOCK * 8);
+  GT_WS(d_gk, uint64_t*, "gt_win_key", n_blk * SPARSE_BLOCK * 8);
+  GT_WS(d_gctl, uint64_t*, "gap_ctl", 4 * 8);
+  HIP_TRY(ctx, hipMemsetAsync(d_ctl, 0, (N_SEG + 4) * 8, ctx->stream));
+  TierParams Q;
+  Q.code = g->d_code + PAD;
+  Q.pack = g->d_pack;
+  Q.run_pos = T.d_run_pos;
+  Q.run_vstart = T.d_run_vstart;
+  Q.n_runs = T.n_runs;
+  Q.n_valid = T.rt.n_valid;
+  Q.rec_vstart = T.d_rec_vstart;
+  Q.n_rec = g->n_rec;
+  Q.tiles = d_tiles;
+  Q.excl_on = 1;
+  Q.excl_hi = (uint32_t)(tau >> 32);
+  Q.dir = d_dir;
+  if (int rc_hp = hash_params_for(ctx, k, &Q.hp)) return rc_hp;
+  Q.bf = filter->d_words;
+  Q.fm = make_fastmod(filter->bytes * 8);
+  Q.w = w;
+  Q.halo = halo;
+  Q.core = core;
+  // tiers going on from tau: (tau, 2 tau], (2 tau, 4 tau], ... while the threshold stays below ~3/4 of all hashes; the last takes the rest
+  Q.scale = (float)(1.0 / ((double)(tau >> 32) + 1.0));
+  Q.exp_shift = 23;
+  Q.exp_bias = 127;
+  uint32_t n_exp = 1;
+  while (n_exp < TR_TIERS_MAX - 1 && (double)prune_c * (double)(2u << n_exp) <= 0.75 * (double)w) ++n_exp;
+  Q.n_tiers = n_exp + 1;
+  Q.seg_j = d_sj;
+  Q.seg_key = d_sk;
+  Q.seg_cap = seg_cap;
+  Q.seg_count = d_ctl;
+  Q.tile_off = d_toff;
+  Q.tile_cnt = d_tcnt;
+  Q.tile_ordered = d_tord;
+  Q.stats = d_ctl + N_SEG + 2;
+  {
+    ScopedTimer t(ctx, "hash_probe"); // (the group the dense pass over the ranges is timed under)
+    hipLaunchKernelGGL(k_tier_dir, dim3((uint32_t)((n_gt + 255) / 256)), dim3(256), 0, ctx->stream, T.d_run_vstart, T.n_runs, T.d_rec_vstart, g->n_rec,
+                       T.rt.n_valid, halo, core, n_gt, d_tiles, d_dir);
+    hipLaunchKernelGGL(k_hash_tiers, dim3((uint32_t)n_gt), dim3(TR_THREADS), 0, ctx->stream, Q);
+  }
+  {
+    ScopedTimer t(ctx, "window_min");
+    if (int rc_s = scan_counts<uint32_t>(ctx, d_tcnt, n_gt, d_tscan)) return rc_s;
+    hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)((n_gt + CC_TILES - 1) / CC_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, seg_cap, d_toff, d_tcnt, d_tord,
+                       d_tscan, n_gt, d_pj, d_pk, m_max, d_ctl + N_SEG + 1, false);
+    SparseParams S;
+    S.pj = d_pj;
+    S.pk = d_pk;
+    S.m_scan_last = d_tscan + (n_gt - 1);
+    S.m_cnt_last = d_tcnt + (n_gt - 1);
+    S.m_max = m_max;
+    S.rec_vstart = d_vs;
+    S.rec_nv = d_nv;
+    S.n_valid = T.rt.n_valid;
+    S.n_rec = (uint32_t)pv.size();
+    S.w = w;
+    S.stage_j = d_stj;
+    S.stage_k = d_stk;
+    S.blk_cnt = d_bcnt;
+    S.gap_lo = S.gap_hi = nullptr;
+    S.gap_count = d_ctl + N_SEG;
+    S.gap_cap = 0;
+    S.overflow = d_ctl + N_SEG + 1;
+    S.rec_holes = 1;
+    hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, S);
+    if (int rc_s = scan_counts<uint64_t>(ctx, d_bcnt, n_blk, d_bscan)) return rc_s;
+    hipLaunchKernelGGL(k_gather_winners, dim3((uint32_t)n_blk), dim3(256), 0, ctx->stream, d_stj, d_stk, d_bcnt, d_bscan, d_gj, d_gk);
+    hipLaunchKernelGGL(k_gap_tiers_ctl, dim3(1), dim3(1), 0, ctx->stream, d_bscan + (n_blk - 1), d_bcnt + (n_blk - 1), sparse.count, d_ctl + N_SEG + 1, d_gctl);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  res.d_j = sparse.d_j;
+  res.d_key = sparse.d_key;
+  res.na = sparse.count;
+  res.b_j = d_gj;
+  res.b_key = d_gk;
+  res.count = sparse.count + std::min<uint64_t>(m_max, covered); // (an upper bound: the real number comes with the call's last mail)
+  res.d_ctl = d_gctl;
+  return NTS_OK;
+#undef GT_WS
+}
+
 int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_t k, uint32_t w, const nts_bf* filter, uint32_t prune_c,
                double p_accept, SortedOut& res, bool accept_all = false, const TierPlan* tp = nullptr)
 {
@@ -3547,9 +3707,11 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       Q.tile_cnt = d_tcnt;
       Q.tile_ordered = d_tord;
       Q.stats = d_tstats;
+      Q.tiles = nullptr;
+      Q.excl_on = Q.excl_hi = 0;
       ScopedTimer t(ctx, "hash_tiers", true);
       hipLaunchKernelGGL(k_tier_dir, dim3((uint32_t)((n_kt + 255) / 256)), dim3(256), 0, ctx->stream, T.d_run_vstart, T.n_runs, T.d_rec_vstart, g->n_rec, V,
-                         tp->halo, tp->core, n_kt, d_dir);
+                         tp->halo, tp->core, n_kt, (const TierTile*)nullptr, d_dir);
       hipLaunchKernelGGL(k_hash_tiers, dim3((uint32_t)n_kt), dim3(TR_THREADS), 0, ctx->stream, Q);
     } else if (accept_all) {
       AcceptParams A;
@@ -3745,6 +3907,14 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   sparse_list.d_j = d_sj;
   sparse_list.d_key = d_sk;
   sparse_list.count = n_sparse;
+  if (ctx->small_gap_path) { // the ranges through the tiered selection; not applicable, or a retry after it gave up: the dense kernels
+    int rc_g = run_gap_tiers(ctx, g, T, k, w, filter, tau, prune_c, pv, pn, covered, sparse_list, dense);
+    if (rc_g) return rc_g;
+    if (dense.d_ctl) {
+      res = dense;
+      return NTS_OK;
+    }
+  }
   int rc = run_dense_sorted(ctx, g, T, k, w, filter, &pv, &pn, &tiles, covered, "gap_", dense, &sparse_list, &spans);
   if (rc) return rc;
   if (dense.d_ctl) { // merged on the device: the caller reads the count after its own synchronisation
@@ -3825,6 +3995,7 @@ extern "C" int nts_sketch_tiers(nts_ctx* ctx, int mode, double x0, int half_step
     return fail(ctx, NTS_EINVAL, "nts_sketch_tiers: mode is -1 (query), 0 (auto), 1 (never) or 2 (wherever the kernel applies); 0 <= x0 <= 64");
   if (mode >= 0) {
     ctx->tier_mode = mode;
+    ctx->gap_tiers_off = mode == 1 ? 1 : 0;
     ctx->tier_x0 = x0;
     ctx->tier_half = half_steps ? 1u : 0u;
   }
@@ -3961,9 +4132,10 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     //  1280 / 1397 / 1420 / 1476 / 1413 Gbases/s; c = 16 at p = 0.70.  Round 5, same family: c = 12 .. 17 -> 1118 / 1250 / 1432 / 1468 /
     //  1522 / 1516.)  An assembly in thousands of pieces (more than one run of valid bases per 2^20 k-mers) has its uncovered
     //  ranges whatever c is -- scaffold ends, gaps, repeats -- and a listing cost that rises faster with c (tiles that list more than
-    //  their slots hold): the assembly-like family at 3 x 3 Gbp, p = 0.55: c = 14 / 16 / 18 / 21 -> 986 / 1134 / 1121 / 1070 Gbases/s.
+    //  their slots hold): the assembly-like family at 3 x 3 Gbp, p = 0.55: c = 14 / 16 / 18 / 21 -> 986 / 1134 / 1121 / 1070 Gbases/s; with the uncovered
+    //  ranges through the tiered selection (run_gap_tiers): c = 12 / 14 / 16 / 18 -> 933 / 1193 / 1291 / 1250.
     const bool in_pieces = (uint64_t)T->n_runs > (rt.n_valid >> 20) + 64;
-    const double cp = in_pieces ? 9.5 : 11.0;
+    const double cp = in_pieces ? 8.7 : 11.0;
     const double want = std::max(8.0, std::ceil(cp / std::max(p, 1e-4)));
     // (measured: at a quarter of the k-mers as candidates the pruned pass is still twice as fast as the dense one;
     // at 40 % single lanes run out of slots in most tiles and it is half as fast)
