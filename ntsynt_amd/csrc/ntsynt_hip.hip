@@ -4286,7 +4286,7 @@ void nts_mx_free(nts_ctx* ctx, nts_mx* mx)
   if (!mx) return;
   if (ctx) hipSetDevice(ctx->device);
   if (mx->d_h1) { // h1 | pos | rec share one allocation
-    if (ctx && ctx->mx_pool.size() < 8 && mx->cap_bytes)
+    if (ctx && ctx->mx_pool.size() < 32 && mx->cap_bytes)
       ctx->mx_pool.push_back({ mx->d_h1, mx->cap_bytes });
     else
       dev_free(mx->d_h1);

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof
 mkdir -p $O
-LEGS="--no-cpu-baseline --no-e2e --no-c4-leg --no-cold-leg --no-nruns-leg --no-c5-leg"
+LEGS="--no-cpu-baseline --no-e2e --no-c4-leg --no-cold-leg --no-nruns-leg --no-c5-leg --no-valley-leg"
 B1="python bench.py --steps 1 --warmup 0 $LEGS --no-dense-leg"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --steps 5 --warmup 2 $LEGS > $O/stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 1 --warmup 0 $LEGS > $O/pf.log 2>&1
