@@ -3424,6 +3424,17 @@ struct TierPlan
   double c0 = 0;
 };
 
+void launch_tiers(nts_ctx* ctx, const TierParams& Q, uint64_t n_tiles)
+{
+  const dim3 grid((uint32_t)n_tiles), block(TR_THREADS);
+  if (Q.fm.form == 2)
+    hipLaunchKernelGGL(k_hash_tiers<2>, grid, block, 0, ctx->stream, Q);
+  else if (Q.fm.form == 1)
+    hipLaunchKernelGGL(k_hash_tiers<1>, grid, block, 0, ctx->stream, Q);
+  else
+    hipLaunchKernelGGL(k_hash_tiers<0>, grid, block, 0, ctx->stream, Q);
+}
+
 __global__ void k_gap_tiers_ctl(const uint64_t* __restrict__ blk_scan_last, const uint64_t* __restrict__ blk_cnt_last, uint64_t n_sparse,
                                 const unsigned long long* __restrict__ overflow, uint64_t* __restrict__ ctl)
 {
@@ -3540,7 +3551,7 @@ int run_gap_tiers(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint
     ScopedTimer t(ctx, "hash_probe"); // (the group the dense pass over the ranges is timed under)
     hipLaunchKernelGGL(k_tier_dir, dim3((uint32_t)((n_gt + 255) / 256)), dim3(256), 0, ctx->stream, T.d_run_vstart, T.n_runs, T.d_rec_vstart, g->n_rec,
                        T.rt.n_valid, halo, core, n_gt, d_tiles, d_dir);
-    hipLaunchKernelGGL(k_hash_tiers, dim3((uint32_t)n_gt), dim3(TR_THREADS), 0, ctx->stream, Q);
+    launch_tiers(ctx, Q, n_gt);
   }
   {
     ScopedTimer t(ctx, "window_min");
@@ -3712,7 +3723,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       ScopedTimer t(ctx, "hash_tiers", true);
       hipLaunchKernelGGL(k_tier_dir, dim3((uint32_t)((n_kt + 255) / 256)), dim3(256), 0, ctx->stream, T.d_run_vstart, T.n_runs, T.d_rec_vstart, g->n_rec, V,
                          tp->halo, tp->core, n_kt, (const TierTile*)nullptr, d_dir);
-      hipLaunchKernelGGL(k_hash_tiers, dim3((uint32_t)n_kt), dim3(TR_THREADS), 0, ctx->stream, Q);
+      launch_tiers(ctx, Q, n_kt);
     } else if (accept_all) {
       AcceptParams A;
       A.code = S.code;
