@@ -1047,7 +1047,7 @@ def main():
             key = "k_hash_select_hi" if hi_kernel else "k_hash_select"
             per_64 = 17.2 if hi_kernel else 29.8
             sq_source = None
-            for rnd in (4, 3, 2):
+            for rnd in (5, 4, 3, 2):
                 try:
                     sq = json.load(open(os.path.join(ROOT, "profiles", f"r0{rnd}_sq_counters.json")))
                     per_64 = float(sq["kernels"][key]["valu_wave_instructions_per_64_kmers"])
@@ -1254,7 +1254,7 @@ def pmc_traffic(name, pruned_run, algorithmic_bytes=None, line_bytes=None):
     section prescribes for gfx950: FETCH_SIZE tallies every 128-byte request at 64 B, so it is doubled (the probes of this
     kernel are 128-byte requests one and all: profiles/r02_probe_granularity.md; so are its 16-byte-per-lane LDS-DMA reads of
     the base words); WRITE_SIZE is taken as it is (uncalibrated in the guide)."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (4, 3, 2)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (5, 4, 3, 2)) if os.path.exists(q)), None)
     if name != "c3" or path is None:
         return None
     kernels = json.load(open(path))["kernels"]
