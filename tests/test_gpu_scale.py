@@ -123,7 +123,9 @@ def test_records_longer_than_2_to_32(ctx):
 
 
 @pytest.mark.parametrize("record,family,div,n_fam", [("r04_e2e_oracle_c3.json", "structural", 0.01, 3), ("r04_e2e_oracle_c5_like.json", "assembly-like", 0.013, 3),
-                                                     ("r04_e2e_oracle_2x3Gbp_d0.1.json", "structural", 0.001, 2), ("r04_e2e_oracle_c4.json", "structural", 0.10, 8)])
+                                                     ("r04_e2e_oracle_2x3Gbp_d0.1.json", "structural", 0.001, 2), ("r04_e2e_oracle_c4.json", "structural", 0.10, 8),
+                                                     # (round 5) three genomes at 10 %: a filter that accepts 2.4 % of the k-mers, the tiered selection's regime
+                                                     ("r05_e2e_oracle_valley_3x10pct.json", "structural", 0.10, 3)])
 def test_whole_output_at_headline_size_equals_the_recorded_oracle_run(ctx, record, family, div, n_fam):
     """BASELINE configs[2] (and configs[4]'s parameters on the assembly-like family, and the reference's first published row: two 3 Gbp
     genomes at 0.1 %, README.md:156, and configs[3]: eight genomes at 10 %, the sparse-filter regime) at full size, the WHOLE output: the common

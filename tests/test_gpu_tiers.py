@@ -133,3 +133,45 @@ def test_tiers_probe_a_fraction_of_the_kmers(ctx):
     n_kmers = dg[0].valid_kmers(k)
     assert len(mx) > 0 and n_tiers >= 3
     assert probes < 0.45 * n_kmers, (probes, n_kmers)
+
+
+@pytest.mark.parametrize("n,div,w", [(3, 0.10, 1000), (4, 0.06, 500)])
+def test_pipeline_in_the_valley_is_byte_identical_to_the_oracle_pipeline(ctx, tmp_path, n, div, w):
+    """FASTA files of a family whose common filter accepts a few per cent of the k-mers -> the whole product pipeline (GPU parse, fused
+    cascade, sketches through k_hash_tiers, graph stage in HBM, two refinement rounds) == the oracle
+    pipeline: both synteny TSVs and every minimizer TSV byte for byte (`ntSynt -d 10`-like distances, bin/ntSynt:95-97)"""
+    import os
+    from ntsynt_amd import pipeline, synth
+    from oracle import synteny_oracle as SO
+    paths = synth.make_family(str(tmp_path), n, 2_500_000, 3, div, seed=77 + n, micro=4, n_runs=True, soft_mask=True)
+    kw = dict(k=24, w=w, w_rounds=[100, 10], indel=10000, merge=10000, block_size=500, prefix="v")
+    cwd = os.getcwd()
+    ctx.profile(1)
+    ctx.sketch_tiers("always")                  # (files of a few Mbp: the library would take the sparse-filter path, which applies to small filters too)
+    try:
+        os.makedirs(tmp_path / "hip")
+        os.makedirs(tmp_path / "ora")
+        os.chdir(tmp_path / "hip")
+        try:
+            eng = pipeline.run(paths, log=lambda *a: None, ctx=ctx, **kw)
+            hip_out = eng.outputs
+        except SystemExit:                      # "no paths found" (S:630-632): then on both sides
+            hip_out = None
+        tiers_ms, tiers_launches = ctx.timing("hash_tiers")
+        os.chdir(tmp_path / "ora")
+        try:
+            ora_out = SO.run_pipeline(paths, **kw).outputs
+        except SystemExit:
+            ora_out = None
+    finally:
+        os.chdir(cwd)
+        ctx.profile(0)
+        ctx.sketch_tiers("auto")
+    assert tiers_launches >= 1, "the whole-genome sketches did not go through the tiered selection"
+    assert (hip_out is None) == (ora_out is None)
+    if hip_out is not None:
+        for name in ("v.synteny_blocks.tsv", "v.pre-collinear-merge.synteny_blocks.tsv"):
+            assert hip_out[name] == ora_out[name], name
+    for p in paths:
+        name = f"{os.path.basename(p)}.k24.w{w}.tsv"
+        assert open(tmp_path / "hip" / name).read() == open(tmp_path / "ora" / name).read(), name
