@@ -73,6 +73,13 @@ void nts_mem_reset_peak(void);
  * context without workspaces (the first sketch of a run: rule indexlr runs once per genome, bin/ntsynt_run_pipeline.smk:74-85) spends
  * allocating -- bench.py's `cold` leg takes the difference around a call. */
 int nts_alloc_stats(uint64_t* calls, double* ms);
+/* Device blocks the library frees are kept (up to 64 GB, per device) and handed out again to requests of nearly their size: on some
+ * boxes a hipMalloc of a few hundred MB takes 20-100 ms, and every genome, filter and context of a run allocates and frees.  live /
+ * peak of nts_mem_stats count blocks in use, not cached ones (device_used_bytes sees both).  nts_mem_trim gives every cached block back
+ * to the driver (bytes released); an allocation that fails does so by itself and tries again.  nts_mem_cache_stats: bytes cached now,
+ * allocations served from the cache. */
+uint64_t nts_mem_trim(void);
+int nts_mem_cache_stats(uint64_t* cached_bytes, uint64_t* hits);
 
 /* ---- A1: Bloom filter sizing ----------------------------------------------------------------
  * replaces approximate_bf_size(), src/ntsynt_make_common_bf.cpp:28-40, and the byte rounding of

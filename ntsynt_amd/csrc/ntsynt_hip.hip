@@ -47,7 +47,12 @@ using namespace nts;
 // counterpart is this mark.
 namespace nts_mem {
 std::mutex mu;
-std::map<void*, size_t> sizes;
+struct Block
+{
+  size_t bytes;
+  int device;
+};
+std::map<void*, Block> sizes;
 std::atomic<uint64_t> live{0}, peak{0};
 // calls of hipMalloc / hipFree made through here and the host time they took (nts_alloc_stats: what a cold call spends allocating)
 std::atomic<uint64_t> alloc_calls{0}, alloc_ns{0};
@@ -61,19 +66,80 @@ struct AllocClock
   }
 };
 
+// Freed blocks are kept (per device, up to CACHE_LIMIT bytes in all) and handed out again to requests of nearly their size.  On some
+// boxes of the pool this build runs on a hipMalloc of a few hundred MB takes 20-100 ms (the driver's round-4 line: 94.8 ms for the
+// first sketch of a fresh genome; a builder box in round 5: 45.9 ms in the 41 allocations of a context's first sketch and 111.9 ms in the
+// FIVE allocations of a later genome's 2-bit image and tables, where the box next to it takes 0.04 ms: bench.py `cold`), and every
+// genome, filter and context of a run allocates and frees: 2-bit images, tables, 14.8 GB filters, the build's 25 GB of buckets when a
+// context closes and the next one opens.  A block goes back to the driver when the cache is full, when an allocation fails (the
+// cache is emptied and the allocation tried again) and on nts_mem_trim.  `live` / `peak` count blocks in use, not cached ones.
+constexpr uint64_t CACHE_LIMIT = 64ull << 30;
+constexpr size_t CACHE_MIN_BLOCK = 64u << 10;
+std::multimap<std::pair<int, size_t>, void*> cache; // (device, bytes) -> block
+uint64_t cached_bytes = 0;
+std::atomic<uint64_t> cache_hits{0};
+
+inline void count_live(size_t n)
+{
+  const uint64_t now = live.fetch_add(n) + n;
+  uint64_t seen = peak.load();
+  while (now > seen && !peak.compare_exchange_weak(seen, now)) {
+  }
+}
+
+// every cached block back to the driver; returns the bytes released
+inline uint64_t trim()
+{
+  std::vector<void*> gone;
+  uint64_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& kv : cache) gone.push_back(kv.second);
+    bytes = cached_bytes;
+    cache.clear();
+    cached_bytes = 0;
+  }
+  for (void* q : gone) {
+    AllocClock clk;
+    ::hipFree(q);
+  }
+  return bytes;
+}
+
 inline hipError_t dev_malloc(void** p, size_t n)
 {
-  AllocClock clk;
-  const hipError_t e = ::hipMalloc(p, n);
+  int dev = 0;
+  ::hipGetDevice(&dev);
+  if (n >= CACHE_MIN_BLOCK) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.lower_bound({ dev, n });
+    if (it != cache.end() && it->first.first == dev && it->first.second <= n + n / 4 + (1u << 20)) {
+      *p = it->second;
+      const size_t bytes = it->first.second;
+      cache.erase(it);
+      cached_bytes -= bytes;
+      sizes[*p] = { bytes, dev };
+      cache_hits.fetch_add(1);
+      count_live(bytes);
+      return hipSuccess;
+    }
+  }
+  hipError_t e;
+  {
+    AllocClock clk;
+    e = ::hipMalloc(p, n);
+  }
+  if (e == hipErrorOutOfMemory && trim() > 0) { // (what the cache held may be what was missing)
+    (void)hipGetLastError();
+    AllocClock clk;
+    e = ::hipMalloc(p, n);
+  }
   if (e == hipSuccess && *p) {
     {
       std::lock_guard<std::mutex> g(mu);
-      sizes[*p] = n;
+      sizes[*p] = { n, dev };
     }
-    const uint64_t now = live.fetch_add(n) + n;
-    uint64_t seen = peak.load();
-    while (now > seen && !peak.compare_exchange_weak(seen, now)) {
-    }
+    count_live(n);
   }
   return e;
 }
@@ -84,7 +150,7 @@ inline hipError_t dev_malloc(T** p, size_t n)
   return dev_malloc((void**)p, n);
 }
 
-// the same with allocation flags (hipDeviceMallocUncached / hipDeviceMallocFinegrained: how the L2 treats the memory)
+// the same with allocation flags (hipDeviceMallocUncached / hipDeviceMallocFinegrained: how the L2 treats the memory); never cached
 inline hipError_t dev_malloc_flags(void** p, size_t n, unsigned flags)
 {
   AllocClock clk;
@@ -92,24 +158,43 @@ inline hipError_t dev_malloc_flags(void** p, size_t n, unsigned flags)
   if (e == hipSuccess && *p) {
     {
       std::lock_guard<std::mutex> g(mu);
-      sizes[*p] = n;
+      sizes[*p] = { n, -1 };
     }
-    const uint64_t now = live.fetch_add(n) + n;
-    uint64_t seen = peak.load();
-    while (now > seen && !peak.compare_exchange_weak(seen, now)) {
-    }
+    count_live(n);
   }
   return e;
 }
 
 inline hipError_t dev_free(void* p)
 {
-  if (p) {
+  if (!p) return hipSuccess;
+  Block blk = { 0, -1 };
+  bool known = false;
+  {
     std::lock_guard<std::mutex> g(mu);
     auto it = sizes.find(p);
     if (it != sizes.end()) {
-      live.fetch_sub(it->second);
+      blk = it->second;
+      known = true;
+      live.fetch_sub(blk.bytes);
       sizes.erase(it);
+    }
+  }
+  if (known && blk.device >= 0 && blk.bytes >= CACHE_MIN_BLOCK) {
+    // what hipFree does before it gives memory back: nothing queued on the device still uses the block (it may be handed to another
+    // stream or context next)
+    int cur = 0;
+    ::hipGetDevice(&cur);
+    if (cur != blk.device) ::hipSetDevice(blk.device);
+    const hipError_t es = ::hipDeviceSynchronize();
+    if (cur != blk.device) ::hipSetDevice(cur);
+    if (es == hipSuccess) {
+      std::lock_guard<std::mutex> g(mu);
+      if (cached_bytes + blk.bytes <= CACHE_LIMIT) {
+        cache.insert({ { blk.device, blk.bytes }, p });
+        cached_bytes += blk.bytes;
+        return hipSuccess;
+      }
     }
   }
   AllocClock clk;
@@ -1923,6 +2008,22 @@ int nts_alloc_stats(uint64_t* calls, double* ms)
 {
   if (calls) *calls = nts_mem::alloc_calls.load();
   if (ms) *ms = (double)nts_mem::alloc_ns.load() * 1e-6;
+  return NTS_OK;
+}
+
+// Every block the library's allocation cache holds goes back to the driver; bytes released.  (A process that shares the GPU with other
+// users of its memory calls this when a run is over; an allocation that fails does it by itself.)
+uint64_t nts_mem_trim(void)
+{
+  return nts_mem::trim();
+}
+
+// bytes the cache holds now, and how many allocations it has served
+int nts_mem_cache_stats(uint64_t* cached_bytes, uint64_t* hits)
+{
+  std::lock_guard<std::mutex> g(nts_mem::mu);
+  if (cached_bytes) *cached_bytes = nts_mem::cached_bytes;
+  if (hits) *hits = nts_mem::cache_hits.load();
   return NTS_OK;
 }
 

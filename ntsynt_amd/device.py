@@ -136,6 +136,16 @@ class Context:
         self.lib.nts_alloc_stats(ctypes.byref(n), ctypes.byref(ms))
         return n.value, ms.value
 
+    def mem_trim(self):
+        "every block of the library's allocation cache back to the driver; bytes released (nts_mem_trim)"
+        return int(self.lib.nts_mem_trim())
+
+    def mem_cache_stats(self):
+        "(bytes the allocation cache holds, allocations it has served): nts_mem_cache_stats"
+        a, b = u64(), u64()
+        self.lib.nts_mem_cache_stats(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
     def mem_reset_peak(self):
         self.lib.nts_mem_reset_peak()
 
