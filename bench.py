@@ -414,6 +414,10 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
         paths = e2e_inputs(args, device, n_fam, total_bp, contigs, div, workdir)
     t_write = time.time() - t
     a, divergence_pct = e2e_params(args, paths, div)
+    # a user's run starts in a fresh process: what the earlier legs of this one left in the library's allocation cache goes back to the
+    # driver first (the pipeline's own frees and allocations -- loader contexts, per-level workspaces -- still use the cache, as they would there)
+    from ntsynt_amd import _lib
+    cache_released = int(_lib.load().nts_mem_trim())
     cwd = os.getcwd()
     os.chdir(workdir)
     try:
@@ -450,6 +454,7 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
             # RSS (ru_maxrss: since process start, so the sketch legs' host buffers are in it)
             "peak_hbm_bytes": (eng.memory or {}).get("peak_hbm_bytes"), "peak_host_rss_bytes": (eng.memory or {}).get("peak_host_rss_bytes"),
             "hbm_live_at_marks_GB": {n: round(v / 1e9, 2) for n, v in ((eng.memory or {}).get("hbm_live_at_marks") or {}).items()},
+            "allocation_cache_released_before_the_run_GB": round(cache_released / 1e9, 2),
             "write_inputs_s": round(t_write, 1)}
 
 
