@@ -174,3 +174,17 @@ def test_sparse_filter_kernels_fit_their_launch_shapes(code_object):
     for sym in small:
         m = _kernel_meta(notes, sym)
         assert m["private_segment_fixed_size"] == "0" and int(m["vgpr_count"]) <= 32, (sym, m)
+
+
+def test_tiered_selection_keeps_five_workgroups_per_cu(code_object):
+    """k_hash_tiers (csrc/nts_tiers.inc) is bound by chains of dependent trips (list -> hash -> probe) and what hides them is occupancy:
+    five workgroups of 256 lanes per CU need at most 96 vector registers (512 / 5, in granules of 8) AND at most 32 KB of LDS each --
+    measured against four: -4 ... -9 %.  A change that costs a register or a kilobyte would lose it silently."""
+    co, notes = code_object
+    for form in (0, 1, 2):
+        sym = f"_ZN12_GLOBAL__N_112k_hash_tiersILi{form}EEEvNS_10TierParamsE"
+        assert sym in notes, f"{sym} not found (renamed? update this guard with it)"
+        m = _kernel_meta(notes, sym)
+        assert int(m["vgpr_count"]) <= 96, (sym, m)
+        assert int(m["group_segment_fixed_size"]) * 5 <= 160 * 1024, (sym, m)
+        assert int(m.get("vgpr_spill_count", "0")) <= 2 and int(m["private_segment_fixed_size"]) <= 16, (sym, m)   # (one value lives in scratch)
