@@ -4211,9 +4211,11 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   double p = 1.0; // accepted share of the candidates (1 when unknown: sizes the candidate arrays)
   bool tiered = false;
   TierPlan plan;
-  // (tiers forced: also below w = 200, where one threshold is not the default)
+  // (tiers forced: wherever the kernel applies.  Windows of 64 .. 199 k-mers, where one threshold never paid and every k-mer was probed:
+  //  the tiered selection is looked at there too -- a whole 3 Gbp genome at w = 100 against its family's filter: 90 ms the dense way)
   const bool tiers_forced = ctx->tier_mode == 2 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0;
-  if ((pruned || tiers_forced) && prune_c == 0) {
+  const bool tiers_small_w = ctx->tier_mode == 0 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0 && w >= 64 && w < 200;
+  if ((pruned || tiers_forced || tiers_small_w) && prune_c == 0) {
     if (filter) {
       uint64_t pc = 0;
       SK_TRY(nts_bf_popcount(ctx, filter, &pc));
