@@ -4302,7 +4302,13 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     uint32_t shift = 7;
     const uint32_t sum_log2 = NTS_KNOB("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(NTS_KNOB("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
     while ((bits / (double)(1ull << shift)) > (double)(1ull << sum_log2) && shift < 30) ++shift; // summary <= 2^sum_log2 bits
-    if ((double)pc / bits * (double)(1ull << shift) < 0.3) {
+    // How full may the summary be?  A set summary bit sends the k-mer to HBM, so the path costs ~8 ms of hashing and look-ups per 3 Gbp plus
+    // P(bit set) = 1 - exp(-occupancy 2^shift) of the every-k-mer pass (75 ms).  Against the tiered selection (families of 4 .. 7 genomes at
+    // 6-10 %, scripts/summary_switch.py): 32 against 92 ms at 0.31 (five genomes at 10 %: neither path applied there until round 5 --
+    // every k-mer was probed), 52 against 50 at 0.82, 56 against 50 at 0.96: it wins below ~0.7; against every k-mer probed, where the
+    // tiers do not apply, as long as a summary bit says anything at all.
+    const double sum_max = NTS_KNOB("NTS_SUMMARY_MAX") ? atof(NTS_KNOB("NTS_SUMMARY_MAX")) : (tiered ? 0.7 : 3.0);
+    if ((double)pc / bits * (double)(1ull << shift) < sum_max) {
       SK_TRY(bf_make_summary(ctx, filter, shift));
       const uint64_t key_tiles = (rt.n_valid + KEY_TILE - 1) / KEY_TILE;
       SK_WS(d_any, uint32_t*, "tile_any", (key_tiles + 4) * 4);

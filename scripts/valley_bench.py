@@ -24,7 +24,7 @@ for mode in os.environ.get("MODES", "tiers,never").split(","):
     x0s = [float(x) for x in os.environ.get("X0", "2.4").split(",")] if mode == "tiers" else [0.0]
     for x0 in x0s:
         for half in ([int(x) for x in os.environ.get("HALF", "0").split(",")] if mode == "tiers" else [0]):
-            ctx.sketch_tiers("always" if mode == "tiers" else "never", x0=x0, half_steps=bool(half))
+            ctx.sketch_tiers({"tiers": "always", "auto": "auto"}.get(mode, "never"), x0=x0, half_steps=bool(half))
             ctx.sketch_mode("dense" if mode == "dense" else "auto")
             dt = 0
             for i in range(3):
