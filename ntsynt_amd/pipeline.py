@@ -455,7 +455,7 @@ def _exchange_lists(backend, local, n_total):
 def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000, merge=10000,
         block_size=500, common=True, simplify=True, device=0, write_mx_tsv=True, mx_with_seq=True,
         benchmark=False, log=print, ctx=None, backend=None, bf_rounding="up", bf_signature=BF_SIGNATURE, dev=False, interarrivals=False, repeat=False,
-        mx_tsvs=None, common_file=None, m=90, n=0, initial_only=False, write_fai=True, engine="device"):
+        mx_tsvs=None, common_file=None, m=90, n=0, initial_only=False, write_fai=True, engine="device", refine_repeat_file=None):
     """FASTA paths -> engine (outputs in .outputs and in the CWD).  Mirrors oracle.synteny_oracle.run_pipeline's
     signature so the parity tests read alike.  Under torch.distributed (WORLD_SIZE > 1, process group already
     initialised by the caller) genomes are sharded over the ranks.
@@ -614,6 +614,20 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         del bits
         st.stop()
         common = False
+    refine_rep = None
+    if refine_repeat_file is not None:
+        # stage 3's `--filter Indexlr --repeat <file>` (bin/ntsynt_synteny.py:172-180): the refinement rounds' indexlr runs get `-r <file>`
+        # (next to `-s <common>` when there is one); the initial lists come from the files as they are
+        if world > 1 or not isinstance(backend, GpuBackend):
+            raise ValueError("a filter file is read on one GPU")
+        st.start("load_repeat_bf")
+        bits, k_file = read_bf(refine_repeat_file)
+        if k_file != k:
+            raise ValueError(f"{refine_repeat_file}: built for k = {k_file}, this run uses k = {k}")
+        refine_rep = backend.bf_new(bits.size, k)
+        refine_rep.from_numpy(bits)
+        del bits
+        st.stop()
     if common:
         st.start("make_common_bf")
         ordered = sorted(fastas)                               # src/ntsynt_make_common_bf.cpp:105-107
@@ -768,6 +782,8 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
             ml = [masks_by_asm[i] for i in mine_idx] if masks_by_asm is not None else None
             if rep_bf is not None and masks_by_asm is None:
                 got = backend.sketch_dev([genomes[fastas[i]] for i in mine_idx], k, new_w, bf, ml, repeat=rep_bf)
+            elif refine_rep is not None and masks_by_asm is not None:
+                got = backend.sketch_dev([genomes[fastas[i]] for i in mine_idx], k, new_w, bf, ml, repeat=refine_rep)
             else:
                 got = backend.sketch_dev([genomes[fastas[i]] for i in mine_idx], k, new_w, bf, ml)
             local = dict(zip(mine_idx, got))
@@ -911,6 +927,8 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                 sub.free()
     if bf is not None and hasattr(bf, "free"):
         bf.free()
+    if refine_rep is not None:
+        refine_rep.free()
     if own_backend:
         backend.close()
     st.mark("end")

@@ -490,7 +490,7 @@ class SyntenyOracle:
     def sketch_masked(self, asm, ctg_masks, new_w):                 # S:134-192: maskfasta + indexlr + read_minimizers
         "(mx_info, lists) of assembly `asm` re-sketched with hard masks (a seam: list-level tests script this step)"
         mg = self.masked_genome(asm, ctg_masks)
-        mins = O.minimize(mg, self.k, new_w, self.bf, self.threads)
+        mins = O.minimize(mg, self.k, new_w, self.bf, self.threads, repeat=getattr(self, "refine_repeat", None))   # S:172-180: --filter Indexlr adds -r
         return mx_tables_from_tokens(mx_records_from_arrays(mg.names, mins))
 
     def new_minimizers(self, blocks, new_w, prev_w):               # S:532-541

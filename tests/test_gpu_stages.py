@@ -154,3 +154,63 @@ def test_stage_executables_options(tmp_path):
         os.chdir(cwd)
     for n in ("nc.synteny_blocks.tsv", "nc.pre-collinear-merge.synteny_blocks.tsv"):
         assert open(tmp_path / n).read() == ora.outputs[n], n
+
+
+def test_stage3_filter_indexlr_sketches_the_refinement_rounds_with_the_repeat_filter(tmp_path):
+    """`ntsynt_run.py --filter Indexlr --repeat <bf> --common <bf>` (bin/ntsynt_synteny.py:172-180, 598-599): the refinement rounds'
+    indexlr runs get `-r <repeat filter>` next to `-s <common filter>`; the initial lists are read from the files as they are.
+    Against the oracle engine with the same filters; the repeat filter must change the result (else the test proves nothing);
+    `--filter` without `--repeat` is the reference's ValueError, `--filter Filter` is refused."""
+    import re
+    from oracle import nts_oracle as O
+    from ntsynt_amd.pipeline import write_bf
+    src = tmp_path / "in"
+    src.mkdir()
+    paths = synth.make_family(str(src), 3, 900_000, 3, 0.01, seed=61, micro=8)
+    for p in paths:                                         # something repeated in every genome: a stretch of the first record copied further down
+        recs = re.split(r"(?m)^>", open(p).read())[1:]
+        head, *lines = recs[0].split("\n")
+        seq = "".join(lines)
+        seq = seq[:150000] + seq[10000:70000] + seq[150000:]
+        recs[0] = head + "\n" + "\n".join(seq[i:i + 80] for i in range(0, len(seq), 80)) + "\n"
+        open(p, "w").write("".join(">" + r for r in recs))
+    k, w = 24, 400
+    genomes = {p: O.read_fasta(p) for p in paths}
+    common = O.common_bf(genomes, k, 0.025, 1)
+    rep = O.repeat_bf([genomes[p] for p in paths], k, common.size)
+    assert O.bf_popcount(rep) > 10000
+    write_bf(str(tmp_path / "f.common.bf"), common, k)
+    write_bf(str(tmp_path / "f.repeat.bf"), rep, k)
+    tsvs, tables, by_tsv = [], {}, {}
+    for p in paths:
+        t = f"{os.path.basename(p)}.k{k}.w{w}.tsv"
+        O.write_indexlr_tsv(str(tmp_path / t), genomes[p], O.minimize(genomes[p], k, w, common), k)
+        tsvs.append(t)
+        tables[t] = SO.read_minimizers_tsv(str(tmp_path / t))
+        by_tsv[t] = genomes[p]
+    args = tsvs + ["-k", str(k), "-w", str(w), "--w-rounds", "100", "20", "--bp", "600", "--collinear-merge", "3000", "-z", "300", "--common", "f.common.bf",
+                   "--simplify-graph", "--fastas"] + paths
+    _run([os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "withr", "--filter", "Indexlr", "--repeat", "f.repeat.bf"], str(tmp_path))
+    _run([os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "plain", "--repeat", "f.repeat.bf"], str(tmp_path))     # (--repeat alone: echoed, unused)
+    outs = {}
+    cwd = os.getcwd()
+    for label, r in (("withr", rep), ("plain", None)):
+        os.makedirs(tmp_path / f"ora_{label}")
+        os.chdir(tmp_path / f"ora_{label}")
+        try:
+            eng = SO.SyntenyOracle(list(tables), by_tsv, k, w, [100, 20], 600, 3000, 300, label, bf=common, simplify=True)
+            eng.refine_repeat = r
+            eng.load(tables)
+            eng.main()
+        finally:
+            os.chdir(cwd)
+        outs[label] = eng.outputs
+    for label in ("withr", "plain"):
+        for n in (f"{label}.synteny_blocks.tsv", f"{label}.pre-collinear-merge.synteny_blocks.tsv"):
+            assert open(tmp_path / n).read() == outs[label][n] and outs[label][n], n
+    assert outs["withr"]["withr.synteny_blocks.tsv"] != outs["plain"]["plain.synteny_blocks.tsv"]
+    r = subprocess.run([sys.executable, os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "x", "--filter", "Indexlr"], cwd=str(tmp_path), capture_output=True)
+    assert r.returncode != 0 and b"must supply repeat Bloom filter with --repeat" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "x", "--filter", "Filter", "--repeat", "f.repeat.bf"],
+                       cwd=str(tmp_path), capture_output=True)
+    assert r.returncode == 2 and b"not served" in r.stderr
