@@ -1,5 +1,6 @@
 """Whole-genome sketch at small windows (64 <= w < 200: the refinement rounds' values, and `ntSynt -w 100`): the tiered selection
-against every k-mer probed.  W=100 DIV=0.01 python scripts/small_w_bench.py"""
+against every k-mer probed.  W=100 DIV=0.01 [MODES=auto,never,always] python scripts/small_w_bench.py
+(any w: with W=250 ... 700 this is the check of where one threshold hands over to the tiers)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from ntsynt_amd.device import Context, Genome, BloomFilter, bf_size_bytes, sketch
@@ -12,7 +13,7 @@ bf.insert(g0)
 for j in (1, 2):
     g = Genome.synth(ctx, total, 24, 20240207, 1000 + j, div / 2)
     bf.insert_and(g); g.free()
-for mode in ("auto", "never"):
+for mode in os.environ.get("MODES", "auto,never").split(","):
     ctx.sketch_tiers(mode)
     for _ in range(2):
         ctx.sync(); t = time.time(); mx = sketch(ctx, g0, k, w, bf); n = len(mx); mx.free(); ctx.sync(); dt = time.time() - t
