@@ -3648,6 +3648,7 @@ int run_gap_tiers(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint
   Q.tile_cnt = d_tcnt;
   Q.tile_ordered = d_tord;
   Q.stats = d_ctl + N_SEG + 2;
+  Q.exp_stop = 0;
   {
     ScopedTimer t(ctx, "hash_probe"); // (the group the dense pass over the ranges is timed under)
     hipLaunchKernelGGL(k_tier_dir, dim3((uint32_t)((n_gt + 255) / 256)), dim3(256), 0, ctx->stream, T.d_run_vstart, T.n_runs, T.d_rec_vstart, g->n_rec,
@@ -3738,7 +3739,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   // room for the ACCEPTED candidates (share p_accept of the candidates, 1 if unknown); too little is seen and retried
   uint64_t cseg_cap = (uint64_t)((double)V * frac * std::min(1.0, 1.5 * p_accept + (accept_all ? 1e-4 : 0.02)) * 1.25 / N_SEG) + 8192;
   // tiers: the accepted k-mers found are ~p x (3.4/p probes per window) plus what conserved stretches add; a retry follows if it was too small
-  if (tp) cseg_cap = (uint64_t)((double)V * (6.0 / (double)w + 0.002) * 1.25 / N_SEG) + 8192;
+  if (tp) cseg_cap = (uint64_t)((double)V * (std::max(6.0, 2.5 * ctx->tier_x0) / (double)w + 0.002) * 1.25 / N_SEG) + 8192;
   // the upper-halves kernel drops about 70 % of the accepted k-mers again (those that cannot win a window) -- where its tiles lie inside
   // one run; the window and gather kernels are launched over the capacity, so half of it is what they get until a call has
   // needed more (an assembly in pieces: the retry below, once per context)
@@ -3819,6 +3820,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       Q.tile_cnt = d_tcnt;
       Q.tile_ordered = d_tord;
       Q.stats = d_tstats;
+      Q.exp_stop = NTS_KNOB("NTS_TR_STOP") ? (uint32_t)atoi(NTS_KNOB("NTS_TR_STOP")) : 0u;
       Q.tiles = nullptr;
       Q.excl_on = Q.excl_hi = 0;
       ScopedTimer t(ctx, "hash_tiers", true);

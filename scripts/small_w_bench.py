@@ -14,8 +14,8 @@ for j in (1, 2):
     g = Genome.synth(ctx, total, 24, 20240207, 1000 + j, div / 2)
     bf.insert_and(g); g.free()
 for mode in os.environ.get("MODES", "auto,never").split(","):
-    ctx.sketch_tiers(mode)
+    ctx.sketch_tiers(mode.split(':')[0], x0=float(mode.split(':')[1]) if ':' in mode else 0.0)   # (always:6 = forced, first tier aimed at 6 accepted k-mers per window)
     for _ in range(2):
         ctx.sync(); t = time.time(); mx = sketch(ctx, g0, k, w, bf); n = len(mx); mx.free(); ctx.sync(); dt = time.time() - t
     pr, rounds, tiers = ctx.sketch_tiers()
-    print(f"w={w} div={div}: tiers {mode:5s} (planned {tiers}): {dt * 1e3:7.2f} ms = {g0.total_bp / dt / 1e9:6.1f} Gbases/s, probes per k-mer {pr / g0.valid_kmers(k):.3f}, minimizers {n}", flush=True)
+    print(f"w={w} div={div}: tiers {mode:9s} (planned {tiers}): {dt * 1e3:7.2f} ms = {g0.total_bp / dt / 1e9:6.1f} Gbases/s, probes per k-mer {pr / g0.valid_kmers(k):.3f}, minimizers {n}", flush=True)
