@@ -374,6 +374,10 @@ int nts_mx_split(nts_ctx* ctx, const nts_mx* mx, uint32_t n_parts, const uint32_
 /* the inverse: the lists of a genome's shards (nts_genome_slice), in record order, as the genome's list -- part p's record
  * numbers raised by rec_offset[p] */
 int nts_mx_concat(nts_ctx* ctx, uint32_t n_parts, const nts_mx* const* parts, const uint32_t* rec_offset, nts_mx** out);
+/* ntJoin's read_minimizers(file, repeat_bf) -- stage 3's `--filter Filter --repeat <bf>` (bin/ntsynt_synteny.py:183-184,601-604; the
+ * function itself is ntJoin's and not in the reference tree: [RECALLED]): *out = the minimizers of `mx` whose k-mer
+ * (k bases of `g` at the minimizer's record and position) the filter does NOT hold, in order; released with nts_mx_free. */
+int nts_mx_screen(nts_ctx* ctx, const nts_genome* g, const nts_mx* mx, uint32_t k, const nts_bf* filter_out, nts_mx** out);
 /* build a device list from host arrays (receiving side of the all-gather, tests) */
 int nts_mx_upload(nts_ctx* ctx,
                   const uint64_t* h1,

@@ -149,6 +149,7 @@ SYMBOLS = [
                                           ctypes.POINTER(c_vp)]),
     ("nts_mx_split", ctypes.c_int, [c_vp, c_vp, u32, c_u32p, ctypes.POINTER(c_vp)]),
     ("nts_mx_concat", ctypes.c_int, [c_vp, u32, ctypes.POINTER(c_vp), c_u32p, ctypes.POINTER(c_vp)]),
+    ("nts_mx_screen", ctypes.c_int, [c_vp, c_vp, c_vp, u32, c_vp, ctypes.POINTER(c_vp)]),
     ("nts_mx_upload", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, u64, ctypes.POINTER(c_vp)]),
     ("nts_hash_all", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_u64p), c_u64p]),
     ("nts_graph_build", ctypes.c_int, [c_vp, u32, ctypes.POINTER(MxList), ctypes.POINTER(Graph)]),

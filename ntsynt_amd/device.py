@@ -524,6 +524,13 @@ class Minimizers:
             self.ctx.check(self.ctx.lib.nts_mx_kmers(self.ctx.h, genome.h, self.h, int(k), out.ctypes.data), "nts_mx_kmers")
         return out
 
+    def screened(self, genome, k, filter_out):
+        """ntJoin's read_minimizers(file, repeat_bf) (stage 3's `--filter Filter`): a new list without the minimizers whose k-mer -- the
+        k bases of `genome` at their record and position -- the filter holds (nts_mx_screen)"""
+        h = c_vp()
+        self.ctx.check(self.ctx.lib.nts_mx_screen(self.ctx.h, genome.h, self.h, int(k), filter_out.h, ctypes.byref(h)), "nts_mx_screen")
+        return Minimizers(self.ctx, h)
+
     def split(self, rec_base):
         """The list of a Genome.concat() batch taken apart on the device (nts_mx_split): one Minimizers per part, record ids
         local to the part; rec_base = Genome.rec_base of the batch."""

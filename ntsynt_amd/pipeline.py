@@ -455,7 +455,7 @@ def _exchange_lists(backend, local, n_total):
 def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000, merge=10000,
         block_size=500, common=True, simplify=True, device=0, write_mx_tsv=True, mx_with_seq=True,
         benchmark=False, log=print, ctx=None, backend=None, bf_rounding="up", bf_signature=BF_SIGNATURE, dev=False, interarrivals=False, repeat=False,
-        mx_tsvs=None, common_file=None, m=90, n=0, initial_only=False, write_fai=True, engine="device", refine_repeat_file=None):
+        mx_tsvs=None, common_file=None, m=90, n=0, initial_only=False, write_fai=True, engine="device", refine_repeat_file=None, screen_repeat_file=None):
     """FASTA paths -> engine (outputs in .outputs and in the CWD).  Mirrors oracle.synteny_oracle.run_pipeline's
     signature so the parity tests read alike.  Under torch.distributed (WORLD_SIZE > 1, process group already
     initialised by the caller) genomes are sharded over the ranks.
@@ -614,6 +614,15 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         del bits
         st.stop()
         common = False
+    if refine_repeat_file is not None and screen_repeat_file is not None:
+        raise ValueError("the repeat filter serves either the refinement sketches (--filter Indexlr) or the reading of the lists (--filter Filter)")
+    screen_lists = screen_repeat_file is not None
+    if screen_lists:
+        # stage 3's `--filter Filter --repeat <file>` (S:183-184,601-604): ntJoin's read_minimizers leaves out the minimizers whose k-mer the
+        # filter holds -- of the initial files and of every refinement round's lists (nts_mx_screen); the sketches themselves are unscreened
+        if mx_tsvs is None or initial_only:
+            raise ValueError("lists are screened in stage 3 on given minimizer files, with the FASTA files read")
+        refine_repeat_file = screen_repeat_file
     refine_rep = None
     if refine_repeat_file is not None:
         # stage 3's `--filter Indexlr --repeat <file>` (bin/ntsynt_synteny.py:172-180): the refinement rounds' indexlr runs get `-r <file>`
@@ -782,10 +791,15 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
             ml = [masks_by_asm[i] for i in mine_idx] if masks_by_asm is not None else None
             if rep_bf is not None and masks_by_asm is None:
                 got = backend.sketch_dev([genomes[fastas[i]] for i in mine_idx], k, new_w, bf, ml, repeat=rep_bf)
-            elif refine_rep is not None and masks_by_asm is not None:
+            elif refine_rep is not None and masks_by_asm is not None and not screen_lists:
                 got = backend.sketch_dev([genomes[fastas[i]] for i in mine_idx], k, new_w, bf, ml, repeat=refine_rep)
             else:
                 got = backend.sketch_dev([genomes[fastas[i]] for i in mine_idx], k, new_w, bf, ml)
+            if screen_lists:
+                seen = [m_.screened(genomes[fastas[i]], k, refine_rep) for i, m_ in zip(mine_idx, got)]
+                for m_ in got:
+                    m_.free()
+                got = seen
             local = dict(zip(mine_idx, got))
             if world == 1:
                 return local
@@ -813,6 +827,10 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
                     order = np.lexsort((pos, rec))
                     h1, rec, pos = h1[order], rec[order], pos[order]
                 initial_dev[i] = Minimizers.from_numpy(backend.ctx, h1, rec, pos)
+                if screen_lists:
+                    whole = initial_dev[i]
+                    initial_dev[i] = whole.screened(genomes[p], k, refine_rep)
+                    whole.free()
             write_mx_tsv = False
         else:
             initial_dev = sketch_dev_round(None, w)

@@ -130,7 +130,7 @@ def run_parser():
     p.add_argument("-k", help="k-mer size used for minimizer step", required=True, type=int)
     p.add_argument("-w", help="Window size used for minimizers", required=True, type=int)
     p.add_argument("-z", help="Minimum synteny block size (bp) [500]", type=int, default=500)
-    p.add_argument("--filter", help="Type of repeat filtering (experimental in the reference; Indexlr: the refinement rounds sketch with -r <repeat filter>; Filter is not served)", choices=["Filter", "Indexlr"], type=str)
+    p.add_argument("--filter", help="Type of repeat filtering (experimental in the reference; Indexlr: the refinement rounds sketch with -r <repeat filter>; Filter: minimizers whose k-mer the repeat filter holds are not read)", choices=["Filter", "Indexlr"], type=str)
     p.add_argument("--common", help="Input common BF for minimizer selection", type=str)
     p.add_argument("--repeat", help="Repeat BF (must be included if --filter is specified)", type=str)
     p.add_argument("--btllib_t", help="accepted for compatibility: threads of the reference's btllib wrappers [4]", type=int, default=4)
@@ -179,11 +179,8 @@ def run(argv=None):
     args = run_parser().parse_args(argv)
     if args.filter and not args.repeat:
         raise ValueError("If --filter is specified, must supply repeat Bloom filter with --repeat")     # bin/ntsynt_synteny.py:598-599
-    if args.filter == "Filter":
-        # S:602-604, 183-184: ntJoin's read_minimizers drops the minimizers whose k-mer the repeat filter holds -- a function of the
-        # ntJoin package, absent from the reference tree; its rule is not restated from memory here
-        print("--filter Filter (minimizers screened by ntJoin's read_minimizers against the repeat filter) is not served by this build; "
-              "--filter Indexlr is", file=sys.stderr)
+    if args.filter == "Filter" and args.initial_only:
+        print("--filter Filter reads the FASTA files (the lists are screened against their k-mers): not with --initial-only", file=sys.stderr)
         return 2
     merge = collinear_merge_bp(args.collinear_merge, args.w)
     fastas = pair_files(args.FILES, args.fastas)
@@ -214,6 +211,7 @@ def run(argv=None):
                  common=False, common_file=args.common, simplify=args.simplify_graph, device=args.device, mx_tsvs=list(args.FILES),
                  m=args.m, n=args.n, dev=args.dev, interarrivals=args.interarrivals, initial_only=args.initial_only, write_fai=False,
                  refine_repeat_file=args.repeat if args.filter == "Indexlr" else None,
+                 screen_repeat_file=args.repeat if args.filter == "Filter" else None,
                  log=print if args.dev else (lambda *a, **k: None))
     print("Done ntSynt synteny stage", flush=True)
     return 0

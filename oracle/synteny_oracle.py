@@ -48,8 +48,10 @@ def mx_tables_from_tokens(records):
     return mx_info, lists
 
 
-def read_minimizers_tsv(path):
-    "Parse an indexlr `--long --pos [--seq]` TSV (row B4) and apply row C1."
+def read_minimizers_tsv(path, repeat_bf=None):
+    """Parse an indexlr `--long --pos [--seq]` TSV (row B4) and apply row C1.  repeat_bf (stage 3's `--filter Filter`, S:183-184,601-604;
+    ntJoin's read_minimizers(file, repeat_bf), [RECALLED] like the rest of that function): a token whose k-mer text (third field) the
+    filter holds is not read at all -- it is neither listed nor counted as a sighting of its hash."""
     records = []
     with open(path, encoding="utf-8") as fh:
         for line in fh:
@@ -58,6 +60,8 @@ def read_minimizers_tsv(path):
                 toks = []
                 for tok in cols[1].split(" "):
                     parts = tok.split(":")
+                    if repeat_bf is not None and O.bf_contains(repeat_bf, O.hash_kmer(parts[2])[0]):
+                        continue
                     toks.append((parts[0], int(parts[1])))
                 records.append((cols[0], toks))
     return mx_tables_from_tokens(records)
@@ -491,7 +495,16 @@ class SyntenyOracle:
         "(mx_info, lists) of assembly `asm` re-sketched with hard masks (a seam: list-level tests script this step)"
         mg = self.masked_genome(asm, ctg_masks)
         mins = O.minimize(mg, self.k, new_w, self.bf, self.threads, repeat=getattr(self, "refine_repeat", None))   # S:172-180: --filter Indexlr adds -r
-        return mx_tables_from_tokens(mx_records_from_arrays(mg.names, mins))
+        records = mx_records_from_arrays(mg.names, mins)
+        screen = getattr(self, "screen_repeat", None)                # S:183-184: --filter Filter, read_minimizers(file, repeat_bf)
+        if screen is not None:
+            g = self.genomes[asm]                                     # (a minimizer's k-mer holds no masked base: the unmasked record serves)
+            kept = []
+            for r, (name, toks) in enumerate(records):
+                rec = g.record(r)
+                kept.append((name, [(h, p) for h, p in toks if not O.bf_contains(screen, O.hash_kmer(rec[p:p + self.k])[0])]))
+            records = kept
+        return mx_tables_from_tokens(records)
 
     def new_minimizers(self, blocks, new_w, prev_w):               # S:532-541
         masks = self.mask_intervals(blocks, prev_w)

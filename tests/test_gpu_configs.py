@@ -462,6 +462,39 @@ def test_repeat_filter_matches_oracle(ctx, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,nbytes", [(24, 1 << 18), (20, 100_003 * 8), (40, 1 << 16), (70, 1 << 16)])
+def test_minimizer_list_screened_against_a_repeat_filter(ctx, k, nbytes):
+    """nts_mx_screen (stage 3's `--filter Filter`: ntJoin's read_minimizers(file, repeat_bf)): the minimizers whose k-mer the filter holds
+    leave the list, the others stay in order -- against the oracle's filter test on the k-mer text; soft-masked and ragged records"""
+    from ntsynt_amd.device import BloomFilter, sketch
+    from tests.helpers import random_records, to_device
+    rng = np.random.default_rng(k)
+    seqs = random_records(rng, [50_000, 0, k - 1, k, 3000, 120_000, 700], n_frac=0.01)
+    names = [f"r{i}" for i in range(len(seqs))]
+    g = to_device(ctx, names, seqs)
+    og = O.Genome(names, seqs)
+    want_bf = O.bf_build(og, k, nbytes)                    # (every k-mer of the genome: all minimizers would go)
+    bits = np.unpackbits(want_bf, bitorder="little")
+    bits[rng.random(bits.size) < 0.5] = 0                  # half of it: some minimizers stay, some go
+    half = np.packbits(bits, bitorder="little")
+    rep = BloomFilter(ctx, nbytes, k)
+    rep.from_numpy(half)
+    mx = sketch(ctx, g, k, 50)
+    h1, rec, pos = mx.to_numpy()
+    keep = np.array([not O.bf_contains(half, O.hash_kmer(seqs[r][p:p + k])[0]) for r, p in zip(rec.tolist(), pos.tolist())], dtype=bool)
+    assert 0.2 < keep.mean() < 0.8 and keep.size > 1000
+    got = mx.screened(g, k, rep)
+    a, b, c = got.to_numpy()
+    assert np.array_equal(a, h1[keep]) and np.array_equal(b, rec[keep]) and np.array_equal(c, pos[keep])
+    empty = mx.screened(g, k, BloomFilter(ctx, nbytes, k, ones=True))
+    assert len(empty) == 0
+    for m in (mx, got, empty):
+        m.free()
+    rep.free()
+    g.free()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bits", [143_467_638 * 8, (1 << 32) + 1, 14_811_708_827 * 8, (1 << 37) - 1, (1 << 38) - 3, (1 << 38) + 5,
                                   (1 << 40) + 12345, 2, 3, (1 << 32), (1 << 32) - 1])
 def test_filter_index_arithmetic_all_forms(ctx, bits):

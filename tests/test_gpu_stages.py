@@ -156,11 +156,13 @@ def test_stage_executables_options(tmp_path):
         assert open(tmp_path / n).read() == ora.outputs[n], n
 
 
-def test_stage3_filter_indexlr_sketches_the_refinement_rounds_with_the_repeat_filter(tmp_path):
+def test_stage3_filter_indexlr_and_filter_filter_against_the_oracle_engine(tmp_path):
     """`ntsynt_run.py --filter Indexlr --repeat <bf> --common <bf>` (bin/ntsynt_synteny.py:172-180, 598-599): the refinement rounds'
     indexlr runs get `-r <repeat filter>` next to `-s <common filter>`; the initial lists are read from the files as they are.
     Against the oracle engine with the same filters; the repeat filter must change the result (else the test proves nothing);
-    `--filter` without `--repeat` is the reference's ValueError, `--filter Filter` is refused."""
+    `--filter Filter --repeat <bf>` (S:183-184,601-604): ntJoin's read_minimizers(file, repeat_bf) leaves out the minimizers whose k-mer
+    the filter holds -- initial files and refinement lists (nts_mx_screen on the device; the oracle screens the TSV's k-mer text).
+    `--filter` without `--repeat` is the reference's ValueError."""
     import re
     from oracle import nts_oracle as O
     from ntsynt_amd.pipeline import write_bf
@@ -192,25 +194,32 @@ def test_stage3_filter_indexlr_sketches_the_refinement_rounds_with_the_repeat_fi
                    "--simplify-graph", "--fastas"] + paths
     _run([os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "withr", "--filter", "Indexlr", "--repeat", "f.repeat.bf"], str(tmp_path))
     _run([os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "plain", "--repeat", "f.repeat.bf"], str(tmp_path))     # (--repeat alone: echoed, unused)
+    # --filter Filter: the minimizers whose k-mer the repeat filter holds are not read (initial files and every refinement round's lists)
+    _run([os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "screened", "--filter", "Filter", "--repeat", "f.repeat.bf"], str(tmp_path))
     outs = {}
     cwd = os.getcwd()
-    for label, r in (("withr", rep), ("plain", None)):
+    for label, r in (("withr", rep), ("plain", None), ("screened", rep)):
         os.makedirs(tmp_path / f"ora_{label}")
         os.chdir(tmp_path / f"ora_{label}")
         try:
             eng = SO.SyntenyOracle(list(tables), by_tsv, k, w, [100, 20], 600, 3000, 300, label, bf=common, simplify=True)
-            eng.refine_repeat = r
-            eng.load(tables)
+            if label == "screened":
+                eng.screen_repeat = r
+                eng.load({t: SO.read_minimizers_tsv(str(tmp_path / t), repeat_bf=r) for t in tsvs})
+            else:
+                eng.refine_repeat = r
+                eng.load(tables)
             eng.main()
         finally:
             os.chdir(cwd)
         outs[label] = eng.outputs
-    for label in ("withr", "plain"):
+    assert outs["screened"]["screened.synteny_blocks.tsv"] not in (outs["plain"]["plain.synteny_blocks.tsv"], outs["withr"]["withr.synteny_blocks.tsv"])
+    for label in ("withr", "plain", "screened"):
         for n in (f"{label}.synteny_blocks.tsv", f"{label}.pre-collinear-merge.synteny_blocks.tsv"):
             assert open(tmp_path / n).read() == outs[label][n] and outs[label][n], n
     assert outs["withr"]["withr.synteny_blocks.tsv"] != outs["plain"]["plain.synteny_blocks.tsv"]
     r = subprocess.run([sys.executable, os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "x", "--filter", "Indexlr"], cwd=str(tmp_path), capture_output=True)
     assert r.returncode != 0 and b"must supply repeat Bloom filter with --repeat" in r.stderr
-    r = subprocess.run([sys.executable, os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "x", "--filter", "Filter", "--repeat", "f.repeat.bf"],
+    r = subprocess.run([sys.executable, os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "x", "--filter", "Filter", "--repeat", "f.repeat.bf", "--initial-only"],
                        cwd=str(tmp_path), capture_output=True)
-    assert r.returncode == 2 and b"not served" in r.stderr
+    assert r.returncode == 2 and b"not with --initial-only" in r.stderr
