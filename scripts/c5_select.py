@@ -30,6 +30,11 @@ for c in [int(x) for x in os.environ.get("CS", "0,14,16,18,21").split(",")]:
         sketch(ctx, g, k, w, bf).free()
     ctx.sync()
     hs = ctx.timing("hash_select")
+    ctx.profile(1)                                        # (every stage timed, each with a synchronisation behind it)
+    for g in gens:
+        sketch(ctx, g, k, w, bf).free()
+    ctx.sync()
+    stages = {nm: ctx.timing(nm) for nm in ("hash_select", "cand_compact", "sparse_win", "gather_winners", "hash_tiers", "hash_probe", "window_min", "finalize", "pack_image")}
     ctx.profile(0)
     print(f"c={c or ctx.last_prune_c}{' (auto)' if not c else ''}: {sum(g.total_bp for g in gens) / dt / 1e9:7.1f} Gbases/s, select {hs[0] / max(hs[1], 1):.3f} ms, "
-          f"candidates {st[0]}, uncovered ranges {st[1]} ({st[2]} k-mers), many-listed {ctx.path_stats()['sketch_many_listed']}, minimizers {n}", flush=True)
+          f"candidates {st[0]}, uncovered ranges {st[1]} ({st[2]} k-mers), many-listed {ctx.path_stats()['sketch_many_listed']}, minimizers {n}; ms per genome: " + ", ".join(f"{nm} {v[0] / 3:.3f}" for nm, v in stages.items() if v[1]) + f"; wall per genome {dt / 3 * 1e3:.3f} ms", flush=True)
