@@ -645,6 +645,7 @@ class Rig:
         for f_ in extra:
             f_.free()
         self.common = common
+        ctx.trim_bf_build()                          # as the pipeline does once its common filter stands (pipeline.run): the buckets go to the allocation cache
         return {"build_s": t_build, "build_again_s": t_warm, "allreduce_s": t_allreduce, "occ_single": occ_single}
 
     def step(self, pool=None):

@@ -588,6 +588,10 @@ int nts_fasta_read(const char* path, nts_fasta* out);
  * that file, in HBM) and the pinned staging lanes -- once the last genome of a run is resident. */
 int nts_genome_from_fasta(nts_ctx* ctx, const char* path, nts_genome** out, nts_fasta* meta);
 int nts_ingest_trim(nts_ctx* ctx);
+/* the Bloom build's bucket arrays (24 GB at 3 Gbp) back to the library's allocation cache once the last filter of a run is made (rules
+ * indexlr and ntsynt_synteny build none: bin/ntsynt_run_pipeline.smk:74-103): later allocations are cut from them; the next build, if
+ * there is one, takes them up again */
+int nts_bf_build_trim(nts_ctx* ctx);
 /* nts_write_indexlr_tsv for records whose bases are not on the host (fa->seq == NULL): `kmers` = nts_mx_kmers' output, or
  * NULL without --seq */
 int nts_write_indexlr_tsv_kmers(const char* path, const nts_fasta* fa, const uint64_t* h1, const uint32_t* rec, const uint64_t* pos,

@@ -183,6 +183,7 @@ SYMBOLS = [
     ("nts_mx_tsv_free", None, [ctypes.POINTER(MxTsv)]),
     ("nts_genome_from_fasta", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(c_vp), ctypes.POINTER(Fasta)]),
     ("nts_ingest_trim", ctypes.c_int, [c_vp]),
+    ("nts_bf_build_trim", ctypes.c_int, [c_vp]),
     ("nts_mx_kmers", ctypes.c_int, [c_vp, c_vp, c_vp, u32, c_vp]),
     ("nts_write_indexlr_tsv_kmers", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Fasta), c_vp, c_vp, c_vp, u64, u32, c_vp]),
     ("nts_write_indexlr_tsv", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Fasta), c_vp, c_vp, c_vp, u64, u32, ctypes.c_int]),

@@ -13,6 +13,7 @@
 //   bloom    : bit idx = h0 % bits at byte idx/8, bit idx%8 (LSB first).
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -30,6 +31,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -47,10 +49,13 @@ using namespace nts;
 // counterpart is this mark.
 namespace nts_mem {
 std::mutex mu;
+struct Slab;
 struct Block
 {
   size_t bytes;
-  int device;
+  int device;     // -1: allocated with flags (never cached)
+  Slab* slab;     // the cached allocation the block was cut from; nullptr: a hipMalloc of its own
+  size_t off;
 };
 std::map<void*, Block> sizes;
 std::atomic<uint64_t> live{0}, peak{0};
@@ -66,17 +71,32 @@ struct AllocClock
   }
 };
 
-// Freed blocks are kept (per device, up to CACHE_LIMIT bytes in all) and handed out again to requests of nearly their size.  On some
-// boxes of the pool this build runs on a hipMalloc of a few hundred MB takes 20-100 ms (the driver's round-4 line: 94.8 ms for the
-// first sketch of a fresh genome; a builder box in round 5: 45.9 ms in the 41 allocations of a context's first sketch and 111.9 ms in the
-// FIVE allocations of a later genome's 2-bit image and tables, where the box next to it takes 0.04 ms: bench.py `cold`), and every
-// genome, filter and context of a run allocates and frees: 2-bit images, tables, 14.8 GB filters, the build's 25 GB of buckets when a
-// context closes and the next one opens.  A block goes back to the driver when the cache is full, when an allocation fails (the
-// cache is emptied and the allocation tried again) and on nts_mem_trim.  `live` / `peak` count blocks in use, not cached ones.
-constexpr uint64_t CACHE_LIMIT = 64ull << 30;
-constexpr size_t CACHE_MIN_BLOCK = 64u << 10;
-std::multimap<std::pair<int, size_t>, void*> cache; // (device, bytes) -> block
-uint64_t cached_bytes = 0;
+// Freed blocks are kept (up to CACHE_LIMIT bytes in all) and handed out again, whole or IN PIECES: a freed hipMalloc allocation becomes a
+// "slab" whose free ranges are indexed by size; a request takes the smallest free range that holds it and leaves the rest of the range
+// in the index; a piece that comes back is joined with its free neighbours.  Why: on some boxes of the pool this build runs on a
+// hipMalloc takes 20-100 ms now and then (the driver's round-4 line: 94.8 ms for the first sketch of a fresh genome; builder boxes in
+// round 5: 45.9 and 98.6 ms in the 41 allocations of a process's first sketch, 111.9 ms in the FIVE allocations of a later genome's
+// 2-bit image and tables, where the box next to it takes 0.04 ms: bench.py `cold`), and every genome, filter and context of a run
+// allocates and frees: 2-bit images, tables, 14.8 GB filters, the FASTA ingest's 3 GB image given back before the first sketch.  With
+// exact-size reuse only (round 5's first version) the first sketch of a process still went to the driver 41 times -- nothing it asks
+// for has the size of anything freed before it; cut from what the ingest or an earlier filter left, it does not.  A slab goes back to
+// the driver when it is wholly free and the cache is over its limit, when an allocation fails (every wholly free slab is released
+// and the allocation tried again) and on nts_mem_trim.  `live` / `peak` count blocks in use, not cached ranges.
+constexpr uint64_t CACHE_LIMIT = 96ull << 30;
+constexpr size_t CACHE_MIN_BLOCK = 64u << 10; // smaller requests go to the driver as they are (its own small-block pool serves them)
+constexpr size_t GRAIN = 4096;                 // cached requests are rounded up to this; pieces are cut at multiples of it
+struct Slab
+{
+  char* base;
+  size_t bytes;
+  int device;
+  std::map<size_t, size_t> free; // offset -> length of the free ranges, none adjacent to another
+  size_t in_use = 0;
+};
+typedef std::tuple<int, size_t, char*> FreeKey; // (device, length, address): lower_bound = the smallest range that holds a request
+std::map<FreeKey, Slab*> free_index;
+std::set<Slab*> slabs;
+uint64_t cached_bytes = 0; // sum of the free ranges
 std::atomic<uint64_t> cache_hits{0};
 
 inline void count_live(size_t n)
@@ -87,59 +107,115 @@ inline void count_live(size_t n)
   }
 }
 
-// every cached block back to the driver; returns the bytes released
+// (callers hold `mu`)
+inline void range_add(Slab* sl, size_t off, size_t len)
+{
+  sl->free[off] = len;
+  free_index[FreeKey(sl->device, len, sl->base + off)] = sl;
+  cached_bytes += len;
+}
+inline void range_del(Slab* sl, size_t off, size_t len)
+{
+  sl->free.erase(off);
+  free_index.erase(FreeKey(sl->device, len, sl->base + off));
+  cached_bytes -= len;
+}
+// [off, off + len) of the slab is free again: joined with the free ranges that touch it
+inline void range_release(Slab* sl, size_t off, size_t len)
+{
+  auto next = sl->free.find(off + len);
+  if (next != sl->free.end()) {
+    const size_t nl = next->second;
+    range_del(sl, off + len, nl);
+    len += nl;
+  }
+  auto prev = sl->free.lower_bound(off);
+  if (prev != sl->free.begin()) {
+    --prev;
+    if (prev->first + prev->second == off) {
+      const size_t po = prev->first, pl = prev->second;
+      range_del(sl, po, pl);
+      off = po;
+      len += pl;
+    }
+  }
+  range_add(sl, off, len);
+}
+// wholly free slabs leave the cache while it holds more than `limit` bytes (the largest first); the caller frees what `gone` collects
+inline void shed(uint64_t limit, std::vector<void*>& gone)
+{
+  while (cached_bytes > limit) {
+    Slab* pick = nullptr;
+    for (Slab* sl : slabs)
+      if (sl->in_use == 0 && (!pick || sl->bytes > pick->bytes)) pick = sl;
+    if (!pick) break;
+    range_del(pick, 0, pick->bytes); // (wholly free: one range)
+    gone.push_back(pick->base);
+    slabs.erase(pick);
+    delete pick;
+  }
+}
+
+// every wholly free slab back to the driver; returns the bytes released
 inline uint64_t trim()
 {
   std::vector<void*> gone;
-  uint64_t bytes = 0;
+  uint64_t before = 0, after = 0;
   {
     std::lock_guard<std::mutex> g(mu);
-    for (auto& kv : cache) gone.push_back(kv.second);
-    bytes = cached_bytes;
-    cache.clear();
-    cached_bytes = 0;
+    before = cached_bytes;
+    shed(0, gone);
+    after = cached_bytes;
   }
   for (void* q : gone) {
     AllocClock clk;
     ::hipFree(q);
   }
-  return bytes;
+  return before - after;
 }
 
 inline hipError_t dev_malloc(void** p, size_t n)
 {
   int dev = 0;
   ::hipGetDevice(&dev);
-  if (n >= CACHE_MIN_BLOCK) {
+  const bool cached_kind = n >= CACHE_MIN_BLOCK;
+  const size_t need = cached_kind ? (n + GRAIN - 1) / GRAIN * GRAIN : n;
+  if (cached_kind) {
     std::lock_guard<std::mutex> g(mu);
-    auto it = cache.lower_bound({ dev, n });
-    if (it != cache.end() && it->first.first == dev && it->first.second <= n + n / 4 + (1u << 20)) {
-      *p = it->second;
-      const size_t bytes = it->first.second;
-      cache.erase(it);
-      cached_bytes -= bytes;
-      sizes[*p] = { bytes, dev };
+    auto it = free_index.lower_bound(FreeKey(dev, need, nullptr));
+    if (it != free_index.end() && std::get<0>(it->first) == dev) {
+      Slab* sl = it->second;
+      const size_t len = std::get<1>(it->first), off = (size_t)(std::get<2>(it->first) - sl->base);
+      range_del(sl, off, len);
+      size_t take = need;
+      if (len - need >= CACHE_MIN_BLOCK)
+        range_add(sl, off + need, len - need); // (what is left stays in the index; a sliver that no request could use goes along)
+      else
+        take = len;
+      sl->in_use += take;
+      *p = sl->base + off;
+      sizes[*p] = { take, dev, sl, off };
       cache_hits.fetch_add(1);
-      count_live(bytes);
+      count_live(take);
       return hipSuccess;
     }
   }
   hipError_t e;
   {
     AllocClock clk;
-    e = ::hipMalloc(p, n);
+    e = ::hipMalloc(p, need);
   }
   if (e == hipErrorOutOfMemory && trim() > 0) { // (what the cache held may be what was missing)
     (void)hipGetLastError();
     AllocClock clk;
-    e = ::hipMalloc(p, n);
+    e = ::hipMalloc(p, need);
   }
   if (e == hipSuccess && *p) {
     {
       std::lock_guard<std::mutex> g(mu);
-      sizes[*p] = { n, dev };
+      sizes[*p] = { need, dev, nullptr, 0 };
     }
-    count_live(n);
+    count_live(need);
   }
   return e;
 }
@@ -158,7 +234,7 @@ inline hipError_t dev_malloc_flags(void** p, size_t n, unsigned flags)
   if (e == hipSuccess && *p) {
     {
       std::lock_guard<std::mutex> g(mu);
-      sizes[*p] = { n, -1 };
+      sizes[*p] = { n, -1, nullptr, 0 };
     }
     count_live(n);
   }
@@ -168,7 +244,7 @@ inline hipError_t dev_malloc_flags(void** p, size_t n, unsigned flags)
 inline hipError_t dev_free(void* p)
 {
   if (!p) return hipSuccess;
-  Block blk = { 0, -1 };
+  Block blk = { 0, -1, nullptr, 0 };
   bool known = false;
   {
     std::lock_guard<std::mutex> g(mu);
@@ -176,26 +252,64 @@ inline hipError_t dev_free(void* p)
     if (it != sizes.end()) {
       blk = it->second;
       known = true;
-      live.fetch_sub(blk.bytes);
-      sizes.erase(it);
     }
   }
   if (known && blk.device >= 0 && blk.bytes >= CACHE_MIN_BLOCK) {
     // what hipFree does before it gives memory back: nothing queued on the device still uses the block (it may be handed to another
-    // stream or context next)
+    // stream or context next).  The block stays in `sizes` until then: nobody else can be given its range.
     int cur = 0;
     ::hipGetDevice(&cur);
     if (cur != blk.device) ::hipSetDevice(blk.device);
     const hipError_t es = ::hipDeviceSynchronize();
     if (cur != blk.device) ::hipSetDevice(cur);
-    if (es == hipSuccess) {
+    std::vector<void*> gone;
+    bool kept = false;
+    {
       std::lock_guard<std::mutex> g(mu);
-      if (cached_bytes + blk.bytes <= CACHE_LIMIT) {
-        cache.insert({ { blk.device, blk.bytes }, p });
-        cached_bytes += blk.bytes;
-        return hipSuccess;
+      sizes.erase(p);
+      live.fetch_sub(blk.bytes);
+      if (blk.slab) { // a piece of a cached allocation goes back to it whatever happened (the slab is freed as a whole, or not at all)
+        blk.slab->in_use -= blk.bytes;
+        range_release(blk.slab, blk.off, blk.bytes);
+        kept = true;
+      } else if (es == hipSuccess) {
+        Slab* sl = new Slab();
+        sl->base = (char*)p;
+        sl->bytes = blk.bytes;
+        sl->device = blk.device;
+        slabs.insert(sl);
+        range_add(sl, 0, blk.bytes);
+        kept = true;
       }
+      if (kept) shed(CACHE_LIMIT, gone);
     }
+    for (void* q : gone) {
+      AllocClock clk;
+      ::hipFree(q);
+    }
+    if (kept) return hipSuccess;
+    AllocClock clk;
+    return ::hipFree(p);
+  }
+  if (known) {
+    std::lock_guard<std::mutex> g(mu);
+    sizes.erase(p);
+    live.fetch_sub(blk.bytes);
+  } else {
+    // not a block in use.  Inside a cached allocation it is a second free of a piece (or of the allocation itself): giving the address
+    // to hipFree would take the whole allocation away from under the cache and the pieces in use -- refused, and said once
+    std::lock_guard<std::mutex> g(mu);
+    for (Slab* sl : slabs)
+      if ((char*)p >= sl->base && (char*)p < sl->base + sl->bytes) {
+        static bool said = false;
+        if (!said) {
+          said = true;
+          fprintf(stderr, "ntsynt_hip: device block %p freed twice (ignored)\n", p);
+          void* bt[24];
+          backtrace_symbols_fd(bt, backtrace(bt, 24), 2);
+        }
+        return hipErrorInvalidValue;
+      }
   }
   AllocClock clk;
   return ::hipFree(p);

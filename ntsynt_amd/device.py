@@ -24,6 +24,7 @@ class Context:
     def __init__(self, device=0, variant=None):
         "variant: None = the product build of the library; 'experiments' = the build with the experiment switches (tests, measurements)"
         self.lib = _lib.load(variant)
+        self.variant = variant                 # (contexts that share device memory come from ONE build: each build has its own allocation cache)
         h = c_vp()
         rc = self.lib.nts_init(int(device), ctypes.byref(h))
         if rc != 0:
@@ -152,6 +153,10 @@ class Context:
     def trim_ingest(self):
         "give back the FASTA ingest's workspaces (the raw image of the largest file, pinned staging): nts_ingest_trim"
         self.check(self.lib.nts_ingest_trim(self.h), "nts_ingest_trim")
+
+    def trim_bf_build(self):
+        "the Bloom build's bucket arrays back to the allocation cache (the run's last filter is made): nts_bf_build_trim"
+        self.check(self.lib.nts_bf_build_trim(self.h), "nts_bf_build_trim")
 
     def close(self):
         if self.h:
@@ -600,7 +605,7 @@ class SketchPool:
 
     def __init__(self, ctx, n):
         self.main = ctx
-        self.ctxs = [ctx] + [Context(ctx.device) for _ in range(max(0, int(n) - 1))]
+        self.ctxs = [ctx] + [Context(ctx.device, ctx.variant) for _ in range(max(0, int(n) - 1))]
         self._pool = None
 
     def configure(self, fn):

@@ -530,7 +530,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         # files in the order the filter takes them (sorted: src/ntsynt_make_common_bf.cpp:105-107), on a context of their own
         from .device import Context
         n_loaders = max(1, min(int(os.environ.get("NTS_LOADERS", "1")), len(mine)))
-        load_ctxs = [Context(backend.device) for _ in range(n_loaders)]
+        load_ctxs = [Context(backend.device, backend.ctx.variant) for _ in range(n_loaders)]      # (the build of the library the run's context is from: one allocation cache)
         genomes = _Arriving(sorted(mine), [(lambda p, c=c: fa.read_fasta_device(c, p)[0]) for c in load_ctxs], arrived)
         try:
             genomes[sorted(mine)[0]]                           # the first one sizes the filter
@@ -688,6 +688,8 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
             else:
                 backend.allreduce_and(bf)                      # GpuBackend: nts_bf_allreduce_and; test doubles bring their own
         log(f"Final Bloom filter FPR: {backend.bf_fpr(bf)}")
+        if isinstance(backend, GpuBackend):
+            backend.ctx.trim_bf_build()                       # (the run builds no further filter: the buckets serve what is allocated next)
         st.stop()
         st.mark("common_filter_done")
     if overlap_load:

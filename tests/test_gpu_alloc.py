@@ -1,0 +1,80 @@
+"""The library's device allocation cache (csrc/ntsynt_hip.hip, namespace nts_mem): freed allocations are kept and handed out again whole
+or in pieces; pieces that come back are joined with their free neighbours; nts_mem_trim gives wholly free allocations back to the
+driver.  Observed through filters of chosen sizes (BloomFilter = one allocation of its byte count), nts_alloc_stats (calls of hipMalloc /
+hipFree made by the library) and nts_mem_cache_stats."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MB = 1 << 20
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ntsynt_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _calls(ctx):
+    return ctx.alloc_stats()[0]
+
+
+def test_freed_allocation_is_cut_into_pieces_and_joined_again(ctx):
+    from ntsynt_amd.device import BloomFilter
+    ctx.sync()
+    ctx.mem_trim()                                            # (start from an empty cache: what other tests left is gone)
+    assert ctx.mem_cache_stats()[0] == 0
+    big = BloomFilter(ctx, 64 * MB, 24)
+    c0 = _calls(ctx)
+    big.free()                                                # kept: no hipFree
+    assert _calls(ctx) == c0 and ctx.mem_cache_stats()[0] == 64 * MB
+    hits0 = ctx.mem_cache_stats()[1]
+    parts = [BloomFilter(ctx, 8 * MB, 24) for _ in range(4)]  # four pieces of the kept allocation: no hipMalloc
+    assert _calls(ctx) == c0 and ctx.mem_cache_stats() == (32 * MB, hits0 + 4)
+    # the pieces are separate memory: each filter keeps its own bits
+    for i, f in enumerate(parts):
+        f.from_numpy(np.full(8 * MB, i + 1, dtype=np.uint8))
+    for i, f in enumerate(parts):
+        got = f.to_numpy()
+        assert got[0] == i + 1 and got[-1] == i + 1 and int(got.sum(dtype=np.uint64)) == (i + 1) * 8 * MB
+    # freed out of order, they join: the whole allocation is one range again and serves a request of its full size
+    for i in (1, 3, 0, 2):
+        parts[i].free()
+    assert ctx.mem_cache_stats()[0] == 64 * MB and _calls(ctx) == c0
+    again = BloomFilter(ctx, 64 * MB, 24)
+    assert _calls(ctx) == c0 and ctx.mem_cache_stats()[0] == 0
+    # a request larger than anything kept goes to the driver; a partly used allocation stays when the cache is trimmed
+    half = None
+    again.free()
+    half = BloomFilter(ctx, 40 * MB, 24)                      # piece of the 64 MB allocation
+    assert ctx.mem_cache_stats()[0] == 24 * MB
+    bigger = BloomFilter(ctx, 100 * MB, 24)
+    assert _calls(ctx) == c0 + 1
+    assert ctx.mem_trim() == 0 and ctx.mem_cache_stats()[0] == 24 * MB          # (nothing wholly free)
+    half.free()
+    assert ctx.mem_cache_stats()[0] == 64 * MB
+    assert ctx.mem_trim() == 64 * MB and ctx.mem_cache_stats()[0] == 0 and _calls(ctx) == c0 + 2
+    bigger.free()
+    assert ctx.mem_trim() >= 100 * MB
+
+
+def test_small_requests_and_odd_sizes(ctx):
+    "requests below 64 KiB go to the driver as they are; sizes that are no multiple of the grain are rounded up and still join"
+    from ntsynt_amd.device import BloomFilter
+    ctx.sync()
+    ctx.mem_trim()
+    a = BloomFilter(ctx, 3 * MB + 8, 24)
+    b = BloomFilter(ctx, 1024, 24)
+    a.free()
+    b.free()
+    kept = ctx.mem_cache_stats()[0]
+    assert 3 * MB + 8 <= kept < 3 * MB + 8 + 8192             # (the small one is not kept)
+    c = BloomFilter(ctx, MB + 8, 24)
+    d = BloomFilter(ctx, MB + 16, 24)
+    c.free()
+    d.free()
+    assert ctx.mem_cache_stats()[0] == kept
+    ctx.mem_trim()
