@@ -178,9 +178,11 @@ inline hipError_t dev_malloc(void** p, size_t n)
 {
   int dev = 0;
   ::hipGetDevice(&dev);
+  // (a small request is served by a piece of a kept allocation like any other; when nothing is kept it goes to the driver as it is and
+  //  is not kept afterwards: the driver's own small-block pool serves those)
   const bool cached_kind = n >= CACHE_MIN_BLOCK;
-  const size_t need = cached_kind ? (n + GRAIN - 1) / GRAIN * GRAIN : n;
-  if (cached_kind) {
+  const size_t need = (n + GRAIN - 1) / GRAIN * GRAIN;
+  if (n) {
     std::lock_guard<std::mutex> g(mu);
     auto it = free_index.lower_bound(FreeKey(dev, need, nullptr));
     if (it != free_index.end() && std::get<0>(it->first) == dev) {
@@ -203,19 +205,19 @@ inline hipError_t dev_malloc(void** p, size_t n)
   hipError_t e;
   {
     AllocClock clk;
-    e = ::hipMalloc(p, need);
+    e = ::hipMalloc(p, cached_kind ? need : n);
   }
   if (e == hipErrorOutOfMemory && trim() > 0) { // (what the cache held may be what was missing)
     (void)hipGetLastError();
     AllocClock clk;
-    e = ::hipMalloc(p, need);
+    e = ::hipMalloc(p, cached_kind ? need : n);
   }
   if (e == hipSuccess && *p) {
     {
       std::lock_guard<std::mutex> g(mu);
-      sizes[*p] = { need, dev, nullptr, 0 };
+      sizes[*p] = { cached_kind ? need : n, dev, nullptr, 0 };
     }
-    count_live(need);
+    count_live(cached_kind ? need : n);
   }
   return e;
 }
@@ -254,7 +256,7 @@ inline hipError_t dev_free(void* p)
       known = true;
     }
   }
-  if (known && blk.device >= 0 && blk.bytes >= CACHE_MIN_BLOCK) {
+  if (known && blk.device >= 0 && (blk.slab || blk.bytes >= CACHE_MIN_BLOCK)) {
     // what hipFree does before it gives memory back: nothing queued on the device still uses the block (it may be handed to another
     // stream or context next).  The block stays in `sizes` until then: nobody else can be given its range.
     int cur = 0;

@@ -78,3 +78,23 @@ def test_small_requests_and_odd_sizes(ctx):
     d.free()
     assert ctx.mem_cache_stats()[0] == kept
     ctx.mem_trim()
+
+
+def test_small_request_is_cut_from_a_kept_allocation(ctx):
+    "below 64 KiB too, when something is kept: no driver call; the piece goes back where it came from"
+    from ntsynt_amd.device import BloomFilter
+    ctx.sync()
+    ctx.mem_trim()
+    a = BloomFilter(ctx, 2 * MB, 24)
+    a.free()
+    c0 = _calls(ctx)
+    small = [BloomFilter(ctx, 8 * (i + 1), 24) for i in range(5)]
+    assert _calls(ctx) == c0 and ctx.mem_cache_stats()[0] == 2 * MB - 5 * 4096
+    for i, f in enumerate(small):
+        f.from_numpy(np.full(8 * (i + 1), 7 * i + 1, dtype=np.uint8))
+    for i, f in enumerate(small):
+        assert set(f.to_numpy().tolist()) == {7 * i + 1}
+    for f in small:
+        f.free()
+    assert ctx.mem_cache_stats()[0] == 2 * MB and _calls(ctx) == c0
+    assert ctx.mem_trim() == 2 * MB
