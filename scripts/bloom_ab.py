@@ -1,5 +1,5 @@
 """A/B of two builds of the library on the Bloom build of one 3 Gbp genome in ONE process, alternating (scripts/valley_ab.py for the why):
-insert into an empty filter, then one fused cascade level.   REPS=8 python scripts/bloom_ab.py"""
+insert into an empty filter, then one fused cascade level.   REPS=8 [FAMILY=assembly-like] python scripts/bloom_ab.py"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from ntsynt_amd.device import Context, Genome, BloomFilter, bf_size_bytes
@@ -8,8 +8,13 @@ total = int(mbp * 1e6)
 side = {}
 for name, variant in (("product", None), ("experiments", "experiments")):
     ctx = Context(0, variant=variant)
-    g0 = Genome.synth(ctx, total, 24, 20240207, 1000, 0.005)
-    g1 = Genome.synth(ctx, total, 24, 20240207, 1001, 0.005)
+    if os.environ.get("FAMILY"):                      # FAMILY=assembly-like: bench.py's c5-like genomes (scaffold tails, N gaps, repeats)
+        import argparse, bench
+        a = argparse.Namespace(family=os.environ["FAMILY"], substitutions_only=False)
+        g0, g1 = (bench.family_genome(ctx, a, total, 24, j, 0.0065) for j in range(2))
+    else:
+        g0 = Genome.synth(ctx, total, 24, 20240207, 1000, 0.005)
+        g1 = Genome.synth(ctx, total, 24, 20240207, 1001, 0.005)
     _, nb = bf_size_bytes(g0.total_bp, 0.025)
     bf = BloomFilter(ctx, nb, k)
     for _ in range(2):
