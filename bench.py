@@ -413,11 +413,27 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
     if paths is None:
         paths = e2e_inputs(args, device, n_fam, total_bp, contigs, div, workdir)
     t_write = time.time() - t
+    if os.environ.get("BENCH_E2E_INPROCESS") != "1" and not getattr(args, "e2e_is_child", False):
+        # A user's run is a process of its own: so is this one (python bench.py --e2e-child <spec>: the timed region is pipeline.run
+        # inside it, as before -- with the code object loaded and every allocation made there, nothing inherited from the legs before.
+        # Round 5's first form ran it here after emptying the library's allocation cache; on boxes whose driver clears freed memory
+        # lazily the run then waited for 60-100 GB of that: 3 s in front of the first insert, which no user's run sees.)
+        import subprocess
+        spec = {"args": {k_: v_ for k_, v_ in vars(args).items() if isinstance(v_, (int, float, str, bool, type(None)))}, "device": device,
+                "n_fam": n_fam, "total_bp": total_bp, "contigs": contigs, "div": div, "workdir": workdir, "paths": paths}
+        spec_path = os.path.join(workdir, "e2e_child.json")
+        with open(spec_path, "w") as fh:
+            json.dump(spec, fh)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-child", spec_path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+        lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("E2E_CHILD_RESULT ")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError("the end-to-end run's process failed: " + r.stderr.decode()[-2000:])
+        out = json.loads(lines[-1][len("E2E_CHILD_RESULT "):])
+        out["write_inputs_s"] = round(t_write, 1)
+        out["process"] = "a process of its own (python bench.py --e2e-child): nothing inherited from the legs before it"
+        return out
     a, divergence_pct = e2e_params(args, paths, div)
-    # a user's run starts in a fresh process: what the earlier legs of this one left in the library's allocation cache goes back to the
-    # driver first (the pipeline's own frees and allocations -- loader contexts, per-level workspaces -- still use the cache, as they would there)
-    from ntsynt_amd import _lib
-    cache_released = int(_lib.load().nts_mem_trim())
+    cache_released = 0
     cwd = os.getcwd()
     os.chdir(workdir)
     try:
@@ -590,7 +606,7 @@ class Rig:
         self.n_all = None
         self.t_sketch = 0.0                          # seconds spent in the sketch calls of step() (reset by the caller around a timed region)
 
-    def build_filter(self, again=False, levels=False):
+    def build_filter(self, again=False, levels=False, trim=False):
         "per-genome filters, local cascade, exchange 1; returns the timings"
         self.levels = []
         from ntsynt_amd.device import BloomFilter, bf_size_bytes
@@ -645,7 +661,8 @@ class Rig:
         for f_ in extra:
             f_.free()
         self.common = common
-        ctx.trim_bf_build()                          # as the pipeline does once its common filter stands (pipeline.run): the buckets go to the allocation cache
+        if trim:
+            ctx.trim_bf_build()                      # as the pipeline does once its common filter stands (pipeline.run): the buckets go to the allocation cache
         return {"build_s": t_build, "build_again_s": t_warm, "allreduce_s": t_allreduce, "occ_single": occ_single}
 
     def step(self, pool=None):
@@ -813,7 +830,18 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def e2e_child(spec_path):
+    "the end-to-end leg's own process: runs the pipeline on the files the parent wrote, prints the leg's record"
+    spec = json.load(open(spec_path))
+    a = argparse.Namespace(**spec["args"])
+    a.e2e_is_child = True
+    out = e2e_leg(a, spec["device"], spec["n_fam"], spec["total_bp"], spec["contigs"], spec["div"], spec["workdir"], paths=spec["paths"])
+    print("E2E_CHILD_RESULT " + json.dumps(out), flush=True)
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--e2e-child":
+        return e2e_child(sys.argv[2])
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))                     # (plain `python bench.py --gpus N`: the ranks are ours to start)
@@ -863,7 +891,7 @@ def main():
     genomes, units, mine, fam_bases, bases, t_synth = rig.genomes, rig.units, rig.mine, rig.fam_bases, rig.bases, rig.t_synth
     shard = rig.plan
     ctx.profile(True)
-    bt = rig.build_filter(again=True)
+    bt = rig.build_filter(again=True, trim=True)    # (the headline rig does what a run does; the later legs' rigs keep their buckets for one another)
     common, nbytes = rig.common, rig.nbytes
     t_build, t_build_warm, t_allreduce, occ_single = bt["build_s"], bt["build_again_s"], bt["allreduce_s"], bt["occ_single"]
     ins_ms, ins_n = ctx.timing("bf_insert")
