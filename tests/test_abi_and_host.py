@@ -373,3 +373,18 @@ def test_bf_file_layout_round_trip_and_rejections(tmp_path):
     open(bad, "wb").write(bf_header(bits.size, 24, hash_num=3) + bits.tobytes())
     with pytest.raises(ValueError, match="hash functions"):
         read_bf(bad)
+
+
+def test_stage3_filter_switch_rules_without_a_gpu(capsys):
+    """bin/ntsynt_synteny.py:598-599: `--filter` needs `--repeat` (the reference's ValueError, same text); `--filter Filter` with
+    --initial-only is refused before anything touches a device"""
+    from ntsynt_amd import stage_cli
+    base = ["a.fa.k24.w1000.tsv", "--fastas", "a.fa", "-k", "24", "-w", "1000"]
+    a = stage_cli.run_parser().parse_args(base + ["--filter", "Indexlr", "--repeat", "r.bf"])
+    assert (a.filter, a.repeat) == ("Indexlr", "r.bf")
+    with pytest.raises(ValueError, match="must supply repeat Bloom filter with --repeat"):
+        stage_cli.run(base + ["--filter", "Filter"])
+    assert stage_cli.run(base + ["--filter", "Filter", "--repeat", "r.bf", "--initial-only"]) == 2
+    assert "not with --initial-only" in capsys.readouterr().err
+    with pytest.raises(SystemExit):
+        stage_cli.run_parser().parse_args(base + ["--filter", "Other"])
