@@ -159,13 +159,27 @@ def collinear_merge_bp(text, w):
     raise ValueError("--collinear-merge must be provided with an integer value or string in the form '<num>w'")
 
 
+FAI_RE = re.compile(r'^(\S+).k\d+.w\d+.tsv')          # bin/ntsynt_synteny.py:25, as written there (unescaped dots, no end anchor)
+
+
+def fasta_name_of(tsv_name):
+    """bin/ntsynt_synteny.py:108-116 (find_fa_name): the FASTA a minimizer TSV belongs to is its name up to '.k<k>.w<w>.tsv'; a name
+    that does not follow the convention ends the run with the reference's message and exit status 1"""
+    m = FAI_RE.search(tsv_name)
+    if m:
+        return m.group(1)
+    print("ERROR: Target assembly minimizer TSV file must follow the naming convention:")
+    print("\ttarget_assembly.fa.k<k>.w<w>.tsv, where <k> and <w> are parameters used for minimizering")
+    sys.exit(1)
+
+
 def pair_files(tsvs, fastas):
     """the FASTA of every minimizer TSV: '<basename of the FASTA>.k<k>.w<w>.tsv' (rule indexlr's output name, smk:78; the reference
-    matches them the same way, by the name with the suffix stripped: synteny_block.py:14,76-77, S:137)"""
+    matches them the same way, by the name with the suffix stripped: synteny_block.py:14,76-77, S:137-144)"""
     by_base = {os.path.basename(f): f for f in fastas}
     out = []
     for t in tsvs:
-        base = re.sub(r"\.k\d+\.w\d+\.tsv$", "", os.path.basename(t))
+        base = fasta_name_of(os.path.basename(t))
         if base not in by_base:
             raise ValueError(f"{t}: no FASTA named {base} among --fastas")
         out.append(by_base[base])

@@ -506,14 +506,9 @@ class SyntenyOracle:
             records = kept
         return mx_tables_from_tokens(records)
 
-    def new_minimizers(self, blocks, new_w, prev_w):               # S:532-541
-        masks = self.mask_intervals(blocks, prev_w)
-        list_mxs, new_info = {}, {}
-        # S:138 iterates the assemblies that appear in synteny_beds (block.assembly_blocks order)
-        order = list(blocks[0].asm) if blocks else []
-        for a in order:
-            new_info[a], list_mxs[a] = self.sketch_masked(a, masks.get(a, {}), new_w)
-        terminal, internal, spans = set(), set(), defaultdict(dict)    # S:205-226
+    def block_marks(self, blocks):                                 # S:205-226 (find_mx_in_blocks) + S:194-203 (update_intervals)
+        "(terminal minimizers, internal minimizers, {assembly: {contig: [(lo + 1, hi)]}}) of the blocks"
+        terminal, internal, spans = set(), set(), defaultdict(dict)
         for blk in blocks:
             for a, ab in blk.asm.items():
                 first, last = ab.minimizers[0], ab.minimizers[-1]
@@ -523,8 +518,14 @@ class SyntenyOracle:
                 if hi - lo >= 2:                                     # S:199
                     spans[a].setdefault(ab.contig_id, []).append((lo + 1, hi))
                 internal.update(h for h, _ in ab.minimizers[1:-1])
+        return terminal, internal, spans
+
+    @staticmethod
+    def filter_lists(list_mxs, internal, new_info, spans):          # S:256-280 (filter_minimizers_synteny_blocks)
+        """Minimizers of the re-sketch that are neither internal to a block nor inside a block's interior; a list is cut where the
+        stretch between two kept neighbours reaches into an interior.  Interval queries are half-open (u11)."""
         idx = {a: {c: _IntervalSet(v) for c, v in d.items()} for a, d in spans.items()}
-        filt = {}                                                       # S:256-280
+        filt = {}
         for a in list_mxs:
             out_lists = []
             for lst in list_mxs[a]:
@@ -541,12 +542,26 @@ class SyntenyOracle:
                         cur.append(h)
                 out_lists.append(cur)
             filt[a] = out_lists
-        filt = filter_minimizers(filt)                                  # S:539
-        valid = {h for ls in filt.values() for lst in ls for h in lst}  # S:282-290
+        return filt
+
+    def update_info(self, filt, new_info):                          # S:282-290 (update_list_mx_info)
+        valid = {h for ls in filt.values() for lst in ls for h in lst}
         for a, info in new_info.items():
             for h in info:
                 if h in valid:
                     self.list_mx_info[a][h] = info[h]
+
+    def new_minimizers(self, blocks, new_w, prev_w):               # S:532-541
+        masks = self.mask_intervals(blocks, prev_w)
+        list_mxs, new_info = {}, {}
+        # S:138 iterates the assemblies that appear in synteny_beds (block.assembly_blocks order)
+        order = list(blocks[0].asm) if blocks else []
+        for a in order:
+            new_info[a], list_mxs[a] = self.sketch_masked(a, masks.get(a, {}), new_w)
+        terminal, internal, spans = self.block_marks(blocks)
+        filt = self.filter_lists(list_mxs, internal, new_info, spans)
+        filt = filter_minimizers(filt)                                  # S:539
+        self.update_info(filt, new_info)
         return filt, terminal
 
     # -- last-round erosion: S:292-362 (row C12) ------------------------------------------------------
