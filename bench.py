@@ -419,7 +419,8 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
         # Round 5's first form ran it here after emptying the library's allocation cache; on boxes whose driver clears freed memory
         # lazily the run then waited for 60-100 GB of that: 3 s in front of the first insert, which no user's run sees.)
         import subprocess
-        spec = {"args": {k_: v_ for k_, v_ in vars(args).items() if isinstance(v_, (int, float, str, bool, type(None)))}, "device": device,
+        child_args = {k_: v_ for k_, v_ in vars(args).items() if isinstance(v_, (int, float, str, bool, type(None)))}
+        spec = {"args": child_args, "device": device,
                 "n_fam": n_fam, "total_bp": total_bp, "contigs": contigs, "div": div, "workdir": workdir, "paths": paths}
         spec_path = os.path.join(workdir, "e2e_child.json")
         with open(spec_path, "w") as fh:
@@ -434,6 +435,9 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
         return out
     a, divergence_pct = e2e_params(args, paths, div)
     cache_released = 0
+    from ntsynt_amd import _lib
+    from ntsynt_amd.device import mem_events, mem_events_since
+    ev0 = mem_events(_lib.load())
     cwd = os.getcwd()
     os.chdir(workdir)
     try:
@@ -471,6 +475,10 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
             "peak_hbm_bytes": (eng.memory or {}).get("peak_hbm_bytes"), "peak_host_rss_bytes": (eng.memory or {}).get("peak_host_rss_bytes"),
             "hbm_live_at_marks_GB": {n: round(v / 1e9, 2) for n, v in ((eng.memory or {}).get("hbm_live_at_marks") or {}).items()},
             "allocation_cache_released_before_the_run_GB": round(cache_released / 1e9, 2),
+            # what the run asked of the driver (one reserve call sized from the files, ntsynt_amd.pipeline.reserve_for_run; anything
+            # else is a request the plan did not cover) and what other processes held of the GPU's memory when it started
+            "allocator": dict(mem_events_since(_lib.load(), ev0), reserved_GB=round(getattr(eng, "reserved_bytes", 0) / 1e9, 2)),
+            "device_memory_in_use_by_others_at_start_GB": getattr(args, "device_used_by_parent_GB", None),
             "write_inputs_s": round(t_write, 1)}
 
 
@@ -481,6 +489,7 @@ def c5_like_leg(args, ctx, device, total_bp, contigs, workdir):
     duplications, 600 / 1500 / 4000 scaffolds per genome + as many short ones, N gaps, half of the bases lower case in the files):
     Bloom build, sketch, and FASTA files -> final TSV, with the paths an i.i.d. family never takes counted."""
     import copy
+    ev5 = ctx.mem_events()
     from ntsynt_amd.device import BloomFilter, bf_size_bytes, sketch
     a5 = copy.copy(args)
     a5.family, a5.substitutions_only = "assembly-like", False
@@ -544,6 +553,7 @@ def c5_like_leg(args, ctx, device, total_bp, contigs, workdir):
     common.free()
     for g in gens:
         g.free()
+    out["allocator"] = ctx.mem_events_since(ev5)
     return out, a5, div
 
 
@@ -872,6 +882,22 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = Context(local_rank)
     ctx.sketch_mode(args.mode, args.prune_c)
+    # The line's legs build and free families of up to eight 3 Gbp genomes one after the other.  Round 5's driver box took 1.39 s for a
+    # filter build whose seven levels sum to 0.15 s: memory the leg before had given back to the driver was not ready when the next leg
+    # asked for it.  Now ONE driver allocation sized for the largest leg is made here (nts_mem_reserve) and every genome, filter and
+    # workspace of every leg is cut from it; each leg reports what it asked of the driver all the same (`allocator` in c4 / valley /
+    # c5_like / cold, `allocator` + `device_memory_in_use_by_others_at_start_GB` in the end-to-end runs, which are processes of their own
+    # and reserve their own plan: ntsynt_amd.pipeline.reserve_for_run).
+    from ntsynt_amd.pipeline import plan_bytes
+    arena_plan, arena_got, t_arena = 0, 0, 0.0
+    if os.environ.get("NTS_BENCH_ARENA", "1") != "0":
+        n_res = max(3, -(-8 // world)) if not args.workload or args.workload == "c3" else 3
+        per_genome = int((args.mbp or {"c2": 100, "c3": 3000, "c4": 3000}.get(args.workload or "c3", 3000)) * 1e6)
+        arena_plan = plan_bytes([per_genome] * n_res, args.fpr, True) + (44 << 30)     # (+ the headline family's filter and workspaces, live next to the leg's)
+        t_ar = time.time()
+        arena_got = ctx.mem_reserve(arena_plan)
+        t_arena = time.time() - t_ar
+    ev_start = ctx.mem_events()
     # The two exchanges run inside libntsynt_hip.so over RCCL (nts_bf_allreduce_and / _parts, nts_mx_allgather) and nowhere else:
     # a communicator that does not come up ends the run with its error (round 3 fell back to torch.distributed here)
     comm, exchanges, rccl_ranks, served_by = None, "none (one GPU)", 1, None
@@ -1038,19 +1064,25 @@ def main():
         for g in rig.genomes:
             g.free()
         rig.genomes, rig.units = [], []
+        ev4 = ctx.mem_events()
         r4 = Rig("c4", args, ctx, comm, world, rank, use_overrides=False)
         b4 = r4.build_filter(levels=(world == 1))
+        alloc4_build = ctx.mem_events_since(ev4)
         d4, n4 = timed(1, 2, level=0, step=r4.step)
         c4 = {"workload": f"c4: 8 synthetic {r4.mbp:g} Mbp genomes at 10% divergence, genome g on GPU g mod {world}",
               "n_gpus": world, "value_Gbases_s": round(sum(r4.fam_bases) * 2 / d4 / 1e9, 3), "ms_per_step": round(d4 / 2 * 1e3, 2),
               "common_filter_occupancy": r4.common.get_fpr(), "minimizers_per_step_rank0": n4, "minimizers_per_step_all_genomes": r4.n_all if world > 1 else n4,
               "common_filter_build_s": round(b4["build_s"], 4), "allreduce_and_s": round(b4["allreduce_s"], 4),
               "all_reduce_gathered_set_bit_indices": bool(comm.last_sparse()) if comm is not None else None,
-              "common_filter_levels": r4.levels or None, "balance": r4.balance}
+              "common_filter_levels": r4.levels or None, "balance": r4.balance,
+              # what the leg asked of the driver while it generated its genomes and built its filter, and over the whole leg
+              "allocator": {"genomes_and_filter_build": alloc4_build, "whole_leg": ctx.mem_events_since(ev4)}}
         r4.free()
         if world == 1 and not args.no_valley_leg:
+            evv = ctx.mem_events()
             valley = {"three_genomes_at_10pct": valley_leg(args, ctx, total_bp, contigs, 3, 0.10),
                       "eight_genomes_at_4pct": valley_leg(args, ctx, total_bp, contigs, 8, 0.04)}
+            valley["allocator"] = ctx.mem_events_since(evv)
         if world == 1:                                                  # the later legs of the N = 1 line work on the headline family again
             rig.genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in mine]
             rig.units = rig.genomes
@@ -1198,6 +1230,9 @@ def main():
                 "valu.mix, valu.peak": "profiles/r03_valu_mix.json (instruction classes counted from the ISA) priced at this run's measured issue rates"
                 if valu and "kernel" in valu else None},
             "constants": {"peak": "MI355X_MICROARCH.md: HBM3E 8 TB/s", "algorithmic_bytes_per_base": "SURVEY.md 8(d): 64 B per probe; DESIGN.md 4.1"}}
+        out["allocator"] = {"what": "one nts_mem_reserve at start, sized for the largest leg; every leg's genomes, filters and workspaces are cut from it",
+                            "arena_planned_GB": round(arena_plan / 1e9, 2), "arena_reserved_GB": round(arena_got / 1e9, 2), "reserve_s": round(t_arena, 4),
+                            "sketch_legs_after_the_reserve": ctx.mem_events_since(ev_start)}
         if cold:
             out["cold"] = cold
         if nruns:
@@ -1233,7 +1268,9 @@ def main():
                     g.free()                                         # e2e legs' peak-memory figures are the pipeline's own), the
                 if common is not None:                               # pipeline starts from files like a user's run
                     common.free()
-                ctx.close()
+                # (this process keeps its context and its reserved memory while the runs below have processes of their own: closing the
+                #  last context gives the memory back, and a driver that clears freed memory lazily makes the next process wait for it)
+                args.device_used_by_parent_GB = round(ctx.mem_stats()["device_used"] / 1e9, 2)
                 if c5 is not None:
                     sub = os.path.join(workdir, "c5_like")
                     os.makedirs(sub, exist_ok=True)

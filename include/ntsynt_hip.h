@@ -73,13 +73,23 @@ void nts_mem_reset_peak(void);
  * context without workspaces (the first sketch of a run: rule indexlr runs once per genome, bin/ntsynt_run_pipeline.smk:74-85) spends
  * allocating -- bench.py's `cold` leg takes the difference around a call. */
 int nts_alloc_stats(uint64_t* calls, double* ms);
-/* Device blocks the library frees are kept (up to 64 GB, per device) and handed out again to requests of nearly their size: on some
- * boxes a hipMalloc of a few hundred MB takes 20-100 ms, and every genome, filter and context of a run allocates and frees.  live /
- * peak of nts_mem_stats count blocks in use, not cached ones (device_used_bytes sees both).  nts_mem_trim gives every cached block back
- * to the driver (bytes released); an allocation that fails does so by itself and tries again.  nts_mem_cache_stats: bytes cached now,
- * allocations served from the cache. */
+/* Device blocks the library frees are kept (up to 96 GB in all) and handed out again, whole or in pieces: on some boxes a hipMalloc of
+ * a few hundred MB takes 20-100 ms, memory a process has just given back costs the next allocation a wait, and every genome, filter
+ * and context of a run allocates and frees.  Requests below 64 KB live in 8 MB slabs of their own (a long-lived small workspace never
+ * holds a large kept allocation).  live / peak of nts_mem_stats count blocks in use, not cached ones (device_used_bytes sees both).
+ * nts_mem_trim gives every cached block back to the driver (bytes released); an allocation that fails does so by itself and tries
+ * again; so does nts_destroy of the process's last context.  nts_mem_cache_stats: bytes cached now, allocations served from the cache.
+ * nts_mem_reserve: ONE driver allocation of `bytes` on `device` (less when the device has less to give; *reserved_bytes says), kept
+ * for the allocations to come -- a run that knows its plan (file sizes -> filter, build workspaces, resident genomes) asks the driver
+ * once, before its first file is read, and never again; may be called from a thread of its own.  Replaces nothing in the reference
+ * (it allocates two filters once, src/ntsynt_make_common_bf.cpp:121-137): it is what makes "allocated once" true of the GPU run.
+ * nts_mem_events: out[0..7] = hipMalloc + hipFree calls, ns spent in them, allocations served from the cache, allocations tried again
+ * after the cache was emptied, bytes taken from the driver, bytes given back, ns spent waiting for the device before a freed block was
+ * kept, nts_mem_reserve calls that got memory (process-wide, monotonic: take differences around a stage). */
 uint64_t nts_mem_trim(void);
 int nts_mem_cache_stats(uint64_t* cached_bytes, uint64_t* hits);
+int nts_mem_reserve(int device, uint64_t bytes, uint64_t* reserved_bytes);
+int nts_mem_events(uint64_t out[8]);
 
 /* ---- A1: Bloom filter sizing ----------------------------------------------------------------
  * replaces approximate_bf_size(), src/ntsynt_make_common_bf.cpp:28-40, and the byte rounding of

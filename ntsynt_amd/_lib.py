@@ -127,6 +127,8 @@ SYMBOLS = [
     ("nts_alloc_stats", ctypes.c_int, [c_vp, c_vp]),
     ("nts_mem_trim", ctypes.c_uint64, []),
     ("nts_mem_cache_stats", ctypes.c_int, [c_vp, c_vp]),
+    ("nts_mem_reserve", ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, c_vp]),
+    ("nts_mem_events", ctypes.c_int, [c_vp]),
     ("nts_mx_allgather_ex", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_vp), c_u32p, u32, u32, ctypes.POINTER(c_vp)]),
     ("nts_bf_allreduce_parts", ctypes.c_int, [c_vp, ctypes.POINTER(c_vp), u32, c_vp, u32, ctypes.POINTER(ctypes.c_int32), u32]),
     ("nts_mx_export", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),

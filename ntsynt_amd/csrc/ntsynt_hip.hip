@@ -61,6 +61,9 @@ std::map<void*, Block> sizes;
 std::atomic<uint64_t> live{0}, peak{0};
 // calls of hipMalloc / hipFree made through here and the host time they took (nts_alloc_stats: what a cold call spends allocating)
 std::atomic<uint64_t> alloc_calls{0}, alloc_ns{0};
+// what else a leg of a run wants to know about its allocations (nts_mem_events): allocations that failed and were tried again after the
+// cache was emptied, bytes asked of / given back to the driver, host time spent waiting for the device before a block was kept
+std::atomic<uint64_t> oom_retries{0}, driver_bytes_in{0}, driver_bytes_out{0}, free_sync_ns{0}, reserve_calls{0};
 struct AllocClock
 {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -83,7 +86,10 @@ struct AllocClock
 // the driver when it is wholly free and the cache is over its limit, when an allocation fails (every wholly free slab is released
 // and the allocation tried again) and on nts_mem_trim.  `live` / `peak` count blocks in use, not cached ranges.
 constexpr uint64_t CACHE_LIMIT = 96ull << 30;
-constexpr size_t CACHE_MIN_BLOCK = 64u << 10; // smaller requests go to the driver as they are (its own small-block pool serves them)
+constexpr size_t CACHE_MIN_BLOCK = 64u << 10; // requests below this are "small": served from slabs of their own (SMALL_SLAB bytes each), so
+                                               // that a long-lived 4 KB workspace never holds a multi-GB allocation in the cache
+constexpr size_t SMALL_SLAB = 8u << 20;
+constexpr size_t SMALL_GRAIN = 256;
 constexpr size_t GRAIN = 4096;                 // cached requests are rounded up to this; pieces are cut at multiples of it
 struct Slab
 {
@@ -92,11 +98,17 @@ struct Slab
   int device;
   std::map<size_t, size_t> free; // offset -> length of the free ranges, none adjacent to another
   size_t in_use = 0;
+  bool small = false;  // serves requests below CACHE_MIN_BLOCK only
+  bool pinned = false; // reserved ahead of a run (nts_mem_reserve): stays when the cache is over its limit; leaves on trim / when an allocation fails
 };
-typedef std::tuple<int, size_t, char*> FreeKey; // (device, length, address): lower_bound = the smallest range that holds a request
+// (device * 2 + small, length, address): lower_bound = the smallest range of that kind that holds a request
+typedef std::tuple<int, size_t, char*> FreeKey;
+inline int kind_of(const Slab* sl) { return sl->device * 2 + (sl->small ? 1 : 0); }
 std::map<FreeKey, Slab*> free_index;
 std::set<Slab*> slabs;
 uint64_t cached_bytes = 0; // sum of the free ranges
+uint64_t cached_pinned = 0; // ... of which in reserved slabs (not counted against CACHE_LIMIT: they were asked for)
+uint64_t cached_small = 0;  // ... of which in the slabs of the small requests (nts_mem_cache_stats leaves them out)
 std::atomic<uint64_t> cache_hits{0};
 
 inline void count_live(size_t n)
@@ -111,14 +123,18 @@ inline void count_live(size_t n)
 inline void range_add(Slab* sl, size_t off, size_t len)
 {
   sl->free[off] = len;
-  free_index[FreeKey(sl->device, len, sl->base + off)] = sl;
+  free_index[FreeKey(kind_of(sl), len, sl->base + off)] = sl;
   cached_bytes += len;
+  if (sl->pinned) cached_pinned += len;
+  if (sl->small) cached_small += len;
 }
 inline void range_del(Slab* sl, size_t off, size_t len)
 {
   sl->free.erase(off);
-  free_index.erase(FreeKey(sl->device, len, sl->base + off));
+  free_index.erase(FreeKey(kind_of(sl), len, sl->base + off));
   cached_bytes -= len;
+  if (sl->pinned) cached_pinned -= len;
+  if (sl->small) cached_small -= len;
 }
 // [off, off + len) of the slab is free again: joined with the free ranges that touch it
 inline void range_release(Slab* sl, size_t off, size_t len)
@@ -142,14 +158,15 @@ inline void range_release(Slab* sl, size_t off, size_t len)
   range_add(sl, off, len);
 }
 // wholly free slabs leave the cache while it holds more than `limit` bytes (the largest first); the caller frees what `gone` collects
-inline void shed(uint64_t limit, std::vector<void*>& gone)
+inline void shed(uint64_t limit, std::vector<void*>& gone, bool pinned_too = false)
 {
-  while (cached_bytes > limit) {
+  while (cached_bytes - (pinned_too ? 0 : cached_pinned) > limit) {
     Slab* pick = nullptr;
     for (Slab* sl : slabs)
-      if (sl->in_use == 0 && (!pick || sl->bytes > pick->bytes)) pick = sl;
+      if (sl->in_use == 0 && (pinned_too || !sl->pinned) && (!pick || sl->bytes > pick->bytes)) pick = sl;
     if (!pick) break;
     range_del(pick, 0, pick->bytes); // (wholly free: one range)
+    driver_bytes_out.fetch_add(pick->bytes);
     gone.push_back(pick->base);
     slabs.erase(pick);
     delete pick;
@@ -163,9 +180,9 @@ inline uint64_t trim()
   uint64_t before = 0, after = 0;
   {
     std::lock_guard<std::mutex> g(mu);
-    before = cached_bytes;
-    shed(0, gone);
-    after = cached_bytes;
+    before = cached_bytes - cached_small; // (the small requests' slabs go too when wholly free; the figure reported is the large blocks')
+    shed(0, gone, true);
+    after = cached_bytes - cached_small;
   }
   for (void* q : gone) {
     AllocClock clk;
@@ -174,51 +191,126 @@ inline uint64_t trim()
   return before - after;
 }
 
+// one hipMalloc of `bytes` that goes straight into the cache as a free slab (callers do not hold `mu`)
+inline hipError_t slab_from_driver(int dev, size_t bytes, bool small, bool pinned)
+{
+  void* q = nullptr;
+  hipError_t e;
+  {
+    AllocClock clk;
+    e = ::hipMalloc(&q, bytes);
+  }
+  if (e != hipSuccess || !q) return e == hipSuccess ? hipErrorOutOfMemory : e;
+  driver_bytes_in.fetch_add(bytes);
+  std::lock_guard<std::mutex> g(mu);
+  Slab* sl = new Slab();
+  sl->base = (char*)q;
+  sl->bytes = bytes;
+  sl->device = dev;
+  sl->small = small;
+  sl->pinned = pinned;
+  slabs.insert(sl);
+  range_add(sl, 0, bytes);
+  return hipSuccess;
+}
+
+// (callers hold `mu`) a piece of `need` bytes from the smallest free range of the kind that holds it
+inline bool cut_from_cache(int dev, bool small, size_t need, size_t min_rest, void** p)
+{
+  auto it = free_index.lower_bound(FreeKey(dev * 2 + (small ? 1 : 0), need, nullptr));
+  if (it == free_index.end() || std::get<0>(it->first) != dev * 2 + (small ? 1 : 0)) return false;
+  Slab* sl = it->second;
+  const size_t len = std::get<1>(it->first), off = (size_t)(std::get<2>(it->first) - sl->base);
+  range_del(sl, off, len);
+  size_t take = need;
+  if (len - need >= min_rest)
+    range_add(sl, off + need, len - need); // (what is left stays in the index; a sliver that no request could use goes along)
+  else
+    take = len;
+  sl->in_use += take;
+  *p = sl->base + off;
+  sizes[*p] = { take, dev, sl, off };
+  cache_hits.fetch_add(1);
+  count_live(take);
+  return true;
+}
+
 inline hipError_t dev_malloc(void** p, size_t n)
 {
   int dev = 0;
   ::hipGetDevice(&dev);
-  // (a small request is served by a piece of a kept allocation like any other; when nothing is kept it goes to the driver as it is and
-  //  is not kept afterwards: the driver's own small-block pool serves those)
-  const bool cached_kind = n >= CACHE_MIN_BLOCK;
-  const size_t need = (n + GRAIN - 1) / GRAIN * GRAIN;
-  if (n) {
-    std::lock_guard<std::mutex> g(mu);
-    auto it = free_index.lower_bound(FreeKey(dev, need, nullptr));
-    if (it != free_index.end() && std::get<0>(it->first) == dev) {
-      Slab* sl = it->second;
-      const size_t len = std::get<1>(it->first), off = (size_t)(std::get<2>(it->first) - sl->base);
-      range_del(sl, off, len);
-      size_t take = need;
-      if (len - need >= CACHE_MIN_BLOCK)
-        range_add(sl, off + need, len - need); // (what is left stays in the index; a sliver that no request could use goes along)
-      else
-        take = len;
-      sl->in_use += take;
-      *p = sl->base + off;
-      sizes[*p] = { take, dev, sl, off };
-      cache_hits.fetch_add(1);
-      count_live(take);
-      return hipSuccess;
+  const bool small = n < CACHE_MIN_BLOCK;
+  if (small && n) {
+    // small requests live in slabs of their own: the first one of a process (or the one that finds them full) asks the driver for a slab
+    const size_t need = (n + SMALL_GRAIN - 1) / SMALL_GRAIN * SMALL_GRAIN;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      {
+        std::lock_guard<std::mutex> g(mu);
+        if (cut_from_cache(dev, true, need, SMALL_GRAIN, p)) return hipSuccess;
+      }
+      if (attempt == 0 && slab_from_driver(dev, SMALL_SLAB, true, true) != hipSuccess) {
+        (void)hipGetLastError();
+        break;
+      }
     }
+  }
+  const size_t need = (n + GRAIN - 1) / GRAIN * GRAIN;
+  if (n && !small) {
+    std::lock_guard<std::mutex> g(mu);
+    if (cut_from_cache(dev, false, need, CACHE_MIN_BLOCK, p)) return hipSuccess;
   }
   hipError_t e;
   {
     AllocClock clk;
-    e = ::hipMalloc(p, cached_kind ? need : n);
+    e = ::hipMalloc(p, small ? n : need);
   }
   if (e == hipErrorOutOfMemory && trim() > 0) { // (what the cache held may be what was missing)
     (void)hipGetLastError();
+    oom_retries.fetch_add(1);
     AllocClock clk;
-    e = ::hipMalloc(p, cached_kind ? need : n);
+    e = ::hipMalloc(p, small ? n : need);
   }
   if (e == hipSuccess && *p) {
+    driver_bytes_in.fetch_add(small ? n : need);
     {
       std::lock_guard<std::mutex> g(mu);
-      sizes[*p] = { cached_kind ? need : n, dev, nullptr, 0 };
+      sizes[*p] = { small ? n : need, dev, nullptr, 0 };
     }
-    count_live(cached_kind ? need : n);
+    count_live(small ? n : need);
   }
+  return e;
+}
+
+// `bytes` of device memory taken from the driver in ONE call and kept in the cache for the requests to come (nts_mem_reserve).  When
+// the device cannot give that much, what it can (less a margin) is taken instead; *got = the bytes reserved.
+inline hipError_t reserve(int dev, uint64_t bytes, uint64_t* got)
+{
+  if (got) *got = 0;
+  int cur = 0;
+  ::hipGetDevice(&cur);
+  if (cur != dev) ::hipSetDevice(dev);
+  size_t fr = 0, tot = 0;
+  hipError_t e = ::hipMemGetInfo(&fr, &tot);
+  if (e == hipSuccess) {
+    const size_t margin = 2ull << 30;
+    if (bytes + margin > fr) bytes = fr > margin ? fr - margin : 0;
+    bytes = bytes / GRAIN * GRAIN;
+    if (bytes >= CACHE_MIN_BLOCK) {
+      e = slab_from_driver(dev, bytes, false, true);
+      if (e == hipSuccess) {
+        reserve_calls.fetch_add(1);
+        if (got) *got = bytes;
+      }
+    }
+    bool have_small = false;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (Slab* sl : slabs) have_small |= sl->small && sl->device == dev;
+    }
+    if (e == hipSuccess && !have_small) (void)slab_from_driver(dev, SMALL_SLAB, true, true);
+  }
+  if (e != hipSuccess) (void)hipGetLastError();
+  if (cur != dev) ::hipSetDevice(cur);
   return e;
 }
 
@@ -262,7 +354,9 @@ inline hipError_t dev_free(void* p)
     int cur = 0;
     ::hipGetDevice(&cur);
     if (cur != blk.device) ::hipSetDevice(blk.device);
+    const auto ts = std::chrono::steady_clock::now();
     const hipError_t es = ::hipDeviceSynchronize();
+    free_sync_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ts).count());
     if (cur != blk.device) ::hipSetDevice(cur);
     std::vector<void*> gone;
     bool kept = false;
@@ -290,10 +384,12 @@ inline hipError_t dev_free(void* p)
       ::hipFree(q);
     }
     if (kept) return hipSuccess;
+    driver_bytes_out.fetch_add(blk.bytes);
     AllocClock clk;
     return ::hipFree(p);
   }
   if (known) {
+    driver_bytes_out.fetch_add(blk.bytes);
     std::lock_guard<std::mutex> g(mu);
     sizes.erase(p);
     live.fetch_sub(blk.bytes);
@@ -321,6 +417,17 @@ using nts_mem::dev_free;
 using nts_mem::dev_malloc;
 using nts_mem::dev_malloc_flags;
 
+static std::atomic<int> g_live_contexts{0};
+// Sketches of several genomes at once (one context each, device.SketchPool / NTS_SKETCH_POOL): the select kernels of the contexts of a
+// device run one after the other -- each waits for the one launched before it -- while a genome's latency-bound tail (compaction,
+// window decisions, gather, uncovered ranges, finalize) floats next to the following genome's select kernel.  Started together the
+// select kernels would share the chip and finish together, and the tails would again find nothing to hide behind.
+namespace nts_chain {
+std::mutex mu;
+hipEvent_t ev[32] = {};
+bool live[32] = {};
+} // namespace nts_chain
+
 namespace {
 
 constexpr uint64_t PAD = 256;          // invalid bytes before and after the sequence
@@ -345,6 +452,7 @@ struct Timing
 struct nts_ctx
 {
   int device = 0;
+  bool counted = false; // among the process's live contexts (nts_init got through)
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr; // bulk device -> host copies that may run behind later kernels (nts_bf_download)
   // pinned host page the device writes small results into (counters, the first uncovered ranges): one stream
@@ -2056,6 +2164,8 @@ int nts_init(int device, nts_ctx** out)
   if (const char* v = getenv("NTS_IO_THREADS")) ctx->io_threads = (unsigned)std::max(1, std::min(32, atoi(v)));
   if (const char* v = NTS_KNOB("NTS_COMM_SPARSE")) ctx->comm_sparse_mode = atoi(v) == 0 ? 1 : 0;
   if (const char* v = NTS_KNOB("NTS_COMM_SPARSE_BELOW")) ctx->comm_sparse_below = strtoull(v, nullptr, 10);
+  ctx->counted = true;
+  g_live_contexts.fetch_add(1);
   *out = ctx;
   return NTS_OK;
 }
@@ -2076,7 +2186,11 @@ void nts_destroy(nts_ctx* ctx)
   if (ctx->stage) hipHostFree(ctx->stage);
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
+  const bool last = ctx->counted && g_live_contexts.fetch_sub(1) == 1;
   delete ctx;
+  // the process's last context is gone: what the allocation cache holds goes back to the driver (another process on this GPU that runs
+  // out of memory cannot ask this one to let go)
+  if (last) nts_mem::trim();
 }
 
 const char* nts_last_error(nts_ctx* ctx)
@@ -2138,7 +2252,7 @@ uint64_t nts_mem_trim(void)
 int nts_mem_cache_stats(uint64_t* cached_bytes, uint64_t* hits)
 {
   std::lock_guard<std::mutex> g(nts_mem::mu);
-  if (cached_bytes) *cached_bytes = nts_mem::cached_bytes;
+  if (cached_bytes) *cached_bytes = nts_mem::cached_bytes - nts_mem::cached_small;
   if (hits) *hits = nts_mem::cache_hits.load();
   return NTS_OK;
 }
@@ -2146,6 +2260,29 @@ int nts_mem_cache_stats(uint64_t* cached_bytes, uint64_t* hits)
 void nts_mem_reset_peak(void)
 {
   nts_mem::peak.store(nts_mem::live.load());
+}
+
+// One driver allocation of `bytes` on `device`, kept for the allocations of the run to come (they are cut from it; nothing goes back
+// to the driver before nts_mem_trim, an allocation failure, or the end of the process).
+int nts_mem_reserve(int device, uint64_t bytes, uint64_t* reserved_bytes)
+{
+  return nts_mem::reserve(device, bytes, reserved_bytes) == hipSuccess ? NTS_OK : NTS_EHIP;
+}
+
+// out[0..7]: hipMalloc+hipFree calls, ns spent in them, allocations served from the cache, allocations retried after the cache was
+// emptied, bytes taken from the driver, bytes given back, ns spent in hipDeviceSynchronize before keeping a freed block, reserve calls
+int nts_mem_events(uint64_t out[8])
+{
+  if (!out) return NTS_EINVAL;
+  out[0] = nts_mem::alloc_calls.load();
+  out[1] = nts_mem::alloc_ns.load();
+  out[2] = nts_mem::cache_hits.load();
+  out[3] = nts_mem::oom_retries.load();
+  out[4] = nts_mem::driver_bytes_in.load();
+  out[5] = nts_mem::driver_bytes_out.load();
+  out[6] = nts_mem::free_sync_ns.load();
+  out[7] = nts_mem::reserve_calls.load();
+  return NTS_OK;
 }
 
 int nts_timing(nts_ctx* ctx, const char* name, double* total_ms, uint64_t* launches)
@@ -3973,6 +4110,24 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       ScopedTimer t(ctx, "hash_accept", true);
       if (int rc_a = launch_accept(ctx, g, k, A, ctx->cur_fold, n_kt)) return rc_a;
     } else {
+      const bool chained = g_live_contexts.load() > 1 && ctx->device < 32 && !(NTS_KNOB("NTS_SELECT_CHAIN") && atoi(NTS_KNOB("NTS_SELECT_CHAIN")) == 0);
+      std::unique_lock<std::mutex> chain_lock(nts_chain::mu, std::defer_lock);
+      if (chained) {
+        chain_lock.lock();
+        if (nts_chain::live[ctx->device]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, nts_chain::ev[ctx->device], 0));
+      }
+      struct ChainRecord // (behind the timer's closing event, whichever way the block is left)
+      {
+        nts_ctx* c;
+        bool on;
+        ~ChainRecord()
+        {
+          if (!on) return;
+          hipEvent_t& e = nts_chain::ev[c->device];
+          if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return;
+          if (hipEventRecord(e, c->stream) == hipSuccess) nts_chain::live[c->device] = true;
+        }
+      } chain_record{ ctx, chained };
       ScopedTimer t(ctx, filter ? "hash_select" : "hash_select_nofilter", true);
       // a lane rolls 64 k-mers and keeps 64*c/w candidates on average: 8 private slots while that is small, 16 beyond
       // (a lane that runs out sends its tile through the general path, i.e. hashes it twice)

@@ -18,6 +18,28 @@ class NtsError(RuntimeError):
     pass
 
 
+MEM_EVENT_NAMES = ("driver_calls", "ns_in_driver_calls", "served_from_cache", "retried_after_emptying_the_cache", "bytes_from_driver",
+                   "bytes_to_driver", "ns_waiting_for_device_before_keeping_a_block", "reserve_calls")
+
+
+def mem_events(lib):
+    "nts_mem_events of a loaded library (no context needed: the counters are the process's)"
+    out = (ctypes.c_uint64 * 8)()
+    lib.nts_mem_events(out)
+    return dict(zip(MEM_EVENT_NAMES, [int(x) for x in out]))
+
+
+def mem_events_since(lib, before):
+    "what a stage did to the allocator, in the units a bench line prints"
+    now = mem_events(lib)
+    d = {k: now[k] - before[k] for k in now}
+    return {"hipMalloc_hipFree_calls": d["driver_calls"], "ms_in_hipMalloc_hipFree": round(d["ns_in_driver_calls"] * 1e-6, 2),
+            "allocations_served_from_kept_memory": d["served_from_cache"], "allocations_retried_after_emptying_the_cache": d["retried_after_emptying_the_cache"],
+            "GB_from_driver": round(d["bytes_from_driver"] / 1e9, 3), "GB_to_driver": round(d["bytes_to_driver"] / 1e9, 3),
+            "ms_waiting_for_device_before_keeping_a_block": round(d["ns_waiting_for_device_before_keeping_a_block"] * 1e-6, 2),
+            "reserve_calls": d["reserve_calls"]}
+
+
 class Context:
     """One per GPU (owns a HIP stream)."""
 
@@ -149,6 +171,39 @@ class Context:
 
     def mem_reset_peak(self):
         self.lib.nts_mem_reset_peak()
+
+    def mem_reserve(self, nbytes):
+        "one driver allocation of `nbytes` kept for the allocations to come (nts_mem_reserve); returns the bytes reserved"
+        got = u64()
+        self.check(self.lib.nts_mem_reserve(self.device, int(nbytes), ctypes.byref(got)), "nts_mem_reserve")
+        return got.value
+
+    def mem_reserve_async(self, nbytes):
+        """the same on a thread of its own (the call spends its time in the driver, outside the interpreter lock): a run starts it
+        before it opens its first file; .join() returns the bytes reserved (0 when the driver refused: the run then allocates as it goes)"""
+        import threading
+        box = {"got": 0}
+
+        def work():
+            try:
+                box["got"] = self.mem_reserve(nbytes)
+            except Exception:
+                box["got"] = 0
+        th = threading.Thread(target=work, name="nts_mem_reserve", daemon=True)
+        th.start()
+
+        class _Pending:
+            def join(self_inner):
+                th.join()
+                return box["got"]
+        return _Pending()
+
+    def mem_events(self):
+        "process-wide allocation counters (nts_mem_events) as a dict; take differences around a stage (mem_events_since)"
+        return mem_events(self.lib)
+
+    def mem_events_since(self, before):
+        return mem_events_since(self.lib, before)
 
     def trim_ingest(self):
         "give back the FASTA ingest's workspaces (the raw image of the largest file, pinned staging): nts_ingest_trim"

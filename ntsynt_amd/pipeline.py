@@ -452,6 +452,42 @@ def _exchange_lists(backend, local, n_total):
     return [merged[i] for i in range(n_total)]
 
 
+def plan_bytes(file_bytes, fpr, build_filter):
+    """Device bytes a run over files of these sizes will have live at its peak (an upper estimate from the files alone: a base per byte,
+    four per byte of a .gz): the filter (39.5 bits per base of the first file in sorted order at fpr 0.025: A1), the Bloom build's two
+    bucket arrays and bypass list (12 bytes per k-mer of the largest genome), the resident genomes with their 2-bit images and tables
+    (1.3 bytes per base), sketch and graph workspaces.  3 x 3 Gbp: 63.6 GB planned, 60.2 GB measured (bench.py e2e)."""
+    import math
+    if not file_bytes:
+        return 0
+    n0, n_max, total = file_bytes[0], max(file_bytes), sum(file_bytes)
+    plan = 1.3 * total + (2 << 30)
+    if build_filter:
+        plan += math.ceil(-n0 / math.log(1 - fpr)) / 8 + 12 * n_max
+    return int(plan)
+
+
+def reserve_for_run(ctx, fastas, fpr, build_filter, log=None):
+    """nts_mem_reserve of what plan_bytes says, less what the process's allocation cache already holds, started on a thread of its own;
+    returns an object whose join() gives the bytes reserved (0: nothing asked, or the driver refused -- the run then allocates as it goes)"""
+    class _Nothing:
+        def join(self):
+            return 0
+    if os.environ.get("NTS_RESERVE", "1") == "0":
+        return _Nothing()
+    sizes = []
+    for p in sorted(fastas):
+        try:
+            sz = os.path.getsize(p)
+        except OSError:
+            return _Nothing()
+        sizes.append(sz * 4 if p.endswith(".gz") else sz)
+    want = plan_bytes(sizes, fpr, build_filter) - ctx.mem_cache_stats()[0]
+    if want < (256 << 20):                                      # small runs: the driver's latency is not what they wait for
+        return _Nothing()
+    return ctx.mem_reserve_async(want)
+
+
 def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000, merge=10000,
         block_size=500, common=True, simplify=True, device=0, write_mx_tsv=True, mx_with_seq=True,
         benchmark=False, log=print, ctx=None, backend=None, bf_rounding="up", bf_signature=BF_SIGNATURE, dev=False, interarrivals=False, repeat=False,
@@ -502,6 +538,20 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         G_ = len(fastas)
         mine = [fastas[(rank * G_) // world]] if world >= G_ else [p for i, p in enumerate(fastas) if (i * world) // G_ == rank]
 
+    reserving = []
+
+    def join_reserve():
+        if reserving:
+            st.reserved_bytes = reserving.pop().join()
+            st.mark("memory_reserved")
+    if isinstance(backend, GpuBackend) and not (mx_tsvs is not None and initial_only):
+        # the run's device memory in ONE driver allocation, before its first file is opened (nts_mem_reserve): the filter, the Bloom
+        # build's workspaces and the resident genomes are cut from it, and nothing goes back to the driver while the run lasts
+        # (the reference allocates its two filters once: src/ntsynt_make_common_bf.cpp:121-137)
+        # On a thread of its own: memory the GPU has not handed out since the driver came up costs 7-20 ms per GB on the boxes this
+        # build ran on (0.5 s for a 3 x 3 Gbp run's 65 GB; scripts/malloc_probe.py, bench.py `allocator`), time the first file's ingest
+        # can share.  Joined before the filter is allocated.
+        reserving.append(reserve_for_run(backend.ctx, fastas if world == 1 else mine, fpr, common and common_file is None, log))
     # limits of this implementation, checked before anything is written (the reference has none of them)
     for ww in [w] + list(w_rounds):
         if not 1 <= int(ww) <= MAX_W:
@@ -646,6 +696,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         log(f"Genome size (bp): {first_bp}")
         log(f"BF size (bytes): {approx}")
         my_sorted = [p for p in ordered if owner[p] == rank] if not shard_mode else []
+        join_reserve()                                        # (the filter and the build's workspaces are cut from the reserved memory)
         bf = backend.bf_new(nbytes, k, world, ones=(world > 1 and not my_sorted and not shard_mode))
         st.mark("bf_allocated")
         part_filters = [bf]
@@ -759,6 +810,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         else:
             submit_file(f"{prefix}.common.bf", lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k, signature=bf_signature))
 
+    join_reserve()                                            # (runs without a filter build get here with the reservation still under way)
     if device_engine:
         from .synteny_device import DeviceSyntenyEngine
         mine_idx = [i for i, p in enumerate(fastas) if owner[p] == rank]
@@ -954,5 +1006,6 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     st.mark("end")
     eng.stage_times = st.rows
     eng.stage_marks = st.marks
+    eng.reserved_bytes = getattr(st, "reserved_bytes", 0)
     eng.memory = memory
     return eng
