@@ -825,6 +825,16 @@ def cold_leg(args, ctx, rig):
             "includes": "2-bit image, run table of valid k-mers, first-k-mer tables, workspace allocation (the first of the three)"}
 
 
+def vs_n1(which, now):
+    "this run's figure over the committed one-GPU line's (profiles/r06_bench_n1.json): `value`, or the c4 leg's value_Gbases_s"
+    try:
+        base = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_n1.json")))
+        ref = base["value"] if which == "value" else base["c4"]["value_Gbases_s"]
+        return round(now / ref, 3)
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one per GPU, rendezvous on
     127.0.0.1) and hand their exit status on; the line comes from rank 0 of that job."""
@@ -893,7 +903,8 @@ def main():
     if os.environ.get("NTS_BENCH_ARENA", "1") != "0":
         n_res = max(3, -(-8 // world)) if not args.workload or args.workload == "c3" else 3
         per_genome = int((args.mbp or {"c2": 100, "c3": 3000, "c4": 3000}.get(args.workload or "c3", 3000)) * 1e6)
-        arena_plan = plan_bytes([per_genome] * n_res, args.fpr, True) + (44 << 30)     # (+ the headline family's filter and workspaces, live next to the leg's)
+        # (the largest leg's family + 0.7 of the headline family's plan: its filter and workspaces stay live next to the leg's)
+        arena_plan = plan_bytes([per_genome] * n_res, args.fpr, True) + int(0.7 * plan_bytes([per_genome] * 3, args.fpr, True))
         t_ar = time.time()
         arena_got = ctx.mem_reserve(arena_plan)
         t_arena = time.time() - t_ar
@@ -975,6 +986,7 @@ def main():
         step()
     rig.t_sketch = 0.0
     dt, n_mx = timed(0, args.steps)
+    x2_headline = comm.last_exchange2() if comm is not None else None     # (of the last timed step: the later legs exchange other lists)
     t_sk = rig.t_sketch
     if world > 1:                                                   # the slowest rank's sketch time
         tt = torch.tensor([t_sk], dtype=torch.float64, device=pg_dev)
@@ -1069,12 +1081,15 @@ def main():
         b4 = r4.build_filter(levels=(world == 1))
         alloc4_build = ctx.mem_events_since(ev4)
         d4, n4 = timed(1, 2, level=0, step=r4.step)
+        x2_c4 = comm.last_exchange2() if comm is not None else None
         c4 = {"workload": f"c4: 8 synthetic {r4.mbp:g} Mbp genomes at 10% divergence, genome g on GPU g mod {world}",
               "n_gpus": world, "value_Gbases_s": round(sum(r4.fam_bases) * 2 / d4 / 1e9, 3), "ms_per_step": round(d4 / 2 * 1e3, 2),
               "common_filter_occupancy": r4.common.get_fpr(), "minimizers_per_step_rank0": n4, "minimizers_per_step_all_genomes": r4.n_all if world > 1 else n4,
               "common_filter_build_s": round(b4["build_s"], 4), "allreduce_and_s": round(b4["allreduce_s"], 4),
               "all_reduce_gathered_set_bit_indices": bool(comm.last_sparse()) if comm is not None else None,
               "common_filter_levels": r4.levels or None, "balance": r4.balance,
+              "speedup_vs_n1": vs_n1("c4", round(sum(r4.fam_bases) * 2 / d4 / 1e9, 3)) if world > 1 else None,
+              "exchange2_bytes_per_step": x2_c4,
               # what the leg asked of the driver while it generated its genomes and built its filter, and over the whole leg
               "allocator": {"genomes_and_filter_build": alloc4_build, "whole_leg": ctx.mem_events_since(ev4)}}
         r4.free()
@@ -1171,6 +1186,13 @@ def main():
                        # sketch calls alone, slowest rank:
                        "sketch_only_Gbases_s": round(sum(fam_bases) * args.steps / t_sk / 1e9, 3) if t_sk > 0 else None,
                        "exchange2_share_of_step": round(max(0.0, 1.0 - t_sk / dt), 4) if world > 1 else 0.0,
+                       # exchange 2's payload (nts_comm_last_exchange2): every rank's lists packed (12 B per minimizer + a record table; the
+                       # lists themselves hold 20 B per minimizer) and what rank 0 sent per step (its slot to each of the others)
+                       "exchange2_bytes_per_step": ({**x2_headline, "packed_over_unpacked": round(x2_headline["packed_bytes"] / max(1, x2_headline["unpacked_bytes"]), 3)}
+                                                    if x2_headline is not None else None),
+                       # against the N = 1 line of this tree (profiles/r06_bench_n1.json, the builder's last one-GPU run: a different box than the
+                       # driver's -- the driver computes scaling from its own runs)
+                       "value_speedup_vs_n1": vs_n1("value", value) if world > 1 else None,
                        # did RCCL see N ranks, and which library served the exchanges
                        "rccl_ranks": rccl_ranks, "rccl_library": served_by, "library": ctx.lib._name,
                        "scaling_base": "c3 (BASELINE configs[2], the metric's configuration) is `value` at every N; c4 (configs[3]) is the `c4` leg of the same line at every N",

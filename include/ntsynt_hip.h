@@ -282,6 +282,10 @@ int nts_bf_allreduce_and(nts_ctx* ctx, nts_bf* bf, nts_comm* comm);
  * reduced filter that is all but empty -- BASELINE config 4 -- moves megabytes instead of the filter's size). */
 int nts_bf_allreduce_groups(nts_ctx* ctx, nts_bf* bf, nts_comm* comm, const int32_t* group_of, uint32_t n_groups);
 int nts_comm_last_sparse(const nts_ctx* ctx);
+/* The context's last exchange 2 (nts_mx_allgather[_ex]): the lists travel packed -- h1 as it is, the position in 32 bits when the
+ * list's largest fits, the record as one start index per RECORD (a list is in record order): 12 bytes per minimizer and a few KB where
+ * the lists themselves hold 20.  packed_bytes / unpacked_bytes: all ranks' lists in the two forms; sent_bytes: what this rank sent. */
+int nts_comm_last_exchange2(const nts_ctx* ctx, uint64_t* packed_bytes, uint64_t* unpacked_bytes, uint64_t* sent_bytes);
 /* Exchange 1 when a family's records are shared out over the ranks by bases, across genome boundaries (ntsynt_amd/pipeline.py
  * partition_plan: three genomes on eight GPUs are eight ranges of 1.125 Gbp, not 3/3/2 ranks per genome): a rank holds one filter per
  * genome its range of records touches.  bfs[0 .. n_local): this rank's filters, all of one size (nts_bf_create_sharded); the first

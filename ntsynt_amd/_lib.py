@@ -123,6 +123,7 @@ SYMBOLS = [
     ("nts_bf_allreduce_and", ctypes.c_int, [c_vp, c_vp, c_vp]),
     ("nts_bf_allreduce_groups", ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_int32), u32]),
     ("nts_comm_last_sparse", ctypes.c_int, [c_vp]),
+    ("nts_comm_last_exchange2", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     ("nts_mx_allgather", ctypes.c_int, [c_vp, c_vp, u32, ctypes.POINTER(c_vp), c_u32p, u32, ctypes.POINTER(c_vp)]),
     ("nts_alloc_stats", ctypes.c_int, [c_vp, c_vp]),
     ("nts_mem_trim", ctypes.c_uint64, []),

@@ -485,6 +485,7 @@ struct nts_ctx
   uint64_t last_many_listed = 0; // candidates of k_hash_select_hi tiles that listed more than their slots hold (repeats, pieces)
   uint64_t last_bf_direct = 0;   // indices of the last partitioned Bloom build that bypassed the buckets (full bucket, lanes in pieces)
   uint32_t last_comm_sparse = 0; // the last all-reduce of a filter gathered set-bit indices instead of chunks
+  uint64_t last_x2_packed_bytes = 0, last_x2_unpacked_bytes = 0, last_x2_sent_bytes = 0; // the last exchange 2 (nts_comm_last_exchange2)
   uint32_t last_bf_fallback = 0; // 1: its late list ran full (store-only build fell back to read-and-OR / fused AND build was redone unfused)
   uint32_t last_bf_sparse_level = 0;     // the last nts_bf_insert_and went the literal way over a sparse running filter (bf_level_sparse)
   uint64_t last_bf_sparse_accepted = 0;  // and accepted this many k-mers

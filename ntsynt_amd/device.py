@@ -520,6 +520,12 @@ class Comm:
         "True if the last all-reduce gathered set-bit indices instead of the reduced chunks"
         return bool(self.ctx.lib.nts_comm_last_sparse(self.ctx.h))
 
+    def last_exchange2(self):
+        "the last exchange 2 of this context: dict(packed_bytes, unpacked_bytes, sent_bytes) -- nts_comm_last_exchange2"
+        a, b, c = u64(), u64(), u64()
+        self.ctx.lib.nts_comm_last_exchange2(self.ctx.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return {"packed_bytes": a.value, "unpacked_bytes": b.value, "sent_bytes": c.value}
+
     def allgather_minimizers(self, local, local_ids, n_total, slots=0):
         """exchange 2: the ranks' Minimizers -> [Minimizers of list g for g in range(n_total)], resident in HBM; slots: lists a rank may
         hold (0: ceil(n_total / world))"""

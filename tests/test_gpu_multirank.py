@@ -192,6 +192,30 @@ def test_bench_starts_its_own_ranks_and_keeps_one_workload_along_the_curve(tmp_p
     assert "refusing" in r.stderr
 
 
+def test_bench_with_eight_ranks_the_driver_command_at_small_size(tmp_path):
+    """`python bench.py --gpus 8` (the driver's scaling command, here with eight ranks on the visible GPU through the stand-in): three
+    genomes shared out over eight ranks by bases (a rank holds up to two parts), config 4's eight genomes one per rank; the lists
+    cross exchange 2 packed (12 bytes per minimizer and a record table instead of 20) and add up to the one-rank run's"""
+    small = ["--steps", "2", "--warmup", "1", "--mbp", "8", "--contigs", "4"]
+    env = _env(NTS_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + small, env, tmp_path)
+    assert out["n_gpus"] == 8 and out["value"] > 0 and out["config"]["rccl_ranks"] == 8
+    assert "3 genomes over 8 GPUs" in out["config"]["parallelism"]
+    x2 = out["config"]["exchange2_bytes_per_step"]
+    n_all = out["config"]["minimizers_per_step_all_genomes"]
+    assert x2["unpacked_bytes"] == 20 * n_all
+    assert 12 * n_all <= x2["packed_bytes"] <= 12 * n_all + 8 * 64 * 12 and x2["packed_over_unpacked"] <= 0.62      # (<= 0.6 x + the record tables)
+    assert x2["sent_bytes"] > 0
+    assert out["c4"]["n_gpus"] == 8 and out["c4"]["balance"]["max_over_mean"] <= 1.01 and out["c4"]["exchange2_bytes_per_step"]["packed_bytes"] > 0
+    ref = _bench_line([sys.executable, os.path.join(ROOT, "bench.py")] + small +
+                      ["--no-e2e", "--no-cpu-baseline", "--no-dense-leg", "--no-cold-leg", "--no-nruns-leg", "--no-c5-leg", "--no-valley-leg"],
+                      dict(os.environ, PYTHONPATH=ROOT), tmp_path)
+    assert n_all == ref["config"]["minimizers_per_step_rank0"]
+    assert ref["c4"]["minimizers_per_step_all_genomes"] == out["c4"]["minimizers_per_step_all_genomes"]
+    assert ref["config"]["exchange2_bytes_per_step"] is None and ref["config"]["value_speedup_vs_n1"] is None
+
+
 @pytest.mark.parametrize("world,n_genomes,contigs,extra", [(4, 3, 3, []), (5, 2, 2, []), (3, 2, 1, []), (2, 3, 3, []), (3, 5, 2, []),
                                                            (4, 3, 2, ["--no-common", "--no-simplify-graph"])])
 def test_pipeline_with_genomes_that_do_not_deal_out_evenly_matches_single_rank(world, n_genomes, contigs, extra, tmp_path):
