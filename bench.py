@@ -479,6 +479,7 @@ def e2e_leg(args, device, n_fam, total_bp, contigs, div, workdir, paths=None):
             # else is a request the plan did not cover) and what other processes held of the GPU's memory when it started
             "allocator": dict(mem_events_since(_lib.load(), ev0), reserved_GB=round(getattr(eng, "reserved_bytes", 0) / 1e9, 2)),
             "device_memory_in_use_by_others_at_start_GB": getattr(args, "device_used_by_parent_GB", None),
+            "GB_the_bench_process_gave_back_before_this_run": getattr(args, "parent_freed_GB", None),
             "write_inputs_s": round(t_write, 1)}
 
 
@@ -1069,7 +1070,7 @@ def main():
         valu = {"wave_instr_per_s_per_cu": {n: round(r["wave_instr_per_s_per_cu"] / 1e9, 3) for n, r in rows.items()},
                 "unit": "G wave-instructions/s/CU", "how": "nts_bench_valu: 8 waves per SIMD, eight independent chains per lane, wall clock"}
 
-    c4 = valley = None
+    c4 = valley = rows = None
     if name == "c3" and not args.no_c4_leg:
         # BASELINE configs[3] at this N, in the same line: eight genomes at 10 %, genome g on rank g mod N, the filter's cascade local,
         # then the AND all-reduce; every step ends with the all-gather of the lists.  (At N = 1: all eight on this GPU.)
@@ -1098,6 +1099,10 @@ def main():
             valley = {"three_genomes_at_10pct": valley_leg(args, ctx, total_bp, contigs, 3, 0.10),
                       "eight_genomes_at_4pct": valley_leg(args, ctx, total_bp, contigs, 8, 0.04)}
             valley["allocator"] = ctx.mem_events_since(evv)
+            # the reference's third published row as a shape (README.md:158: eleven bee genomes of 0.44 Gbp): eleven synthetic genomes of 16
+            # chromosomes at 4 %; its end-to-end run against the CPU restatement is on record (profiles/r06_e2e_oracle_11x440Mbp_4pct.json)
+            if not args.mbp:
+                rows = {"eleven_genomes_of_440Mbp_at_4pct": valley_leg(args, ctx, 440_000_000, 16, 11, 0.04)}
         if world == 1:                                                  # the later legs of the N = 1 line work on the headline family again
             rig.genomes = [family_genome(ctx, args, total_bp, contigs, g, div / 2.0) for g in mine]
             rig.units = rig.genomes
@@ -1254,6 +1259,8 @@ def main():
             "constants": {"peak": "MI355X_MICROARCH.md: HBM3E 8 TB/s", "algorithmic_bytes_per_base": "SURVEY.md 8(d): 64 B per probe; DESIGN.md 4.1"}}
         out["allocator"] = {"what": "one nts_mem_reserve at start, sized for the largest leg; every leg's genomes, filters and workspaces are cut from it",
                             "arena_planned_GB": round(arena_plan / 1e9, 2), "arena_reserved_GB": round(arena_got / 1e9, 2), "reserve_s": round(t_arena, 4),
+                            # what this box charges for memory it has not handed out before (0.004 on a box whose memory had been used, 28 on one fresh from its driver)
+                            "reserve_ms_per_GB": round(t_arena * 1e3 / max(arena_got / 1e9, 1e-9), 3) if arena_got else None,
                             "sketch_legs_after_the_reserve": ctx.mem_events_since(ev_start)}
         if cold:
             out["cold"] = cold
@@ -1261,6 +1268,8 @@ def main():
             out["nruns"] = nruns
         if valley:
             out["valley"] = valley
+        if rows:
+            out["rows"] = rows
         if c4:
             out["c4"] = c4
             if world == 1:
@@ -1290,10 +1299,21 @@ def main():
                     g.free()                                         # e2e legs' peak-memory figures are the pipeline's own), the
                 if common is not None:                               # pipeline starts from files like a user's run
                     common.free()
-                # (this process keeps its context and its reserved memory while the runs below have processes of their own: closing the
-                #  last context gives the memory back, and a driver that clears freed memory lazily makes the next process wait for it)
-                args.device_used_by_parent_GB = round(ctx.mem_stats()["device_used"] / 1e9, 2)
+                # This process gives its memory back before the runs below start in processes of their own.  Memory a GPU has not handed
+                # out since its driver came up costs 7-28 ms per GB to allocate on the boxes this build ran on (`allocator.reserve_s`
+                # above is this process paying that for its arena; scripts/malloc_probe.py), memory another process has just freed next
+                # to nothing: with the arena kept, the first of the two runs below took its 66 GB from untouched memory (1.8 s in
+                # hipMalloc on one box, 0.48 s on another) and the second from what the first had freed (0.002-0.12 s).  Freed first,
+                # both see the same; what an untouched GPU adds to a run is the reserve rate above times the run's `reserved_GB`.
+                ctx.sync()
+                ev_close = ctx.mem_events()
+                lib_ = ctx.lib
+                ctx.close()                                          # (the process's last context: its workspaces go, then everything kept -- nts_destroy)
+                from ntsynt_amd.device import mem_events_since
+                args.parent_freed_GB = mem_events_since(lib_, ev_close)["GB_to_driver"]
+                args.device_used_by_parent_GB = None
                 if c5 is not None:
+                    a5.parent_freed_GB, a5.device_used_by_parent_GB = args.parent_freed_GB, args.device_used_by_parent_GB
                     sub = os.path.join(workdir, "c5_like")
                     os.makedirs(sub, exist_ok=True)
                     try:

@@ -251,8 +251,9 @@ int nts_and_raw(nts_ctx* ctx, void* acc_dev, const void* other_dev, uint64_t byt
  * nts_comm_library   : which library serves the collectives: "librccl" (the process's copy or the system's), the path
  *                      given in NTS_RCCL_LIB (a site's own build; the test suite's stand-in for ranks that share one
  *                      GPU), or "" when none could be loaded.  (The environment variables the product build reads are four:
- *                      NTS_RCCL_LIB, NTS_COMM_PIECE, NTS_IO_THREADS, NTS_HOST_THREADS -- csrc/nts_knobs.h; the experiment switches
- *                      exist only in libntsynt_hip_exp.so.)
+ *                      NTS_RCCL_LIB, NTS_COMM_PIECE, NTS_IO_THREADS, NTS_HOST_THREADS -- csrc/nts_knobs.h; NTS_COMM_PIECE and
+ *                      NTS_IO_THREADS are read ONCE per context, by nts_init: set them before the context is created.  The
+ *                      experiment switches exist only in libntsynt_hip_exp.so.)
  * nts_bf_create_sharded : a filter whose allocation is `world` chunks of a multiple of 16 bytes -- the layout the
  *                      all-reduce exchanges; otherwise identical to nts_bf_create
  * nts_bf_fill_ones   : identity of AND, for a rank that owns no genome

@@ -11,694 +11,9 @@
 //              numbering.  Windows are defined over that compact numbering.
 //   keys     : one u64 per valid k-mer: h0, or KEY_MAX when the common Bloom filter rejects it.
 //   bloom    : bit idx = h0 % bits at byte idx/8, bit idx%8 (LSB first).
-#include <hip/hip_runtime.h>
-
-#include <execinfo.h>
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-#include <mutex>
-#include <thread>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdint>
-#include <cstdlib>
-#include <cstring>
-#include <atomic>
-#include <chrono>
-#include <map>
-#include <set>
-#include <string>
-#include <tuple>
-#include <vector>
-
-#include <rocprim/rocprim.hpp>
-
-#include "../../include/ntsynt_hip.h"
-#include "nts_device.h"
-#include "nts_knobs.h"
-
-using namespace nts;
-
-// ---- device memory accounting ---------------------------------------------------------------------------------------
-// Every device allocation of the library goes through dev_malloc / dev_free: live bytes and their high-water mark per
-// process (all contexts), read by nts_mem_stats.  The reference publishes exactly two figures per run, wall clock and peak
-// memory (README.md:156-158; `--benchmark` records the RSS of every rule, bin/ntsynt_run_pipeline.smk:26-35); its HBM
-// counterpart is this mark.
-namespace nts_mem {
-std::mutex mu;
-struct Slab;
-struct Block
-{
-  size_t bytes;
-  int device;     // -1: allocated with flags (never cached)
-  Slab* slab;     // the cached allocation the block was cut from; nullptr: a hipMalloc of its own
-  size_t off;
-};
-std::map<void*, Block> sizes;
-std::atomic<uint64_t> live{0}, peak{0};
-// calls of hipMalloc / hipFree made through here and the host time they took (nts_alloc_stats: what a cold call spends allocating)
-std::atomic<uint64_t> alloc_calls{0}, alloc_ns{0};
-// what else a leg of a run wants to know about its allocations (nts_mem_events): allocations that failed and were tried again after the
-// cache was emptied, bytes asked of / given back to the driver, host time spent waiting for the device before a block was kept
-std::atomic<uint64_t> oom_retries{0}, driver_bytes_in{0}, driver_bytes_out{0}, free_sync_ns{0}, reserve_calls{0};
-struct AllocClock
-{
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  ~AllocClock()
-  {
-    alloc_calls.fetch_add(1);
-    alloc_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
-  }
-};
-
-// Freed blocks are kept (up to CACHE_LIMIT bytes in all) and handed out again, whole or IN PIECES: a freed hipMalloc allocation becomes a
-// "slab" whose free ranges are indexed by size; a request takes the smallest free range that holds it and leaves the rest of the range
-// in the index; a piece that comes back is joined with its free neighbours.  Why: on some boxes of the pool this build runs on a
-// hipMalloc takes 20-100 ms now and then (the driver's round-4 line: 94.8 ms for the first sketch of a fresh genome; builder boxes in
-// round 5: 45.9 and 98.6 ms in the 41 allocations of a process's first sketch, 111.9 ms in the FIVE allocations of a later genome's
-// 2-bit image and tables, where the box next to it takes 0.04 ms: bench.py `cold`), and every genome, filter and context of a run
-// allocates and frees: 2-bit images, tables, 14.8 GB filters, the FASTA ingest's 3 GB image given back before the first sketch.  With
-// exact-size reuse only (round 5's first version) the first sketch of a process still went to the driver 41 times -- nothing it asks
-// for has the size of anything freed before it; cut from what the ingest or an earlier filter left, it does not.  A slab goes back to
-// the driver when it is wholly free and the cache is over its limit, when an allocation fails (every wholly free slab is released
-// and the allocation tried again) and on nts_mem_trim.  `live` / `peak` count blocks in use, not cached ranges.
-constexpr uint64_t CACHE_LIMIT = 96ull << 30;
-constexpr size_t CACHE_MIN_BLOCK = 64u << 10; // requests below this are "small": served from slabs of their own (SMALL_SLAB bytes each), so
-                                               // that a long-lived 4 KB workspace never holds a multi-GB allocation in the cache
-constexpr size_t SMALL_SLAB = 8u << 20;
-constexpr size_t SMALL_GRAIN = 256;
-constexpr size_t GRAIN = 4096;                 // cached requests are rounded up to this; pieces are cut at multiples of it
-struct Slab
-{
-  char* base;
-  size_t bytes;
-  int device;
-  std::map<size_t, size_t> free; // offset -> length of the free ranges, none adjacent to another
-  size_t in_use = 0;
-  bool small = false;  // serves requests below CACHE_MIN_BLOCK only
-  bool pinned = false; // reserved ahead of a run (nts_mem_reserve): stays when the cache is over its limit; leaves on trim / when an allocation fails
-};
-// (device * 2 + small, length, address): lower_bound = the smallest range of that kind that holds a request
-typedef std::tuple<int, size_t, char*> FreeKey;
-inline int kind_of(const Slab* sl) { return sl->device * 2 + (sl->small ? 1 : 0); }
-std::map<FreeKey, Slab*> free_index;
-std::set<Slab*> slabs;
-uint64_t cached_bytes = 0; // sum of the free ranges
-uint64_t cached_pinned = 0; // ... of which in reserved slabs (not counted against CACHE_LIMIT: they were asked for)
-uint64_t cached_small = 0;  // ... of which in the slabs of the small requests (nts_mem_cache_stats leaves them out)
-std::atomic<uint64_t> cache_hits{0};
-
-inline void count_live(size_t n)
-{
-  const uint64_t now = live.fetch_add(n) + n;
-  uint64_t seen = peak.load();
-  while (now > seen && !peak.compare_exchange_weak(seen, now)) {
-  }
-}
-
-// (callers hold `mu`)
-inline void range_add(Slab* sl, size_t off, size_t len)
-{
-  sl->free[off] = len;
-  free_index[FreeKey(kind_of(sl), len, sl->base + off)] = sl;
-  cached_bytes += len;
-  if (sl->pinned) cached_pinned += len;
-  if (sl->small) cached_small += len;
-}
-inline void range_del(Slab* sl, size_t off, size_t len)
-{
-  sl->free.erase(off);
-  free_index.erase(FreeKey(kind_of(sl), len, sl->base + off));
-  cached_bytes -= len;
-  if (sl->pinned) cached_pinned -= len;
-  if (sl->small) cached_small -= len;
-}
-// [off, off + len) of the slab is free again: joined with the free ranges that touch it
-inline void range_release(Slab* sl, size_t off, size_t len)
-{
-  auto next = sl->free.find(off + len);
-  if (next != sl->free.end()) {
-    const size_t nl = next->second;
-    range_del(sl, off + len, nl);
-    len += nl;
-  }
-  auto prev = sl->free.lower_bound(off);
-  if (prev != sl->free.begin()) {
-    --prev;
-    if (prev->first + prev->second == off) {
-      const size_t po = prev->first, pl = prev->second;
-      range_del(sl, po, pl);
-      off = po;
-      len += pl;
-    }
-  }
-  range_add(sl, off, len);
-}
-// wholly free slabs leave the cache while it holds more than `limit` bytes (the largest first); the caller frees what `gone` collects
-inline void shed(uint64_t limit, std::vector<void*>& gone, bool pinned_too = false)
-{
-  while (cached_bytes - (pinned_too ? 0 : cached_pinned) > limit) {
-    Slab* pick = nullptr;
-    for (Slab* sl : slabs)
-      if (sl->in_use == 0 && (pinned_too || !sl->pinned) && (!pick || sl->bytes > pick->bytes)) pick = sl;
-    if (!pick) break;
-    range_del(pick, 0, pick->bytes); // (wholly free: one range)
-    driver_bytes_out.fetch_add(pick->bytes);
-    gone.push_back(pick->base);
-    slabs.erase(pick);
-    delete pick;
-  }
-}
-
-// every wholly free slab back to the driver; returns the bytes released
-inline uint64_t trim()
-{
-  std::vector<void*> gone;
-  uint64_t before = 0, after = 0;
-  {
-    std::lock_guard<std::mutex> g(mu);
-    before = cached_bytes - cached_small; // (the small requests' slabs go too when wholly free; the figure reported is the large blocks')
-    shed(0, gone, true);
-    after = cached_bytes - cached_small;
-  }
-  for (void* q : gone) {
-    AllocClock clk;
-    ::hipFree(q);
-  }
-  return before - after;
-}
-
-// one hipMalloc of `bytes` that goes straight into the cache as a free slab (callers do not hold `mu`)
-inline hipError_t slab_from_driver(int dev, size_t bytes, bool small, bool pinned)
-{
-  void* q = nullptr;
-  hipError_t e;
-  {
-    AllocClock clk;
-    e = ::hipMalloc(&q, bytes);
-  }
-  if (e != hipSuccess || !q) return e == hipSuccess ? hipErrorOutOfMemory : e;
-  driver_bytes_in.fetch_add(bytes);
-  std::lock_guard<std::mutex> g(mu);
-  Slab* sl = new Slab();
-  sl->base = (char*)q;
-  sl->bytes = bytes;
-  sl->device = dev;
-  sl->small = small;
-  sl->pinned = pinned;
-  slabs.insert(sl);
-  range_add(sl, 0, bytes);
-  return hipSuccess;
-}
-
-// (callers hold `mu`) a piece of `need` bytes from the smallest free range of the kind that holds it
-inline bool cut_from_cache(int dev, bool small, size_t need, size_t min_rest, void** p)
-{
-  auto it = free_index.lower_bound(FreeKey(dev * 2 + (small ? 1 : 0), need, nullptr));
-  if (it == free_index.end() || std::get<0>(it->first) != dev * 2 + (small ? 1 : 0)) return false;
-  Slab* sl = it->second;
-  const size_t len = std::get<1>(it->first), off = (size_t)(std::get<2>(it->first) - sl->base);
-  range_del(sl, off, len);
-  size_t take = need;
-  if (len - need >= min_rest)
-    range_add(sl, off + need, len - need); // (what is left stays in the index; a sliver that no request could use goes along)
-  else
-    take = len;
-  sl->in_use += take;
-  *p = sl->base + off;
-  sizes[*p] = { take, dev, sl, off };
-  cache_hits.fetch_add(1);
-  count_live(take);
-  return true;
-}
-
-inline hipError_t dev_malloc(void** p, size_t n)
-{
-  int dev = 0;
-  ::hipGetDevice(&dev);
-  const bool small = n < CACHE_MIN_BLOCK;
-  if (small && n) {
-    // small requests live in slabs of their own: the first one of a process (or the one that finds them full) asks the driver for a slab
-    const size_t need = (n + SMALL_GRAIN - 1) / SMALL_GRAIN * SMALL_GRAIN;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-      {
-        std::lock_guard<std::mutex> g(mu);
-        if (cut_from_cache(dev, true, need, SMALL_GRAIN, p)) return hipSuccess;
-      }
-      if (attempt == 0 && slab_from_driver(dev, SMALL_SLAB, true, true) != hipSuccess) {
-        (void)hipGetLastError();
-        break;
-      }
-    }
-  }
-  const size_t need = (n + GRAIN - 1) / GRAIN * GRAIN;
-  if (n && !small) {
-    std::lock_guard<std::mutex> g(mu);
-    if (cut_from_cache(dev, false, need, CACHE_MIN_BLOCK, p)) return hipSuccess;
-  }
-  hipError_t e;
-  {
-    AllocClock clk;
-    e = ::hipMalloc(p, small ? n : need);
-  }
-  if (e == hipErrorOutOfMemory && trim() > 0) { // (what the cache held may be what was missing)
-    (void)hipGetLastError();
-    oom_retries.fetch_add(1);
-    AllocClock clk;
-    e = ::hipMalloc(p, small ? n : need);
-  }
-  if (e == hipSuccess && *p) {
-    driver_bytes_in.fetch_add(small ? n : need);
-    {
-      std::lock_guard<std::mutex> g(mu);
-      sizes[*p] = { small ? n : need, dev, nullptr, 0 };
-    }
-    count_live(small ? n : need);
-  }
-  return e;
-}
-
-// `bytes` of device memory taken from the driver in ONE call and kept in the cache for the requests to come (nts_mem_reserve).  When
-// the device cannot give that much, what it can (less a margin) is taken instead; *got = the bytes reserved.
-inline hipError_t reserve(int dev, uint64_t bytes, uint64_t* got)
-{
-  if (got) *got = 0;
-  int cur = 0;
-  ::hipGetDevice(&cur);
-  if (cur != dev) ::hipSetDevice(dev);
-  size_t fr = 0, tot = 0;
-  hipError_t e = ::hipMemGetInfo(&fr, &tot);
-  if (e == hipSuccess) {
-    const size_t margin = 2ull << 30;
-    if (bytes + margin > fr) bytes = fr > margin ? fr - margin : 0;
-    bytes = bytes / GRAIN * GRAIN;
-    if (bytes >= CACHE_MIN_BLOCK) {
-      e = slab_from_driver(dev, bytes, false, true);
-      if (e == hipSuccess) {
-        reserve_calls.fetch_add(1);
-        if (got) *got = bytes;
-      }
-    }
-    bool have_small = false;
-    {
-      std::lock_guard<std::mutex> g(mu);
-      for (Slab* sl : slabs) have_small |= sl->small && sl->device == dev;
-    }
-    if (e == hipSuccess && !have_small) (void)slab_from_driver(dev, SMALL_SLAB, true, true);
-  }
-  if (e != hipSuccess) (void)hipGetLastError();
-  if (cur != dev) ::hipSetDevice(cur);
-  return e;
-}
-
-template <class T>
-inline hipError_t dev_malloc(T** p, size_t n)
-{
-  return dev_malloc((void**)p, n);
-}
-
-// the same with allocation flags (hipDeviceMallocUncached / hipDeviceMallocFinegrained: how the L2 treats the memory); never cached
-inline hipError_t dev_malloc_flags(void** p, size_t n, unsigned flags)
-{
-  AllocClock clk;
-  const hipError_t e = ::hipExtMallocWithFlags(p, n, flags);
-  if (e == hipSuccess && *p) {
-    {
-      std::lock_guard<std::mutex> g(mu);
-      sizes[*p] = { n, -1, nullptr, 0 };
-    }
-    count_live(n);
-  }
-  return e;
-}
-
-inline hipError_t dev_free(void* p)
-{
-  if (!p) return hipSuccess;
-  Block blk = { 0, -1, nullptr, 0 };
-  bool known = false;
-  {
-    std::lock_guard<std::mutex> g(mu);
-    auto it = sizes.find(p);
-    if (it != sizes.end()) {
-      blk = it->second;
-      known = true;
-    }
-  }
-  if (known && blk.device >= 0 && (blk.slab || blk.bytes >= CACHE_MIN_BLOCK)) {
-    // what hipFree does before it gives memory back: nothing queued on the device still uses the block (it may be handed to another
-    // stream or context next).  The block stays in `sizes` until then: nobody else can be given its range.
-    int cur = 0;
-    ::hipGetDevice(&cur);
-    if (cur != blk.device) ::hipSetDevice(blk.device);
-    const auto ts = std::chrono::steady_clock::now();
-    const hipError_t es = ::hipDeviceSynchronize();
-    free_sync_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ts).count());
-    if (cur != blk.device) ::hipSetDevice(cur);
-    std::vector<void*> gone;
-    bool kept = false;
-    {
-      std::lock_guard<std::mutex> g(mu);
-      sizes.erase(p);
-      live.fetch_sub(blk.bytes);
-      if (blk.slab) { // a piece of a cached allocation goes back to it whatever happened (the slab is freed as a whole, or not at all)
-        blk.slab->in_use -= blk.bytes;
-        range_release(blk.slab, blk.off, blk.bytes);
-        kept = true;
-      } else if (es == hipSuccess) {
-        Slab* sl = new Slab();
-        sl->base = (char*)p;
-        sl->bytes = blk.bytes;
-        sl->device = blk.device;
-        slabs.insert(sl);
-        range_add(sl, 0, blk.bytes);
-        kept = true;
-      }
-      if (kept) shed(CACHE_LIMIT, gone);
-    }
-    for (void* q : gone) {
-      AllocClock clk;
-      ::hipFree(q);
-    }
-    if (kept) return hipSuccess;
-    driver_bytes_out.fetch_add(blk.bytes);
-    AllocClock clk;
-    return ::hipFree(p);
-  }
-  if (known) {
-    driver_bytes_out.fetch_add(blk.bytes);
-    std::lock_guard<std::mutex> g(mu);
-    sizes.erase(p);
-    live.fetch_sub(blk.bytes);
-  } else {
-    // not a block in use.  Inside a cached allocation it is a second free of a piece (or of the allocation itself): giving the address
-    // to hipFree would take the whole allocation away from under the cache and the pieces in use -- refused, and said once
-    std::lock_guard<std::mutex> g(mu);
-    for (Slab* sl : slabs)
-      if ((char*)p >= sl->base && (char*)p < sl->base + sl->bytes) {
-        static bool said = false;
-        if (!said) {
-          said = true;
-          fprintf(stderr, "ntsynt_hip: device block %p freed twice (ignored)\n", p);
-          void* bt[24];
-          backtrace_symbols_fd(bt, backtrace(bt, 24), 2);
-        }
-        return hipErrorInvalidValue;
-      }
-  }
-  AllocClock clk;
-  return ::hipFree(p);
-}
-} // namespace nts_mem
-using nts_mem::dev_free;
-using nts_mem::dev_malloc;
-using nts_mem::dev_malloc_flags;
-
-static std::atomic<int> g_live_contexts{0};
-// Sketches of several genomes at once (one context each, device.SketchPool / NTS_SKETCH_POOL): the select kernels of the contexts of a
-// device run one after the other -- each waits for the one launched before it -- while a genome's latency-bound tail (compaction,
-// window decisions, gather, uncovered ranges, finalize) floats next to the following genome's select kernel.  Started together the
-// select kernels would share the chip and finish together, and the tails would again find nothing to hide behind.
-namespace nts_chain {
-std::mutex mu;
-hipEvent_t ev[32] = {};
-bool live[32] = {};
-} // namespace nts_chain
+#include "nts_internal.h"
 
 namespace {
-
-constexpr uint64_t PAD = 256;          // invalid bytes before and after the sequence
-constexpr int HASH_THREADS = 256;
-constexpr int HASH_PER_THREAD = 32;    // consecutive k-mers rolled by one lane
-constexpr int WIN_THREADS = 512;     // 8 waves share one tile: shorter phases, twice the waves per CU for the same LDS
-constexpr uint32_t WIN_TILE = 4096;    // windows per workgroup
-constexpr uint32_t WIN_CHUNK = 16;     // elements scanned sequentially by one lane
-constexpr uint32_t WIN_MAX_W = 12000;  // LDS bound: (WIN_TILE + w) * 8 B + tables <= 160 KiB
-constexpr uint32_t MAIL_WORDS = 32768; // 64-bit words of the pinned result mailbox (nts_ctx::mail)
-
-std::string g_init_error;
-
-struct Timing
-{
-  double ms = 0;
-  uint64_t launches = 0;
-};
-
-} // namespace
-
-struct nts_ctx
-{
-  int device = 0;
-  bool counted = false; // among the process's live contexts (nts_init got through)
-  hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr; // bulk device -> host copies that may run behind later kernels (nts_bf_download)
-  // pinned host page the device writes small results into (counters, the first uncovered ranges): one stream
-  // synchronisation reads them, instead of a chain of tiny device -> host copies
-  uint64_t* mail = nullptr;     // host address
-  uint64_t* d_mail = nullptr;   // the same memory as the device sees it
-  uint64_t mail_seq = 0;        // last arrival flag posted
-  uint8_t* stage = nullptr;     // pinned staging area for small host -> device tables (grow-only)
-  size_t stage_bytes = 0;
-  std::string err;
-  int profiling = 0; // 0 off, 1 every kernel group, 2 only the dominant kernels (an event pair costs ~10 us of stream bubble)
-  std::map<std::string, Timing> timings;
-  std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
-  std::map<uint32_t, uint64_t*> init_tabs; // per k: device table for the first k-mer of a lane (HashParams::init)
-  std::vector<hipEvent_t> spare_events; // recycled timing events (creating one costs microseconds of host time)
-  // grow-only device scratch, reused across calls (a ctx serves one call at a time)
-  std::map<std::string, std::pair<void*, size_t>> ws;
-  // sketch policy: 0 auto (pruned when w >= 200), 1 dense, 2 pruned; prune_c/w = fraction of hashes kept as candidates
-  std::vector<std::pair<void*, uint64_t>> mx_pool; // recycled result allocations
-  size_t win_lds_set = 0;
-  bool bin_lds_set = false;
-  uint32_t n_cus = 0; // compute units of the device (asked once)
-  bool small_gap_path = true; // uncovered ranges: device-side sort + merge when they are few (nts_pruned.inc)
-  bool sel_ctl_clean = false; // the pruned pass's control block was cleared by the previous call's last kernel
-  int bf_build_mode = 0; // 0 auto (binned build for large genomes), 1 one atomic per k-mer, 2 binned whenever it applies
-  int sketch_mode = 0;
-  uint32_t prune_c = 0; // 0 = adaptive (from the filter's occupancy), else fixed
-  uint32_t last_c = 0;
-  uint64_t last_candidates = 0, last_gaps = 0, last_gap_kmers = 0;
-  uint64_t last_many_listed = 0; // candidates of k_hash_select_hi tiles that listed more than their slots hold (repeats, pieces)
-  uint64_t last_bf_direct = 0;   // indices of the last partitioned Bloom build that bypassed the buckets (full bucket, lanes in pieces)
-  uint32_t last_comm_sparse = 0; // the last all-reduce of a filter gathered set-bit indices instead of chunks
-  uint64_t last_x2_packed_bytes = 0, last_x2_unpacked_bytes = 0, last_x2_sent_bytes = 0; // the last exchange 2 (nts_comm_last_exchange2)
-  uint32_t last_bf_fallback = 0; // 1: its late list ran full (store-only build fell back to read-and-OR / fused AND build was redone unfused)
-  uint32_t last_bf_sparse_level = 0;     // the last nts_bf_insert_and went the literal way over a sparse running filter (bf_level_sparse)
-  uint64_t last_bf_sparse_accepted = 0;  // and accepted this many k-mers
-  // dense sketch over a sparse filter: summary consulted before the filter, key tiles without an accepted k-mer skipped
-  const uint32_t* cur_summary = nullptr;
-  const uint32_t* cur_fold = nullptr; // folded copy of the filter for the LDS first look (k_hash_accept4), or null
-  int fold_mode = 0;                  // 0 auto, 1 never (tests)
-  bool acc4_lds_set = false;
-  bool acc4r_lds_set = false;
-  uint32_t cur_summary_shift = 0;
-  uint32_t* cur_tile_any = nullptr;
-  // pinned staging buffers + streams of the bulk transfers done by host threads (FASTA bytes up: nts_genome_from_fasta; filter
-  // bits down: nts_bf_save), allocated on first use and kept: allocating pinned memory per call cost more than a small transfer
-  struct IoLane
-  {
-    hipStream_t stream = nullptr;
-    uint8_t* stage[2] = { nullptr, nullptr };
-  };
-  std::vector<IoLane> io_up, io_down;
-  const nts_bf* cur_rep = nullptr; // filter-out filter of the running nts_sketch_ex call (indexlr -r), or null
-  bool elim_needs_full_cap = false; // a call's candidate lists did not fit half the capacity sized for the accepted k-mers (run_pruned)
-  int select_impl = 0;  // candidate selection of the pruned sketch: 0 auto, 1 full-width kernel, 2 upper-halves kernel also for assemblies in pieces
-  int summary_mode = 0; // 0 auto, 1 never (tests)
-  uint32_t last_summary = 0;
-  // tiered selection (nts_tiers.inc): 0 auto, 1 never, 2 wherever it applies; figures of the last call that went that way
-  uint64_t comm_piece = 0;        // bytes per piece of exchange 1's reduce-scatter (0: 256 MiB; NTS_COMM_PIECE at nts_init)
-  int comm_sparse_mode = 0;       // 1: never gather set-bit indices (experiments build: NTS_COMM_SPARSE=0)
-  uint64_t comm_sparse_below = 0; // gather indices when the fullest chunk holds at most this many bits (0: chunk bytes / 128)
-  unsigned io_threads = 8;        // host threads of a FASTA upload (NTS_IO_THREADS at nts_init)
-  int gap_tiers_off = 0;          // 1: the uncovered ranges of the one-threshold selection go to the dense kernels (nts_sketch_tiers mode 1)
-  int tier_mode = 0;
-  double tier_x0 = 0;       // accepted k-mers per window the first tier aims at (0: the default)
-  uint32_t tier_half = 0;   // 1: tiers in steps of 1.5 / 1.33 instead of 2
-  uint64_t last_tier_probes = 0, last_tier_rounds = 0, last_tiers = 0;
-};
-
-struct nts_genome
-{
-  uint64_t n = 0; // bytes of concatenated sequence
-  uint32_t n_rec = 0;
-  uint8_t* d_code = nullptr; // PAD + n + PAD bytes; base i at d_code[PAD + i]
-  // the same bases, 2 bits each, 16 per word (base i in word i/16 at bit 2*(i%16); invalid bases read as 0): the
-  // register-resident base streams of k_hash_select.  Built on first use.
-  mutable uint32_t* d_pack = nullptr;
-  std::vector<uint64_t> rec_off, rec_len;
-  uint64_t total_bases = 0;
-  std::vector<uint64_t> part_bases; // nts_genome_concat: bases of each part (empty for an uploaded genome)
-  // maximal stretches [a,b) of valid bases, clipped to records, ascending
-  std::vector<uint64_t> st_a, st_b;
-  uint64_t* d_rec_off = nullptr; // [n_rec] record offsets on the device
-  // per-k run table + record tables, built on first use and kept on the device (unmasked sketches)
-  mutable std::map<uint32_t, struct GenomeTables*> tables;
-};
-
-struct nts_bf
-{
-  uint64_t bytes = 0;
-  uint64_t alloc_bytes = 0; // bytes behind d_words (>= bytes rounded up to 16; nts_bf_create_sharded: world x chunk)
-  uint32_t* d_words = nullptr;
-  bool owned = true;
-  mutable int64_t popcnt = -1; // cached number of set bits, -1 = unknown (any write invalidates it)
-  uint64_t version = 0;        // bumped by every write through the library
-  // summary of a sparse filter (built on demand by the dense sketch): bit g = "some bit of filter bits [g << shift, (g+1) << shift)
-  // is set"; small enough to stay in the L2, so that a probe of an all-but-empty filter ends there (nts_sketch)
-  mutable uint32_t* d_summary = nullptr;
-  mutable uint64_t summary_words = 0;
-  mutable uint32_t summary_shift = 0;
-  mutable uint64_t summary_version = ~0ULL;
-  mutable double summary_density = 1.0;
-  mutable uint32_t* d_fold = nullptr; // the filter folded onto 2^19 bits (bit i mod 2^19), built with the summary: LDS-resident first look
-  mutable std::mutex mu;              // sketches of several genomes may run on contexts of their own at once (SketchPool): the summary is built once
-};
-
-struct nts_mx
-{
-  uint64_t n = 0;
-  uint64_t cap_bytes = 0; // size of the single allocation behind d_h1 | d_pos | d_rec
-  uint64_t* d_h1 = nullptr;
-  uint32_t* d_rec = nullptr;
-  uint64_t* d_pos = nullptr;
-};
-
-namespace {
-
-#define HIP_TRY(ctx, expr)                                                                          \
-  do {                                                                                              \
-    hipError_t e_ = (expr);                                                                         \
-    if (e_ != hipSuccess) {                                                                         \
-      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                               \
-      return e_ == hipErrorOutOfMemory ? NTS_ENOMEM : NTS_EHIP;                                     \
-    }                                                                                               \
-  } while (0)
-
-int fail(nts_ctx* ctx, int code, const std::string& msg)
-{
-  if (ctx) ctx->err = msg;
-  return code;
-}
-
-// device scratch buffer `name` of at least `bytes` bytes (nullptr + ctx->err on failure)
-void* ws_get(nts_ctx* ctx, const char* name, size_t bytes)
-{
-  auto& b = ctx->ws[name];
-  if (b.second >= bytes && b.first) return b.first;
-  if (b.first) {
-    hipStreamSynchronize(ctx->stream);
-    dev_free(b.first);
-    b.first = nullptr;
-    b.second = 0;
-  }
-  const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
-  void* p = nullptr;
-  hipError_t e = dev_malloc(&p, want);
-  if (e != hipSuccess) {
-    e = dev_malloc(&p, std::max<size_t>(bytes, 256));
-    if (e != hipSuccess) {
-      ctx->err = std::string("hipMalloc scratch '") + name + "': " + hipGetErrorString(e);
-      return nullptr;
-    }
-    b.second = std::max<size_t>(bytes, 256);
-  } else {
-    b.second = want;
-  }
-  b.first = p;
-  return p;
-}
-
-void ws_release(nts_ctx* ctx)
-{
-  for (auto& kv : ctx->ws)
-    if (kv.second.first) dev_free(kv.second.first);
-  ctx->ws.clear();
-}
-
-// `want` lanes (stream + two pinned buffers of `chunk` bytes) of a transfer pool, created on first use; fewer if memory is short
-constexpr uint64_t IO_CHUNK = (uint64_t)8 << 20;
-unsigned io_lanes(nts_ctx* ctx, std::vector<nts_ctx::IoLane>& pool, unsigned want)
-{
-  while (pool.size() < want) {
-    nts_ctx::IoLane l;
-    if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) break;
-    if (hipHostMalloc((void**)&l.stage[0], IO_CHUNK) != hipSuccess || hipHostMalloc((void**)&l.stage[1], IO_CHUNK) != hipSuccess) {
-      if (l.stage[0]) hipHostFree(l.stage[0]);
-      hipStreamDestroy(l.stream);
-      break;
-    }
-    pool.push_back(l);
-  }
-  return (unsigned)std::min<size_t>(pool.size(), want);
-}
-
-void io_release(std::vector<nts_ctx::IoLane>& pool)
-{
-  for (auto& l : pool) {
-    hipStreamDestroy(l.stream);
-    hipHostFree(l.stage[0]);
-    hipHostFree(l.stage[1]);
-  }
-  pool.clear();
-}
-
-// ---- timing: HIP events on the context's stream around each kernel ---------------------------
-struct ScopedTimer
-{
-  nts_ctx* ctx;
-  const char* name;
-  hipEvent_t a = nullptr, b = nullptr;
-  bool on;
-  ScopedTimer(nts_ctx* c, const char* n, bool major = false)
-    : ctx(c)
-    , name(n)
-    , on(c->profiling == 1 || (c->profiling == 2 && major))
-  {
-    if (on) {
-      a = take();
-      b = take();
-      hipEventRecord(a, ctx->stream);
-    }
-  }
-  hipEvent_t take()
-  {
-    hipEvent_t e = nullptr;
-    if (!ctx->spare_events.empty()) {
-      e = ctx->spare_events.back();
-      ctx->spare_events.pop_back();
-    } else {
-      hipEventCreate(&e);
-    }
-    return e;
-  }
-  ~ScopedTimer()
-  {
-    if (on) {
-      hipEventRecord(b, ctx->stream);
-      ctx->pending.push_back({ name, { a, b } });
-    }
-  }
-};
-
-void drain_timings(nts_ctx* ctx)
-{
-  for (auto& p : ctx->pending) {
-    hipEventSynchronize(p.second.second);
-    float ms = 0;
-    hipEventElapsedTime(&ms, p.second.first, p.second.second);
-    auto& t = ctx->timings[p.first];
-    t.ms += ms;
-    t.launches += 1;
-    ctx->spare_events.push_back(p.second.first);
-    ctx->spare_events.push_back(p.second.second);
-  }
-  ctx->pending.clear();
-}
 
 // =================================================================================================
 // Kernels
@@ -1239,8 +554,23 @@ struct WinParams
   // if not null (whole-genome dense pass over a sparse filter): tile_any[t] == 0 <=> key tile t holds no accepted k-mer and
   // was not written; its keys count as KEY_MAX
   const uint32_t* tile_any;
+  // k_window_min<true> (short windows, whole genome): no key array -- the tile hashes and probes its own k-mers
+  const uint8_t* code;
+  const uint64_t* run_pos;
+  const uint64_t* run_vstart;
+  uint32_t n_runs;
+  HashParams hp;
+  const uint32_t* bf;
+  FastMod fm;
 };
 constexpr uint32_t N_SEG = 64;
+// Short windows (w < WIN_FUSE_W: the last refinement round's w = 10, -d < 1's defaults bin/ntSynt:89-91, and anything below 64): the
+// pruned selection does not apply (its tiles list c/w of their k-mers: everything), so every k-mer is hashed and probed.  Through
+// the key array that is 8 bytes written and read back per k-mer (2 x 24 GB per 3 Gbp genome: k_hash<MODE_KEYS> 68 ms + k_window_min
+// 21 ms); the halo a window tile shares with its neighbour is (w - 1) / 4096 < 2 % here, so the tile computes the keys it needs
+// itself, in LDS, and the array is never made.  (At w = 1000 the halo is 24 %: there the array stays.)
+constexpr uint32_t WIN_FUSE_W = 64;
+constexpr uint32_t WIN_FUSE_PER = (WIN_TILE + 1 + WIN_FUSE_W - 2 + WIN_THREADS - 1) / WIN_THREADS; // elements a lane hashes: 9
 
 __device__ __forceinline__ uint32_t pe(uint32_t e)
 {
@@ -1271,6 +601,7 @@ __device__ __forceinline__ uint32_t better_idx(const uint64_t* s_key, uint32_t a
   return a > b ? a : b;
 }
 
+template <bool FUSED>
 __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1308,6 +639,109 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
   uint16_t* s_st = s_list + ((n_win + 8) & ~7u);                     // levels x n_chunks
   if (threadIdx.x == 0) s_ctl[0] = 0;
 
+  if (FUSED) {
+    // ---- compute: the tile's own keys (h0 of every k-mer of [ja, jb), KEY_MAX where the filter rejects it) -------------------
+    uint64_t* s_tab = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(s_st + (size_t)P.levels * n_chunks) + 15u) & ~(uintptr_t)15u); // [36] roll tables, seeds
+    uint8_t* s_seq = reinterpret_cast<uint8_t*>(s_tab + 36); // the tile's bases, one byte each (16-byte aligned: 36 words = 288 bytes)
+    const uint32_t tid = threadIdx.x, k = P.hp.k;
+    if (tid < 16) {
+      s_tab[tid] = P.hp.roll_f[tid];
+      s_tab[16 + tid] = P.hp.roll_r[tid];
+    }
+    if (tid < 4) s_tab[32 + tid] = P.hp.seed[tid];
+    // run holding ja (same for every lane: broadcast loads)
+    uint32_t rl = 0, rh = P.n_runs;
+    while (rh - rl > 1) {
+      const uint32_t mid = rl + ((rh - rl) >> 1);
+      if (P.run_vstart[mid] <= ja)
+        rl = mid;
+      else
+        rh = mid;
+    }
+    const uint64_t v0 = P.run_vstart[rl], v1 = P.run_vstart[rl + 1];
+    const bool single = jb <= v1 && k <= FAST_K_MAX;
+    const uint32_t e_lo = tid * WIN_FUSE_PER;
+    const uint32_t n_mine = e_lo < E ? min(WIN_FUSE_PER, E - e_lo) : 0u;
+    if (single) {
+      const uint64_t P0 = P.run_pos[rl] + (ja - v0);
+      const uint32_t a = (uint32_t)(P0 & 15u);
+      const uint8_t* src = P.code + (P0 - a);
+      const uint32_t n16 = (a + E + k - 1 + 15u) >> 4;
+      for (uint32_t cidx = tid; cidx < n16; cidx += WIN_THREADS)
+        reinterpret_cast<uint4*>(s_seq)[cidx] = *reinterpret_cast<const uint4*>(src + 16u * cidx);
+    }
+    __syncthreads(); // (uniform: the tables, and the staged bases of a tile inside one run)
+    if (single) {
+      const uint64_t P0 = P.run_pos[rl] + (ja - v0);
+      const uint32_t a = (uint32_t)(P0 & 15u);
+      auto base_at = [&](uint32_t x) -> uint32_t { return s_seq[x] & 3u; };
+      uint32_t sx = a + e_lo;
+      uint64_t f = 0, r = 0;
+      if (n_mine) hash_init(P.hp, [&](uint32_t i) { return base_at(sx + i); }, f, r);
+      uint64_t h[WIN_FUSE_PER];
+#pragma unroll
+      for (int u = 0; u < (int)WIN_FUSE_PER; ++u) {
+        h[u] = f + r;
+        if ((uint32_t)u + 1u < n_mine) { // (the bases past the lane's last k-mer may lie outside what was staged)
+          const uint32_t cout = base_at(sx), cin = base_at(sx + k);
+          f = srol1(f) ^ s_tab[cin * 4 + cout];
+          r = sror1(r ^ s_tab[16 + cin * 4 + cout]);
+          ++sx;
+        }
+      }
+      if (P.bf != nullptr) {
+        uint32_t wd[WIN_FUSE_PER], bit[WIN_FUSE_PER];
+#pragma unroll
+        for (int u = 0; u < (int)WIN_FUSE_PER; ++u) {
+          const bool wanted = (uint32_t)u < n_mine;
+          const uint64_t idx = P.fm(h[u]);
+          wd[u] = P.bf[wanted ? idx >> 5 : 0ULL]; // (word 0 is cached; the result is not used)
+          bit[u] = wanted ? (uint32_t)idx & 31u : 32u;
+        }
+#pragma unroll
+        for (int u = 0; u < (int)WIN_FUSE_PER; ++u)
+          if (bit[u] == 32u || !((wd[u] >> bit[u]) & 1u)) h[u] = KEY_MAX;
+      }
+#pragma unroll
+      for (int u = 0; u < (int)WIN_FUSE_PER; ++u)
+        if ((uint32_t)u < n_mine) s_key[pe(e_lo + (uint32_t)u)] = h[u];
+    } else if (n_mine) {
+      // a tile over several runs (N stretches inside the record) or a very long k: every lane walks the run table itself
+      uint64_t j = ja + e_lo;
+      const uint64_t j_end = j + n_mine;
+      uint32_t ri = rl;
+      rh = P.n_runs;
+      while (rh - ri > 1) {
+        const uint32_t mid = ri + ((rh - ri) >> 1);
+        if (P.run_vstart[mid] <= j)
+          ri = mid;
+        else
+          rh = mid;
+      }
+      while (j < j_end) {
+        const uint64_t rv0 = P.run_vstart[ri], rv1 = P.run_vstart[ri + 1];
+        const uint64_t seg_end = min(j_end, rv1);
+        uint64_t p = P.run_pos[ri] + (j - rv0);
+        uint64_t f = 0, r = 0;
+        for (uint32_t i = 0; i < k; ++i) {
+          f = srol1(f) ^ s_tab[32 + P.code[p + i]];
+          r = srol1(r) ^ s_tab[32 + 3 - P.code[p + k - 1 - i]];
+        }
+        for (;;) {
+          uint64_t key = f + r;
+          if (P.bf != nullptr && !bf_test(P.bf, P.fm(key))) key = KEY_MAX;
+          s_key[pe((uint32_t)(j - ja))] = key;
+          ++j;
+          if (j >= seg_end) break;
+          const uint32_t cout = P.code[p], cin = P.code[p + k];
+          f = srol1(f) ^ s_tab[cin * 4 + cout];
+          r = sror1(r ^ s_tab[16 + cin * 4 + cout]);
+          ++p;
+        }
+        ++ri;
+      }
+    }
+  } else
   // ---- load: walk the key tiles the range [ja, jb) touches, one transposed row at a time -----------
   for (uint64_t tile = ja / KEY_TILE; tile * KEY_TILE < jb; ++tile) {
     const uint64_t tb = tile * KEY_TILE;
@@ -1740,59 +1174,11 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ j
   pos[i] = gp - rec_off[a];
 }
 
-__global__ __launch_bounds__(256) void k_bf_and(uint4* __restrict__ acc, const uint4* __restrict__ other, uint64_t n16)
-{
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < n16; i += stride) {
-    uint4 a = acc[i];
-    const uint4 o = other[i];
-    a.x &= o.x;
-    a.y &= o.y;
-    a.z &= o.z;
-    a.w &= o.w;
-    acc[i] = a;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_bf_popcount(const uint4* __restrict__ words, uint64_t n16, unsigned long long* __restrict__ total)
-{
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  unsigned long long acc = 0;
-  for (; i < n16; i += stride) {
-    const uint4 v = words[i];
-    acc += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-  }
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(total, acc);
-}
 
 // =================================================================================================
 // Host helpers
 // =================================================================================================
 
-HashParams make_hash_params(uint32_t k)
-{
-  HashParams hp;
-  const uint64_t seed[4] = { SEED_A, SEED_C, SEED_G, SEED_T };
-  uint64_t rotk[4];
-  for (int c = 0; c < 4; ++c) {
-    uint64_t x = seed[c];
-    for (uint32_t i = 0; i < k; ++i) x = srol1(x);
-    rotk[c] = x;
-    hp.seed[c] = seed[c];
-  }
-  for (int cin = 0; cin < 4; ++cin)
-    for (int cout = 0; cout < 4; ++cout) {
-      hp.roll_f[cin * 4 + cout] = seed[cin] ^ rotk[cout];
-      hp.roll_r[cin * 4 + cout] = rotk[3 - cin] ^ seed[3 - cout];
-    }
-  hp.k = k;
-  hp.init = nullptr;
-  hp.init4 = nullptr;
-  return hp;
-}
 
 // hash parameters with the device-resident init table (cached per k in the context)
 int hash_params_for(nts_ctx* ctx, uint32_t k, HashParams* out)
@@ -1846,20 +1232,6 @@ __global__ __launch_bounds__(256) void k_mod_indices(uint64_t* __restrict__ h, u
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) h[i] = fm(h[i]);
 }
 
-FastMod make_fastmod(uint64_t m)
-{
-  FastMod fm;
-  fm.m = m;
-  // floor(2^64 / m) for m >= 2, not a power of two or otherwise: (2^64-1)/m differs only when m | 2^64
-  unsigned __int128 one = ((unsigned __int128)1) << 64;
-  fm.inv = (uint64_t)(one / m);
-  fm.inv32 = (uint32_t)fm.inv;
-  fm.m_lo = (uint32_t)m;
-  fm.m_hi = (uint32_t)(m >> 32);
-  fm.form = (fm.inv >> 32) ? 0u : ((m >> 38) ? 1u : 2u);
-  if (const char* e = NTS_KNOB("NTS_FASTMOD_FORM")) fm.form = std::min<uint32_t>(fm.form, (uint32_t)atoi(e)); // (tests: the longer forms)
-  return fm;
-}
 
 inline uint64_t key_buffer_elems(uint64_t n_valid)
 {
@@ -2318,7 +1690,7 @@ int nts_bf_size_bytes(uint64_t genome_bp, double fpr, uint64_t* approx_bytes, ui
 
 // The part of a genome's set-up that needs its codes in HBM: maximal stretches of valid bases (clipped to records) and the
 // record table on the device.  g->n, g->n_rec, g->rec_off, g->rec_len and g->d_code are in place.
-static int genome_finish(nts_ctx* ctx, nts_genome* g)
+int nts_genome_finish_impl(nts_ctx* ctx, nts_genome* g) // (also called by the FASTA parse, nts_comm_fasta.hip)
 {
   const uint64_t n = g->n;
   const uint32_t n_rec = g->n_rec;
@@ -2413,7 +1785,7 @@ int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64
     const uint64_t blocks = (n + 4095) / 4096;
     hipLaunchKernelGGL(k_encode, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n);
   }
-  if (int rc = genome_finish(ctx, g)) {
+  if (int rc = nts_genome_finish_impl(ctx, g)) {
     dev_free(g->d_code);
     dev_free(g->d_rec_off);
     delete g;
@@ -3258,9 +2630,20 @@ uint64_t tiles_of(const std::vector<uint64_t>& nv, uint32_t w, std::vector<uint6
 }
 
 // dense window kernel over (pseudo-)records already resident on the device; keys must be present for them
+struct WinFuse // what k_window_min<true> hashes and probes with (launch_window_dense: d_keys == nullptr)
+{
+  const uint8_t* code;
+  const uint64_t* run_pos;
+  const uint64_t* run_vstart;
+  uint32_t n_runs;
+  HashParams hp;
+  const uint32_t* bf;
+  FastMod fm;
+};
+
 int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vs, const uint64_t* d_nv, const uint64_t* d_ts,
                         uint32_t n_rec, uint64_t n_tiles, uint32_t w, const OutSegs& out, const char* tag,
-                        const uint32_t* d_tile_ids = nullptr, uint64_t n_tile_ids = 0)
+                        const uint32_t* d_tile_ids = nullptr, uint64_t n_tile_ids = 0, const WinFuse* fuse = nullptr)
 {
   if (n_tiles == 0) return NTS_OK;
   if (n_tiles > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "too many window tiles for one launch");
@@ -3279,10 +2662,16 @@ int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_
   while ((1u << P.levels) <= max_full) ++P.levels;
   const uint32_t E_max = WIN_TILE + 1 + w - 1;
   const uint32_t chunks_max = (E_max + P.chunk - 1) / P.chunk;
-  const size_t lds = (size_t)(E_max + E_max / 32 + 2) * 8 + 16 + (size_t)(WIN_TILE + 16) * 2 + (size_t)P.levels * chunks_max * 2 + 64;
+  size_t lds = (size_t)(E_max + E_max / 32 + 2) * 8 + 16 + (size_t)(WIN_TILE + 16) * 2 + (size_t)P.levels * chunks_max * 2 + 64;
+  if (fuse) lds += 16 + 36 * 8 + (size_t)E_max + FAST_K_MAX + 48; // roll tables and seeds, the tile's bases
   if (lds > 160 * 1024) return fail(ctx, NTS_ERANGE, "window tile does not fit LDS");
-  if (lds > ctx->win_lds_set) {
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_window_min, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (fuse) {
+    if (lds > ctx->win_fused_lds_set) {
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_window_min<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ctx->win_fused_lds_set = lds;
+    }
+  } else if (lds > ctx->win_lds_set) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_window_min<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ctx->win_lds_set = lds;
   }
   P.out_j = out.d_j;
@@ -3291,9 +2680,25 @@ int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_
   P.seg_cap = out.seg_cap;
   P.tile_cnt = out.d_tile_cnt;
   P.tile_cap = out.tile_cap;
-  P.tile_any = (d_tile_ids == nullptr && out.d_tile_cnt == nullptr) ? ctx->cur_tile_any : nullptr;
-  ScopedTimer t(ctx, tag);
-  hipLaunchKernelGGL(k_window_min, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
+  P.tile_any = (d_tile_ids == nullptr && out.d_tile_cnt == nullptr && !fuse) ? ctx->cur_tile_any : nullptr;
+  P.code = nullptr;
+  P.run_pos = P.run_vstart = nullptr;
+  P.n_runs = 0;
+  P.bf = nullptr;
+  if (fuse) {
+    P.code = fuse->code;
+    P.run_pos = fuse->run_pos;
+    P.run_vstart = fuse->run_vstart;
+    P.n_runs = fuse->n_runs;
+    P.hp = fuse->hp;
+    P.bf = fuse->bf;
+    P.fm = fuse->fm;
+  }
+  ScopedTimer t(ctx, tag, fuse != nullptr);
+  if (fuse)
+    hipLaunchKernelGGL(k_window_min<true>, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
+  else
+    hipLaunchKernelGGL(k_window_min<false>, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
   return NTS_OK;
 }
@@ -3455,9 +2860,28 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     if ((rc = T.win_tiles_device(ctx, w, &d_ts))) return rc;
     n_rec = g->n_rec;
   }
+  // short windows over the whole genome: the window tiles hash and probe their own k-mers, no key array (k_window_min<true>)
+  WinFuse fuse_args;
+  const WinFuse* fuse = nullptr;
+  if (!pseudo_vstart && w < WIN_FUSE_W && k <= FAST_K_MAX && !ctx->cur_rep && !(ctx->cur_summary && ctx->cur_tile_any) &&
+      !(NTS_KNOB("NTS_WIN_FUSE") && atoi(NTS_KNOB("NTS_WIN_FUSE")) == 0)) {
+    fuse_args.code = g->d_code + PAD;
+    fuse_args.run_pos = T.d_run_pos;
+    fuse_args.run_vstart = T.d_run_vstart;
+    fuse_args.n_runs = T.n_runs;
+    if (int rc_hp = hash_params_for(ctx, k, &fuse_args.hp)) return rc_hp;
+    fuse_args.bf = filter ? filter->d_words : nullptr;
+    fuse_args.fm = make_fastmod((filter ? filter->bytes : 8) * 8);
+    fuse = &fuse_args;
+  }
   // keys: one slot per key tile of the genome, or only the listed tiles (uncovered ranges) in a compact buffer
-  DN_WS(d_keys, uint64_t*, d_tiles ? "gap_keys" : "keys", (d_tiles ? n_tile_ids * KEY_TILE : key_buffer_elems(rt.n_valid)) * 8);
-  if ((rc = launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, T, k, filter, nullptr, d_keys, d_tiles, n_tile_ids, d_spans))) return rc;
+  uint64_t* d_keys = nullptr;
+  if (!fuse) {
+    d_keys = (uint64_t*)ws_get(ctx, d_tiles ? "gap_keys" : "keys", (d_tiles ? n_tile_ids * KEY_TILE : key_buffer_elems(rt.n_valid)) * 8);
+    if (!d_keys) return NTS_ENOMEM;
+    if ((rc = launch_hash<MODE_KEYS>(ctx, filter ? "hash_probe" : "hash_only", g, T, k, filter, nullptr, d_keys, d_tiles, n_tile_ids, d_spans))) return rc;
+  }
+  const char* win_tag = fuse ? (filter ? "hash_probe" : "hash_only") : "window_min"; // (the fused pass is timed as the hashing pass it replaces)
   OutSegs segs;
   segs.d_count = d_seg;
   segs.seg_cap = std::max<uint64_t>(256, (3 * est_kmers / w + 2 * n_tiles) / N_SEG + 64);
@@ -3475,7 +2899,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     DN_WS(d_gk, uint64_t*, "gap_sorted_key", GAP_LIST_CAP * 8);
     DN_WS(d_gctl, uint64_t*, "gap_ctl", 4 * 8);
     if (!tl.d_j || !tl.d_key || !tl.d_tile_cnt) return NTS_ENOMEM;
-    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, tl, "window_min", d_tiles, n_tile_ids))) return rc;
+    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, tl, win_tag, d_tiles, n_tile_ids, fuse))) return rc;
     {
       ScopedTimer t(ctx, "merge_lists");
       hipLaunchKernelGGL(k_gap_collect, dim3(1), dim3(GAP_COLLECT_THREADS), 0, ctx->stream, tl.d_tile_cnt, (uint32_t)n_tiles, tl.d_j, tl.d_key,
@@ -3500,7 +2924,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     if (!segs.d_j || !segs.d_key) return NTS_ENOMEM;
     HIP_TRY(ctx, hipMemsetAsync(segs.d_j, 0xFF, slots * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
-    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, segs, "window_min", d_tiles, n_tile_ids))) return rc;
+    if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, segs, win_tag, d_tiles, n_tile_ids, fuse))) return rc;
     {
       Mail m(ctx);
       const uint32_t at = m.add(d_seg, N_SEG);
@@ -3560,32 +2984,8 @@ int ensure_pack(nts_ctx* ctx, const nts_genome* g)
   return NTS_OK;
 }
 
-// exclusive scan of per-tile / per-workgroup counts: one single-workgroup kernel while the list is short (one launch,
-// ~4 us), the library's two-kernel scan beyond (a single workgroup would take ~0.1 ms over 2*10^5 counts)
-constexpr uint64_t SCAN1_MAX = 8192;
 constexpr uint32_t SUMMARY_LOG2_BITS = 25; // a sparse filter's summary: at most 2^25 bits = 4 MiB (config 4 on one GPU, 2^23 .. 2^26: 324 / 338 / 349 / 331 Gbases/s; NTS_SUMMARY_LOG2_BITS overrides)
 
-template <typename T>
-struct WidenU64
-{
-  __host__ __device__ uint64_t operator()(T x) const { return (uint64_t)x; }
-};
-
-template <typename T>
-int scan_counts(nts_ctx* ctx, const T* d_in, uint64_t n, uint64_t* d_out)
-{
-  if (n <= SCAN1_MAX) {
-    hipLaunchKernelGGL(k_scan_excl<T>, dim3(1), dim3(SCAN1_THREADS), 0, ctx->stream, d_in, n, d_out);
-    return NTS_OK;
-  }
-  auto src = rocprim::make_transform_iterator(d_in, WidenU64<T>()); // (32-bit counts are widened on the way in)
-  size_t bytes = 0;
-  HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, bytes, src, d_out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
-  void* tmp = ws_get(ctx, "sel_scan_tmp", std::max<size_t>(bytes, 16));
-  if (!tmp) return NTS_ENOMEM;
-  HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, src, d_out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
-  return NTS_OK;
-}
 
 // Summary of a sparse filter (one bit per 2^shift filter bits) and its two folded tables, kept with the filter until its contents
 // change (k_bf_summary: one streaming pass).  The caller holds filter->mu.
@@ -3678,7 +3078,8 @@ int bf_level_sparse(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, const Genome
   uint32_t shift = 7;
   const uint32_t sum_log2 = NTS_KNOB("NTS_SUMMARY_LOG2_BITS") ? (uint32_t)std::max(16, std::min(28, atoi(NTS_KNOB("NTS_SUMMARY_LOG2_BITS")))) : SUMMARY_LOG2_BITS;
   while ((bits / (double)(1ull << shift)) > (double)(1ull << sum_log2) && shift < 30) ++shift; // (the sketch's choice: nts_sketch_ex)
-  // the sketch's own criterion for "sparse" (a summary bit set with probability < 0.3) -- and the level must beat the build, which
+  // an occupancy of the summary below 0.3 -- stricter than the sketch's own criterion for taking the summary path (nts_sketch_ex: 0.7
+  // next to the tiered selection, 3.0 where only the every-k-mer pass is the alternative) -- and the level must beat the build, which
   // with a sparse running filter (k_bin3 skips the residues of empty slices) takes 20-21 ms per 3 Gbp.  Measured level by level on BASELINE configs[3] (scripts/c4_levels.py, profiles/r04_c4_levels.json): through the summary
   // alone the literal level takes 60 / 31 / 22 / 20.3 ms at 27.8 M / 9.0 M / 3.0 M / 1.05 M set bits (17.3 with the tables already in
   // place) -- never ahead; only with the two folded tables in LDS in front of the summary (k_hash_accept4*: 8 ms per genome, up to
@@ -3854,7 +3255,13 @@ int run_gap_tiers(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint
   GT_WS(d_ctl, unsigned long long*, "gt_ctl", (N_SEG + 4) * 8); // [0..63] segment counters, [64] ranges (unused), [65] overflow, [66..67] tier statistics
   // the accepted k-mers of the ranges: a few per window at most where the filter accepts anything at all (the ranges are what the
   // other genomes do not share); a list that does not fit raises the flag and the call is repeated the dense way
-  const uint64_t seg_cap = (uint64_t)((double)covered * 0.05 / N_SEG) + 2048;
+  // Room per output segment: 5 % of the ranges' k-mers dealt out over the segments -- and never less than what the tiles of one
+  // segment can list when every one of them is as rich as a conserved stretch (tiles go to segments round robin; a tile of TR_CORE
+  // k-mers over sequence the other genomes DO share lists up to an eighth of its k-mers): a few long ranges over conserved sequence
+  // used to overflow a segment sized from the average, and the whole sketch then ran again the dense way.
+  const uint64_t tiles_per_seg = (n_gt + N_SEG - 1) / N_SEG;
+  const uint64_t rich = std::min<uint64_t>(tiles_per_seg, 8) * (uint64_t)(core / 8 + 64);
+  const uint64_t seg_cap = std::max<uint64_t>((uint64_t)((double)covered * 0.05 / N_SEG) + 2048, rich);
   const uint64_t m_max = seg_cap * N_SEG, n_blk = (m_max + SPARSE_BLOCK - 1) / SPARSE_BLOCK;
   GT_WS(d_sj, uint64_t*, "gt_seg_j", m_max * 8);
   GT_WS(d_sk, uint64_t*, "gt_seg_key", m_max * 8);
@@ -4324,27 +3731,6 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
 #undef PR_WS
 }
 
-// device memory of a result list: recycled through a small per-context pool (hipMalloc/hipFree synchronise)
-int alloc_result(nts_ctx* ctx, nts_mx* mx, uint64_t count)
-{
-  const uint64_t need = count * 20;
-  for (size_t i = 0; i < ctx->mx_pool.size(); ++i) {
-    if (ctx->mx_pool[i].second >= need && ctx->mx_pool[i].second <= 4 * need + (1u << 20)) {
-      mx->d_h1 = (uint64_t*)ctx->mx_pool[i].first;
-      mx->cap_bytes = ctx->mx_pool[i].second;
-      ctx->mx_pool.erase(ctx->mx_pool.begin() + i);
-      break;
-    }
-  }
-  if (!mx->d_h1) {
-    const uint64_t cap = need + need / 8 + 4096;
-    HIP_TRY(ctx, dev_malloc((void**)&mx->d_h1, cap));
-    mx->cap_bytes = cap;
-  }
-  mx->d_pos = mx->d_h1 + count;
-  mx->d_rec = (uint32_t*)(mx->d_pos + count);
-  return NTS_OK;
-}
 
 } // namespace
 
@@ -4762,442 +4148,3 @@ void nts_free(void* p)
 }
 
 } // extern "C"
-
-#include "nts_comm.inc"
-#include "nts_fasta_dev.inc"
-
-// ---- minimizer graph build (rows C1, C2a, C2b) --------------------------------------------------------
-namespace {
-
-// after a stable sort by hash, duplicates of one assembly are adjacent (global element index is
-// assembly-major): mark elements whose hash is unique within their assembly and kept by the caller
-__global__ __launch_bounds__(256) void k_g_valid(const uint64_t* __restrict__ h_sorted, const uint64_t* __restrict__ idx_sorted,
-                                                 const uint32_t* __restrict__ asm_of, const uint8_t* __restrict__ keep, uint64_t n,
-                                                 uint8_t* __restrict__ valid)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t h = h_sorted[i];
-  const uint64_t e = idx_sorted[i];
-  const uint32_t a = asm_of[e];
-  bool dup = false;
-  if (i > 0 && h_sorted[i - 1] == h && asm_of[idx_sorted[i - 1]] == a) dup = true;
-  if (i + 1 < n && h_sorted[i + 1] == h && asm_of[idx_sorted[i + 1]] == a) dup = true;
-  valid[i] = (!dup && keep[e]) ? 1 : 0;
-}
-
-// group heads (first element of each run of equal hashes): the hash is common iff exactly n_asm
-// valid elements carry it (each assembly contributes at most one)
-__global__ __launch_bounds__(256) void k_g_common(const uint64_t* __restrict__ h_sorted, const uint8_t* __restrict__ valid, uint64_t n,
-                                                  uint32_t n_asm, uint64_t* __restrict__ head_common)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint64_t flag = 0;
-  const uint64_t h = h_sorted[i];
-  if (i == 0 || h_sorted[i - 1] != h) {
-    uint32_t cnt = 0;
-    for (uint64_t j = i; j < n && h_sorted[j] == h; ++j) cnt += valid[j];
-    flag = (cnt == n_asm) ? 1 : 0;
-  }
-  head_common[i] = flag;
-}
-
-// vid_scan = exclusive scan of head_common: every valid element of a common group gets the group's id
-__global__ __launch_bounds__(256) void k_g_assign(const uint64_t* __restrict__ h_sorted, const uint64_t* __restrict__ idx_sorted,
-                                                  const uint8_t* __restrict__ valid, const uint64_t* __restrict__ head_common,
-                                                  const uint64_t* __restrict__ vid_scan, uint64_t n, const uint32_t* __restrict__ asm_of,
-                                                  const uint32_t* __restrict__ rec, const uint64_t* __restrict__ pos, uint64_t nv,
-                                                  uint32_t* __restrict__ elem_vid, uint64_t* __restrict__ v_hash,
-                                                  uint32_t* __restrict__ occ_rec, uint64_t* __restrict__ occ_pos)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t h = h_sorted[i];
-  if (!(i == 0 || h_sorted[i - 1] != h) || !head_common[i]) return;
-  const uint64_t vid = vid_scan[i];
-  v_hash[vid] = h;
-  for (uint64_t j = i; j < n && h_sorted[j] == h; ++j) {
-    if (!valid[j]) continue;
-    const uint64_t e = idx_sorted[j];
-    elem_vid[e] = (uint32_t)vid;
-    const uint32_t a = asm_of[e];
-    occ_rec[(uint64_t)a * nv + vid] = rec[e];
-    occ_pos[(uint64_t)a * nv + vid] = pos[e];
-  }
-}
-
-__global__ __launch_bounds__(256) void k_g_flag_kept(const uint32_t* __restrict__ elem_vid, uint64_t n, uint64_t* __restrict__ flag)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = elem_vid[i] != 0xFFFFFFFFu ? 1 : 0;
-}
-
-// compact the survivors in traversal order: c_vid / c_asm / c_list
-__global__ __launch_bounds__(256) void k_g_compact(const uint32_t* __restrict__ elem_vid, const uint64_t* __restrict__ where, uint64_t n,
-                                                   const uint32_t* __restrict__ asm_of, const uint32_t* __restrict__ list_id,
-                                                   uint32_t* __restrict__ c_vid, uint32_t* __restrict__ c_asm, uint32_t* __restrict__ c_list)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || elem_vid[i] == 0xFFFFFFFFu) return;
-  const uint64_t c = where[i];
-  c_vid[c] = elem_vid[i];
-  c_asm[c] = asm_of[i];
-  c_list[c] = list_id[i];
-}
-
-// adjacent survivors of one list -> edge occurrence (canonical key, sequence number); others get key ~0
-__global__ __launch_bounds__(256) void k_g_pairs(const uint32_t* __restrict__ c_vid, const uint32_t* __restrict__ c_asm,
-                                                 const uint32_t* __restrict__ c_list, uint64_t m, uint64_t* __restrict__ key,
-                                                 uint64_t* __restrict__ seq)
-{
-  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= m) return;
-  uint64_t kk = ~0ULL;
-  if (c + 1 < m && c_asm[c] == c_asm[c + 1] && c_list[c] == c_list[c + 1]) {
-    const uint64_t u = c_vid[c], v = c_vid[c + 1];
-    kk = u < v ? ((u << 32) | v) : ((v << 32) | u);
-  }
-  key[c] = kk;
-  seq[c] = c;
-}
-
-__global__ __launch_bounds__(256) void k_g_edge_heads(const uint64_t* __restrict__ key_sorted, uint64_t m, uint64_t* __restrict__ head)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  const uint64_t kk = key_sorted[i];
-  head[i] = (kk != ~0ULL && (i == 0 || key_sorted[i - 1] != kk)) ? 1 : 0;
-}
-
-__global__ __launch_bounds__(256) void k_g_edges(const uint64_t* __restrict__ key_sorted, const uint64_t* __restrict__ seq_sorted,
-                                                 const uint64_t* __restrict__ head, const uint64_t* __restrict__ head_scan, uint64_t m,
-                                                 const uint32_t* __restrict__ c_vid, uint32_t* __restrict__ e_u, uint32_t* __restrict__ e_v,
-                                                 uint32_t* __restrict__ e_w, uint64_t* __restrict__ e_first)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m || !head[i]) return;
-  const uint64_t kk = key_sorted[i];
-  uint32_t cnt = 0;
-  for (uint64_t j = i; j < m && key_sorted[j] == kk; ++j) ++cnt;
-  const uint64_t e = head_scan[i];
-  const uint64_t s = seq_sorted[i]; // stable sort: the first sighting leads its group
-  e_u[e] = c_vid[s];
-  e_v[e] = c_vid[s + 1];
-  e_w[e] = cnt;
-  e_first[e] = s;
-}
-
-// ---- edge order of the reference: `[(s, t) for s in edges for t in edges[s]]` over ntJoin's dict of dicts ----
-// sources by the time they first became a source, then by creation time; both are sequence numbers < 2^32
-__global__ __launch_bounds__(256) void k_g_src_rank(const uint32_t* __restrict__ e_u, const uint64_t* __restrict__ e_first, uint64_t ne,
-                                                    unsigned long long* __restrict__ src_rank)
-{
-  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < ne) atomicMin(&src_rank[e_u[e]], (unsigned long long)e_first[e]);
-}
-
-__global__ __launch_bounds__(256) void k_g_order_keys(const uint32_t* __restrict__ e_u, const uint64_t* __restrict__ e_first, uint64_t ne,
-                                                      const unsigned long long* __restrict__ src_rank, uint64_t* __restrict__ key,
-                                                      uint64_t* __restrict__ idx)
-{
-  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= ne) return;
-  key[e] = ((uint64_t)src_rank[e_u[e]] << 32) | e_first[e];
-  idx[e] = e;
-}
-
-// element numbers base .. base+m-1 and the assembly id of one list of the concatenation
-__global__ __launch_bounds__(256) void k_g_number(uint64_t* __restrict__ idx, uint32_t* __restrict__ asm_id, uint64_t m, uint64_t base, uint32_t a)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  idx[i] = base + i;
-  asm_id[i] = a;
-}
-
-__global__ __launch_bounds__(256) void k_g_permute_edges(const uint64_t* __restrict__ idx_sorted, uint64_t ne, const uint32_t* __restrict__ e_u,
-                                                         const uint32_t* __restrict__ e_v, const uint32_t* __restrict__ e_w,
-                                                         const uint64_t* __restrict__ e_first, uint32_t* __restrict__ o_u,
-                                                         uint32_t* __restrict__ o_v, uint32_t* __restrict__ o_w, uint64_t* __restrict__ o_first)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ne) return;
-  const uint64_t e = idx_sorted[i];
-  o_u[i] = e_u[e];
-  o_v[i] = e_v[e];
-  o_w[i] = e_w[e];
-  o_first[i] = e_first[e];
-}
-
-template <typename T>
-T* host_copy(nts_ctx* ctx, const T* d, uint64_t n)
-{
-  T* h = (T*)malloc(std::max<uint64_t>(n, 1) * sizeof(T));
-  if (h && n) hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream);
-  return h;
-}
-
-} // namespace
-
-namespace {
-
-// Device-side result of one build, in the context's scratch (valid until the next build on this context)
-struct GraphDev
-{
-  uint64_t n = 0;   // elements given
-  uint64_t nv = 0, ne = 0;
-  uint64_t* v_hash = nullptr; // [nv] ascending
-  uint32_t* occ_rec = nullptr; // [n_asm * nv]
-  uint64_t* occ_pos = nullptr;
-  uint32_t *e_u = nullptr, *e_v = nullptr, *e_w = nullptr; // [ne] dict order
-  uint64_t* e_first = nullptr;
-};
-
-// Hook between duplicate removal and the cross-assembly intersection: given valid[e] per element (in element order),
-// a caller may rewrite the list ids (refinement rounds cut lists between consecutive *kept* minimizers, row C11).
-struct ListHook
-{
-  virtual int operator()(nts_ctx* ctx, uint64_t n, const uint8_t* d_valid_elem, const uint32_t* d_asm, const uint32_t* d_rec, const uint64_t* d_pos,
-                         uint32_t* d_list) = 0;
-  virtual ~ListHook() {}
-};
-
-__global__ __launch_bounds__(256) void k_g_valid_scatter(const uint64_t* __restrict__ idx_sorted, const uint8_t* __restrict__ valid, uint64_t n,
-                                                         uint8_t* __restrict__ valid_elem)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) valid_elem[idx_sorted[i]] = valid[i];
-}
-
-// The build proper.  Expects the concatenated elements (assembly-major) already in the scratch buffers g_h / g_rec / g_pos /
-// g_keep / g_list / g_asm / g_idx (filled by the callers below); leaves the graph in scratch and describes it in `G`.
-int graph_build_core(nts_ctx* ctx, uint32_t n_asm, uint64_t n, GraphDev* G, ListHook* hook)
-{
-  *G = GraphDev();
-  G->n = n;
-  if (n == 0) return NTS_OK;
-#define G_WS(ptr, type, name, bytes)                                                                \
-  type ptr = (type)ws_get(ctx, name, bytes);                                                        \
-  if (!ptr) return NTS_ENOMEM
-  G_WS(d_h, uint64_t*, "g_h", n * 8);
-  G_WS(d_idx, uint64_t*, "g_idx", n * 8);
-  G_WS(d_h2, uint64_t*, "g_h2", n * 8);
-  G_WS(d_idx2, uint64_t*, "g_idx2", n * 8);
-  G_WS(d_asm, uint32_t*, "g_asm", n * 4);
-  G_WS(d_rec, uint32_t*, "g_rec", n * 4);
-  G_WS(d_pos, uint64_t*, "g_pos", n * 8);
-  G_WS(d_keep, uint8_t*, "g_keep", n);
-  G_WS(d_list, uint32_t*, "g_list", n * 4);
-  G_WS(d_valid, uint8_t*, "g_valid", n);
-  G_WS(d_flag, uint64_t*, "g_flag", n * 8);
-  G_WS(d_scan, uint64_t*, "g_scan", (n + 1) * 8);
-  G_WS(d_evid, uint32_t*, "g_evid", n * 4);
-  const uint32_t nb = (uint32_t)((n + 255) / 256);
-  size_t tmp_sort = 0, tmp_scan = 0;
-  HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort, d_h, d_h2, d_idx, d_idx2, n, 0, 64, ctx->stream));
-  HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, tmp_scan, d_flag, d_scan, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
-  G_WS(d_tmp, void*, "g_tmp", std::max<size_t>(std::max(tmp_sort, tmp_scan), 16));
-  {
-    ScopedTimer t(ctx, "graph_build");
-    // C1 + keep mask
-    HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp, tmp_sort, d_h, d_h2, d_idx, d_idx2, n, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(k_g_valid, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_idx2, d_asm, d_keep, n, d_valid);
-  }
-  if (hook) {
-    G_WS(d_valid_elem, uint8_t*, "g_valid_elem", n);
-    hipLaunchKernelGGL(k_g_valid_scatter, dim3(nb), dim3(256), 0, ctx->stream, d_idx2, d_valid, n, d_valid_elem);
-    if (int rc = (*hook)(ctx, n, d_valid_elem, d_asm, d_rec, d_pos, d_list)) return rc;
-  }
-  {
-    ScopedTimer t(ctx, "graph_build");
-    // C2a
-    hipLaunchKernelGGL(k_g_common, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_valid, n, n_asm, d_flag);
-    HIP_TRY(ctx, rocprim::exclusive_scan(d_tmp, tmp_scan, d_flag, d_scan, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
-  }
-  uint64_t last_flag = 0, last_scan = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&last_flag, d_flag + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(&last_scan, d_scan + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const uint64_t nv = last_scan + last_flag;
-  G->nv = nv;
-  if (nv == 0) return NTS_OK;
-  G_WS(d_vhash, uint64_t*, "g_vhash", nv * 8);
-  G_WS(d_orec, uint32_t*, "g_orec", (uint64_t)n_asm * nv * 4);
-  G_WS(d_opos, uint64_t*, "g_opos", (uint64_t)n_asm * nv * 8);
-  HIP_TRY(ctx, hipMemsetAsync(d_evid, 0xFF, n * 4, ctx->stream));
-  {
-    ScopedTimer t(ctx, "graph_build");
-    hipLaunchKernelGGL(k_g_assign, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_idx2, d_valid, d_flag, d_scan, n, d_asm, d_rec, d_pos, nv,
-                       d_evid, d_vhash, d_orec, d_opos);
-    // survivors in traversal order
-    hipLaunchKernelGGL(k_g_flag_kept, dim3(nb), dim3(256), 0, ctx->stream, d_evid, n, d_flag);
-    HIP_TRY(ctx, rocprim::exclusive_scan(d_tmp, tmp_scan, d_flag, d_scan, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
-  }
-  const uint64_t m = (uint64_t)n_asm * nv; // every common hash occurs once per assembly
-  G_WS(d_cvid, uint32_t*, "g_cvid", (m + 1) * 4);
-  G_WS(d_casm, uint32_t*, "g_casm", m * 4);
-  G_WS(d_clist, uint32_t*, "g_clist", m * 4);
-  G_WS(d_key, uint64_t*, "g_key", m * 8);
-  G_WS(d_seq, uint64_t*, "g_seq", m * 8);
-  G_WS(d_key2, uint64_t*, "g_key2", m * 8);
-  G_WS(d_seq2, uint64_t*, "g_seq2", m * 8);
-  G_WS(d_eh, uint64_t*, "g_eh", m * 8);
-  G_WS(d_es, uint64_t*, "g_es", (m + 1) * 8);
-  size_t tmp_sort2 = 0, tmp_scan2 = 0;
-  HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort2, d_key, d_key2, d_seq, d_seq2, m, 0, 64, ctx->stream));
-  HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, tmp_scan2, d_eh, d_es, (uint64_t)0, m, rocprim::plus<uint64_t>(), ctx->stream));
-  G_WS(d_tmp2, void*, "g_tmp2", std::max<size_t>(std::max(tmp_sort2, tmp_scan2), 16));
-  const uint32_t mb = (uint32_t)((m + 255) / 256);
-  {
-    ScopedTimer t(ctx, "graph_build");
-    hipLaunchKernelGGL(k_g_compact, dim3(nb), dim3(256), 0, ctx->stream, d_evid, d_scan, n, d_asm, d_list, d_cvid, d_casm, d_clist);
-    hipLaunchKernelGGL(k_g_pairs, dim3(mb), dim3(256), 0, ctx->stream, d_cvid, d_casm, d_clist, m, d_key, d_seq);
-    HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp2, tmp_sort2, d_key, d_key2, d_seq, d_seq2, m, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(k_g_edge_heads, dim3(mb), dim3(256), 0, ctx->stream, d_key2, m, d_eh);
-    HIP_TRY(ctx, rocprim::exclusive_scan(d_tmp2, tmp_scan2, d_eh, d_es, (uint64_t)0, m, rocprim::plus<uint64_t>(), ctx->stream));
-  }
-  HIP_TRY(ctx, hipMemcpyAsync(&last_flag, d_eh + (m - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(&last_scan, d_es + (m - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const uint64_t ne = last_scan + last_flag;
-  G->ne = ne;
-  G_WS(d_eu, uint32_t*, "g_eu", std::max<uint64_t>(ne, 1) * 4);
-  G_WS(d_ev, uint32_t*, "g_ev", std::max<uint64_t>(ne, 1) * 4);
-  G_WS(d_ew, uint32_t*, "g_ew", std::max<uint64_t>(ne, 1) * 4);
-  G_WS(d_ef, uint64_t*, "g_ef", std::max<uint64_t>(ne, 1) * 8);
-  if (ne) {
-    // the unordered edge arrays reuse buffers the pair stage is done with; d_key/d_seq become sort keys again
-    G_WS(d_eu0, uint32_t*, "g_eu0", ne * 4);
-    G_WS(d_ev0, uint32_t*, "g_ev0", ne * 4);
-    G_WS(d_ew0, uint32_t*, "g_ew0", ne * 4);
-    G_WS(d_ef0, uint64_t*, "g_ef0", ne * 8);
-    G_WS(d_srank, unsigned long long*, "g_srank", nv * 8);
-    size_t tmp_sort3 = 0;
-    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort3, d_key, d_key2, d_seq, d_seq2, ne, 0, 64, ctx->stream));
-    G_WS(d_tmp3, void*, "g_tmp3", std::max<size_t>(tmp_sort3, 16));
-    const uint32_t eb = (uint32_t)((ne + 255) / 256);
-    ScopedTimer t(ctx, "graph_build");
-    hipLaunchKernelGGL(k_g_edges, dim3(mb), dim3(256), 0, ctx->stream, d_key2, d_seq2, d_eh, d_es, m, d_cvid, d_eu0, d_ev0, d_ew0, d_ef0);
-    HIP_TRY(ctx, hipMemsetAsync(d_srank, 0xFF, nv * 8, ctx->stream));
-    hipLaunchKernelGGL(k_g_src_rank, dim3(eb), dim3(256), 0, ctx->stream, d_eu0, d_ef0, ne, d_srank);
-    hipLaunchKernelGGL(k_g_order_keys, dim3(eb), dim3(256), 0, ctx->stream, d_eu0, d_ef0, ne, d_srank, d_key, d_seq);
-    HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp3, tmp_sort3, d_key, d_key2, d_seq, d_seq2, ne, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(k_g_permute_edges, dim3(eb), dim3(256), 0, ctx->stream, d_seq2, ne, d_eu0, d_ev0, d_ew0, d_ef0, d_eu, d_ev, d_ew, d_ef);
-  }
-  HIP_TRY(ctx, hipGetLastError());
-  G->v_hash = d_vhash;
-  G->occ_rec = d_orec;
-  G->occ_pos = d_opos;
-  G->e_u = d_eu;
-  G->e_v = d_ev;
-  G->e_w = d_ew;
-  G->e_first = d_ef;
-  return NTS_OK;
-#undef G_WS
-}
-
-// scratch buffers of the concatenation, sized for n elements
-struct GraphIn
-{
-  uint64_t* h = nullptr;
-  uint64_t* idx = nullptr;
-  uint32_t* asm_id = nullptr;
-  uint32_t* rec = nullptr;
-  uint64_t* pos = nullptr;
-  uint8_t* keep = nullptr;
-  uint32_t* list = nullptr;
-};
-
-int graph_inputs(nts_ctx* ctx, uint64_t n, GraphIn* in)
-{
-  const uint64_t c = std::max<uint64_t>(n, 1);
-  in->h = (uint64_t*)ws_get(ctx, "g_h", c * 8);
-  in->idx = (uint64_t*)ws_get(ctx, "g_idx", c * 8);
-  in->asm_id = (uint32_t*)ws_get(ctx, "g_asm", c * 4);
-  in->rec = (uint32_t*)ws_get(ctx, "g_rec", c * 4);
-  in->pos = (uint64_t*)ws_get(ctx, "g_pos", c * 8);
-  in->keep = (uint8_t*)ws_get(ctx, "g_keep", c);
-  in->list = (uint32_t*)ws_get(ctx, "g_list", c * 4);
-  return (in->h && in->idx && in->asm_id && in->rec && in->pos && in->keep && in->list) ? NTS_OK : NTS_ENOMEM;
-}
-
-} // namespace
-
-extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* lists, nts_graph* out)
-{
-  if (!ctx || !out || n_asm == 0 || !lists) return fail(ctx, NTS_EINVAL, "nts_graph_build: bad arguments");
-  memset(out, 0, sizeof(*out));
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  uint64_t n = 0;
-  for (uint32_t a = 0; a < n_asm; ++a) {
-    if (lists[a].n && (!lists[a].h1 || !lists[a].rec || !lists[a].pos)) return fail(ctx, NTS_EINVAL, "nts_graph_build: NULL list arrays");
-    n += lists[a].n;
-  }
-  if (n >= 0xFFFFFFFFULL) return fail(ctx, NTS_ERANGE, "nts_graph_build: more than 2^32 minimizers");
-  auto finish_empty = [&]() {
-    out->v_hash = (uint64_t*)malloc(8);
-    out->occ_rec = (uint32_t*)malloc(8);
-    out->occ_pos = (uint64_t*)malloc(8);
-    out->e_u = (uint32_t*)malloc(8);
-    out->e_v = (uint32_t*)malloc(8);
-    out->e_w = (uint32_t*)malloc(8);
-    out->e_first = (uint64_t*)malloc(8);
-    return NTS_OK;
-  };
-  if (n == 0) return finish_empty();
-  GraphIn in;
-  if (graph_inputs(ctx, n, &in) != NTS_OK) return NTS_ENOMEM;
-  // assembly-major concatenation; element numbers and assembly ids are generated on the device (each assembly's range is
-  // one launch), the keep mask is uploaded only where a list brings one
-  uint64_t o = 0;
-  for (uint32_t a = 0; a < n_asm; ++a) {
-    const uint64_t m = lists[a].n;
-    if (m) {
-      HIP_TRY(ctx, hipMemcpyAsync(in.h + o, lists[a].h1, m * 8, hipMemcpyHostToDevice, ctx->stream));
-      HIP_TRY(ctx, hipMemcpyAsync(in.rec + o, lists[a].rec, m * 4, hipMemcpyHostToDevice, ctx->stream));
-      HIP_TRY(ctx, hipMemcpyAsync(in.pos + o, lists[a].pos, m * 8, hipMemcpyHostToDevice, ctx->stream));
-      HIP_TRY(ctx, hipMemcpyAsync(in.list + o, lists[a].list_id ? lists[a].list_id : lists[a].rec, m * 4, hipMemcpyHostToDevice, ctx->stream));
-      if (lists[a].keep)
-        HIP_TRY(ctx, hipMemcpyAsync(in.keep + o, lists[a].keep, m, hipMemcpyHostToDevice, ctx->stream));
-      else
-        HIP_TRY(ctx, hipMemsetAsync(in.keep + o, 1, m, ctx->stream));
-      hipLaunchKernelGGL(k_g_number, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, ctx->stream, in.idx + o, in.asm_id + o, m, o, a);
-    }
-    o += m;
-  }
-  GraphDev G;
-  if (int rc = graph_build_core(ctx, n_asm, n, &G, nullptr)) return rc;
-  const uint64_t nv = G.nv, ne = G.ne;
-  out->nv = nv;
-  out->ne = ne;
-  if (nv == 0) return finish_empty();
-  out->v_hash = host_copy(ctx, G.v_hash, nv);
-  out->occ_rec = host_copy(ctx, G.occ_rec, (uint64_t)n_asm * nv);
-  out->occ_pos = host_copy(ctx, G.occ_pos, (uint64_t)n_asm * nv);
-  out->e_u = host_copy(ctx, G.e_u, ne);
-  out->e_v = host_copy(ctx, G.e_v, ne);
-  out->e_w = host_copy(ctx, G.e_w, ne);
-  out->e_first = host_copy(ctx, G.e_first, ne);
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (!out->v_hash || !out->occ_rec || !out->occ_pos || !out->e_u || !out->e_v || !out->e_w || !out->e_first) {
-    nts_graph_free(out);
-    return fail(ctx, NTS_ENOMEM, "nts_graph_build: host allocation failed");
-  }
-  return NTS_OK;
-}
-
-#include "nts_dgraph.inc"
-
-extern "C" void nts_graph_free(nts_graph* g)
-{
-  if (!g) return;
-  free(g->v_hash);
-  free(g->occ_rec);
-  free(g->occ_pos);
-  free(g->e_u);
-  free(g->e_v);
-  free(g->e_w);
-  free(g->e_first);
-  memset(g, 0, sizeof(*g));
-}

@@ -558,13 +558,21 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
             raise ValueError(f"window size {ww} outside 1..{MAX_W} (limit of the window kernels)")
     st.start("read_fasta+upload")
 
+    refused = []                                                # (several ranks: said by every rank after the first exchange, so that none waits for one that left)
+
+    def refuse(msg):
+        if world > 1:
+            refused.append(msg)
+        else:
+            raise ValueError(msg)
+
     def arrived(p, g):
         if len(g.names) == 0 or g.total_bp == 0:
-            raise ValueError(f"{p}: no sequence records")
+            return refuse(f"{p}: no sequence records")
         rl = getattr(g, "rec_len", None)
         if len(g.names) >= MAX_RECORDS or (rl is not None and len(rl) and int(np.max(rl)) >= MAX_RECORD_BP):
-            raise ValueError(f"{p}: more than 2^22 records or a record of 2^40 bases or more "
-                             "(limits of the refinement rounds' composite interval keys)")
+            return refuse(f"{p}: more than 2^22 records or a record of 2^40 bases or more "
+                          "(limits of the refinement rounds' composite interval keys)")
         if write_fai and not shard_mode:                                    # (shard mode: the first rank that holds records of a genome writes for it, below)
             fa.write_fai(f"{fa.basename(p)}.fai", g.recs)
 
@@ -602,7 +610,12 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         meta = {p: (genomes[p].names, genomes[p].total_bp) for p in mine} if not overlap_load else None
     if world > 1:
         gathered = [None] * world
-        dist.all_gather_object(gathered, {p: v + (np.asarray(genomes[p].rec_len, dtype=np.uint64),) for p, v in meta.items()} if shard_mode else meta)
+        mine_meta = {p: v + (np.asarray(genomes[p].rec_len, dtype=np.uint64),) for p, v in meta.items()} if shard_mode else dict(meta)
+        mine_meta["\0refused"] = list(refused)
+        dist.all_gather_object(gathered, mine_meta)
+        all_refused = sorted({msg for part in gathered for msg in part.pop("\0refused")})
+        if all_refused:                                         # an input no rank can work with: every rank says so and stops (a genome
+            raise ValueError("; ".join(all_refused))            # without records would otherwise be missing from the plan: ADVICE r5)
         meta = {p: v for part in gathered for p, v in part.items()}
     shard = None
     if shard_mode:

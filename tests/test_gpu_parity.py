@@ -768,3 +768,55 @@ def test_sketch_pool_equals_one_after_the_other(ctx):
             d.free()
         dbf.free()
         sbf.free()
+
+
+@pytest.mark.parametrize("k,w", [(24, 10), (24, 33), (24, 63), (20, 2), (40, 50), (130, 20)])
+def test_short_windows_fused_kernel_equals_the_key_array_path_and_the_oracle(ctx, ctx_x, monkeypatch, k, w):
+    """w < 64: the window tiles hash and probe their own k-mers (k_window_min<true>, no key array) -- against the two-kernel path
+    (k_hash<MODE_KEYS> + k_window_min<false>; NTS_WIN_FUSE=0 in the experiments build) and the oracle, with and without a filter, on
+    records with N runs inside tiles (the tile then walks the run table), records shorter than a window, records that end a few
+    k-mers into a tile, and k > 128 (the generic walk for every tile)"""
+    from ntsynt_amd.device import BloomFilter, sketch
+    names, seqs = _family(7000 + 13 * w + k, lengths=[70000, 4096 + w + k - 2, k + w - 2, k + w - 1, 0, 9000, 30000], n_frac=0.004)
+    rng = np.random.default_rng(w)
+    other = []
+    for s_ in seqs:
+        a = np.frombuffer(s_, dtype=np.uint8).copy()
+        hit = rng.random(a.size) < 0.03
+        a[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+        other.append(a.tobytes())
+    og = [to_oracle(names, seqs), to_oracle(names, other)]
+    nbytes = O.bf_ctor_bytes(O.bf_approx_bytes(og[0].total_bp, 0.05))
+    obf = O.bf_build(og[1], k, nbytes, prev=O.bf_build(og[0], k, nbytes))
+    for use_filter in (False, True):
+        exp = oracle_flat(O.minimize(og[0], k, w, obf if use_filter else None))
+        got = {}
+        for label, c in (("fused", ctx), ("key array", ctx_x)):
+            if label == "key array":
+                monkeypatch.setenv("NTS_WIN_FUSE", "0")
+            dg = to_device(c, names, seqs)
+            bf = None
+            if use_filter:
+                bf = BloomFilter(c, nbytes, k)
+                bf.from_numpy(obf)
+            c.sketch_mode("dense")                     # (the every-k-mer path: where short windows go at full size, and where the fusion applies)
+            c.profile(1)
+            mx = sketch(c, dg, k, w, bf)
+            got[label] = mx.to_numpy()
+            c.sync()
+            hashed, windows = c.timing("hash_probe" if use_filter else "hash_only")[1], c.timing("window_min")[1]
+            # the fused pass is timed as the hashing pass and launches no window kernel of its own; the key-array path launches both
+            # (a second launch of either: the output segments were sized too small for so short an input, and the pass ran again);
+            # k > 128 is not fused (no LDS staging of the bases: k_hash's generic walk + the window kernel)
+            fused_here = label == "fused" and k <= 128
+            assert hashed >= 1 and (windows == 0 if fused_here else windows >= 1), (label, hashed, windows)
+            c.profile(0)
+            c.sketch_mode("auto")
+            mx.free()
+            if bf is not None:
+                bf.free()
+            dg.free()
+            monkeypatch.delenv("NTS_WIN_FUSE", raising=False)
+        assert got["fused"][0].size > 100
+        for a, b, e in zip(got["fused"], got["key array"], exp):
+            assert np.array_equal(a, b) and np.array_equal(a, e.astype(a.dtype)), (k, w, use_filter)

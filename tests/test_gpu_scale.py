@@ -122,11 +122,15 @@ def test_records_longer_than_2_to_32(ctx):
     common.free()
 
 
-@pytest.mark.parametrize("record,family,div,n_fam", [("r04_e2e_oracle_c3.json", "structural", 0.01, 3), ("r04_e2e_oracle_c5_like.json", "assembly-like", 0.013, 3),
-                                                     ("r04_e2e_oracle_2x3Gbp_d0.1.json", "structural", 0.001, 2), ("r04_e2e_oracle_c4.json", "structural", 0.10, 8),
-                                                     # (round 5) three genomes at 10 %: a filter that accepts 2.4 % of the k-mers, the tiered selection's regime
-                                                     ("r05_e2e_oracle_valley_3x10pct.json", "structural", 0.10, 3)])
-def test_whole_output_at_headline_size_equals_the_recorded_oracle_run(ctx, record, family, div, n_fam):
+@pytest.mark.parametrize("record,family,div,n_fam,mbp,contigs", [
+    ("r04_e2e_oracle_c3.json", "structural", 0.01, 3, 3000, 24), ("r04_e2e_oracle_c5_like.json", "assembly-like", 0.013, 3, 3000, 24),
+    ("r04_e2e_oracle_2x3Gbp_d0.1.json", "structural", 0.001, 2, 3000, 24), ("r04_e2e_oracle_c4.json", "structural", 0.10, 8, 3000, 24),
+    # (round 5) three genomes at 10 %: a filter that accepts 2.4 % of the k-mers, the tiered selection's regime
+    ("r05_e2e_oracle_valley_3x10pct.json", "structural", 0.10, 3, 3000, 24),
+    # (round 6) the reference's other two published rows (README.md:157-158) as shapes: four 3 Gbp assembly-like genomes at 1.3 %
+    # ("great apes"), eleven 0.44 Gbp genomes of 16 chromosomes at 4 % ("bees")
+    ("r06_e2e_oracle_4x3Gbp_apes_like.json", "assembly-like", 0.013, 4, 3000, 24), ("r06_e2e_oracle_11x440Mbp_4pct.json", "structural", 0.04, 11, 440, 16)])
+def test_whole_output_at_headline_size_equals_the_recorded_oracle_run(ctx, record, family, div, n_fam, mbp, contigs):
     """BASELINE configs[2] (and configs[4]'s parameters on the assembly-like family, and the reference's first published row: two 3 Gbp
     genomes at 0.1 %, README.md:156, and configs[3]: eight genomes at 10 %, the sparse-filter regime) at full size, the WHOLE output: the common
     filter's popcount and an order-independent digest of every genome's complete minimizer list (3 x ~6 M minimizers) against what
@@ -144,7 +148,7 @@ def test_whole_output_at_headline_size_equals_the_recorded_oracle_run(ctx, recor
     rec = json.load(open(path))
     assert rec["all_identical"]
     args = argparse.Namespace(family=family, substitutions_only=False, k=24, w=1000, fpr=0.025)
-    total, contigs = 3_000_000_000, 24
+    total = int(mbp * 1e6)
     assert rec["key"] == bench.e2e_key(args, n_fam, total, contigs, div), "the record is for another family / parameter set"
     genomes = [bench.family_genome(ctx, args, total, contigs, j, div / 2.0) for j in range(n_fam)]
     _, nbytes = bf_size_bytes(genomes[0].total_bp, 0.025)           # (syn0.fa sorts first: it sizes the filter, cpp:105-118)

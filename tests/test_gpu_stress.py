@@ -24,4 +24,5 @@ def test_random_sketches_and_filters_match_the_oracle(seed, capsys):
 
 def test_random_families_end_to_end_match_the_oracle(capsys):
     _load("stress_pipeline").main(["--seconds", "12", "--seed", "7"])
-    assert capsys.readouterr().out.startswith("ok:")
+    # (families of many distant genomes may share no chain of four minimizers: both sides then say "no paths found" before the summary line)
+    assert capsys.readouterr().out.strip().splitlines()[-1].startswith("ok:")
