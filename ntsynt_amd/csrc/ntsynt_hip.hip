@@ -2711,6 +2711,7 @@ struct MailParams
   const uint64_t* src[8];
   uint32_t n[8];
   uint32_t off[8];
+  const unsigned long long* limit[8]; // if not null: only the first min(n, *limit) words of the range are wanted (a list and its device-side length)
   uint32_t count;
   uint64_t seq; // arrival flag value, written to the last word of the mailbox
   uint64_t* mail;
@@ -2720,8 +2721,15 @@ struct MailParams
 
 __global__ __launch_bounds__(256) void k_mail(MailParams P)
 {
-  for (uint32_t s = 0; s < P.count; ++s)
-    for (uint32_t i = threadIdx.x; i < P.n[s]; i += 256) P.mail[P.off[s] + i] = P.src[s][i];
+  // (the mailbox is host memory: a word written is a word across PCIe -- 16384 words of a list that holds 969 took 35 us)
+  uint32_t n_eff[8];
+#pragma unroll
+  for (uint32_t s = 0; s < 8; ++s)
+    n_eff[s] = s < P.count ? (P.limit[s] ? (uint32_t)min((unsigned long long)P.n[s], *P.limit[s]) : P.n[s]) : 0u;
+  __syncthreads(); // (a length may sit among the words cleared below: every lane has read it before any lane clears)
+#pragma unroll
+  for (uint32_t s = 0; s < 8; ++s)
+    for (uint32_t i = threadIdx.x; i < n_eff[s]; i += 256) P.mail[P.off[s] + i] = P.src[s][i];
   for (uint32_t i = threadIdx.x; i < P.n_zero; i += 256) P.zero[i] = 0; // (not among the sources of this mail)
   // arrival flag for the polling host: after every lane's values are visible system-wide
   __threadfence_system();
@@ -2748,9 +2756,10 @@ struct Mail
     P.n_zero = n_words;
   }
   // returns the word offset of the range in the mailbox
-  uint32_t add(const void* dev, uint32_t n_words)
+  uint32_t add(const void* dev, uint32_t n_words, const unsigned long long* dev_limit = nullptr)
   {
     P.src[P.count] = (const uint64_t*)dev;
+    P.limit[P.count] = dev_limit;
     P.n[P.count] = n_words;
     P.off[P.count] = used;
     ++P.count;
@@ -3614,8 +3623,8 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       const uint32_t a_cnt = mb.add(d_bcnt + (n_blk - 1), 1);
       const uint32_t a_tscan = mb.add(d_tscan + (n_kt - 1), 1);
       const uint32_t a_tcnt = mb.add((const uint64_t*)(d_tcnt + ((n_kt - 1) & ~1ull)), 1); // (32-bit counts: the pair holding the last one)
-      const uint32_t a_lo = mb.add(d_glo, peek);
-      const uint32_t a_hi = mb.add(d_ghi, peek);
+      const uint32_t a_lo = mb.add(d_glo, peek, d_ctl + N_SEG); // (the first n_gap of them: the count travels in the same mail)
+      const uint32_t a_hi = mb.add(d_ghi, peek, d_ctl + N_SEG);
       const uint32_t a_tier = tp ? mb.add((const uint64_t*)ws_get(ctx, "tier_stats", 16), 2) : 0u;
       // the gather runs behind the mail kernel: the counters are on their way to the host while it works
       int rc_m = mb.launch(ctx);
