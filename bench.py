@@ -1133,7 +1133,7 @@ def main():
             key = "k_hash_select_hi" if hi_kernel else "k_hash_select"
             per_64 = 17.2 if hi_kernel else 29.8
             sq_source = None
-            for rnd in (5, 4, 3, 2):
+            for rnd in (6, 5, 4, 3, 2):
                 try:
                     sq = json.load(open(os.path.join(ROOT, "profiles", f"r0{rnd}_sq_counters.json")))
                     per_64 = float(sq["kernels"][key]["valu_wave_instructions_per_64_kmers"])
