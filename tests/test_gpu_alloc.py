@@ -144,3 +144,34 @@ def test_a_small_block_does_not_hold_a_large_kept_allocation(ctx):
     assert ctx.mem_cache_stats()[0] == 128 * MB                               # not cut from the kept block
     assert ctx.mem_trim() == 128 * MB                                         # which is wholly free and goes
     tiny.free()
+
+
+def test_a_pipeline_run_reserves_its_plan_once_and_cuts_everything_from_it(tmp_path):
+    """ntsynt_amd.pipeline.run: one nts_mem_reserve sized from the file sizes (plan_bytes) before the first file is read; the filter, the
+    Bloom build's workspaces, the genomes and the sketch / graph workspaces are cut from it -- next to the reserve the run makes a
+    handful of driver calls at most (pinned slabs of the small requests, what the ingest asked while the reserve was under way)"""
+    import os
+    from ntsynt_amd import _lib, pipeline, synth
+    from ntsynt_amd.device import mem_events, mem_events_since
+    paths = synth.make_family(str(tmp_path), 3, 60_000_000, 3, 0.01, seed=77)
+    sizes = sorted(os.path.getsize(p) for p in sorted(paths))
+    plan = pipeline.plan_bytes([os.path.getsize(p) for p in sorted(paths)], 0.025, True)
+    assert plan > 2 * (1 << 30) + 1.3 * sum(sizes)
+    lib = _lib.load()
+    lib.nts_mem_trim()
+    ev0 = mem_events(lib)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        eng = pipeline.run(paths, k=24, w=1000, prefix="r", log=lambda *a: None)
+    finally:
+        os.chdir(cwd)
+    d = mem_events_since(lib, ev0)
+    assert eng.reserved_bytes >= plan - (1 << 20) and d["reserve_calls"] == 1
+    assert d["allocations_retried_after_emptying_the_cache"] == 0
+    assert d["allocations_served_from_kept_memory"] > 50
+    # the reserve, the small requests' slab, and at most a few allocations of the first file's ingest that ran next to the reserve
+    assert d["hipMalloc_hipFree_calls"] <= 12, d
+    assert d["GB_from_driver"] < plan / 1e9 + 1.0
+    assert len(eng.outputs["r.synteny_blocks.tsv"].splitlines()) > 10
+    assert "memory_reserved" in dict(eng.stage_marks)
