@@ -562,6 +562,12 @@ struct WinParams
   HashParams hp;
   const uint32_t* bf;
   FastMod fm;
+  // k_window_min<true>, whole genome: a tile writes its winners IN INDEX ORDER into the room it reserves in one of the N_SEG
+  // segments and leaves (offset, count) in a directory; a scan of the counts and one gather (k_cand_compact_slots) then give the
+  // ordered list -- no fill of the segments, no radix sort.  (A look-back chain for the tile's final offset was tried first: tiles
+  // that wait for their predecessors' counts hold their LDS and wave slots, and the probes in flight halve: 166 instead of 84 ms.)
+  uint64_t* dir_off;  // [n_tiles] first slot of the tile's winners in out_j / out_key (~0: its reservation did not fit)
+  uint32_t* dir_cnt;  // [n_tiles]
 };
 constexpr uint32_t N_SEG = 64;
 // Short windows (w < WIN_FUSE_W: the last refinement round's w = 10, -d < 1's defaults bin/ntSynt:89-91, and anything below 64): the
@@ -864,6 +870,44 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
       for (uint32_t x = 0; x < n_emit; ++x) rank += s_list[x] < idx ? 1u : 0u;
       P.out_j[(uint64_t)blockIdx.x * P.tile_cap + rank] = jb + idx;
       P.out_key[(uint64_t)blockIdx.x * P.tile_cap + rank] = s_key[pe(idx)];
+    }
+    return;
+  }
+  if (FUSED && P.dir_cnt != nullptr) {
+    // ---- ordered flush: room in a segment, the winners in index order inside it, (offset, count) into the directory ------------
+    uint64_t* s_tab = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(s_st + (size_t)P.levels * n_chunks) + 15u) & ~(uintptr_t)15u);
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_tab + 36); // (the tile's staged bases are not needed any more)
+    const uint32_t words = (E + 31u) >> 5;                      // <= 131
+    uint32_t* s_pref = s_bits + words;
+    const uint32_t seg = blockIdx.x % N_SEG;
+    if (threadIdx.x == 0) {
+      unsigned long long base = n_emit ? atomicAdd(&P.seg_count[seg], (unsigned long long)n_emit) : 0ull;
+      const bool fits = base + n_emit <= P.seg_cap;
+      P.dir_cnt[blockIdx.x] = n_emit;
+      P.dir_off[blockIdx.x] = fits ? (uint64_t)seg * P.seg_cap + base : ~0ULL;
+      if (!fits) base = ~0ull;
+      s_ctl[1] = (uint32_t)base;
+      s_ctl[2] = (uint32_t)(base >> 32);
+    }
+    // rank of a winner inside the tile: winners are distinct element indices below E -- a bitmap and the popcounts in front of each word
+    for (uint32_t q = threadIdx.x; q < words; q += WIN_THREADS) s_bits[q] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_emit; i += WIN_THREADS) atomicOr(&s_bits[s_list[i] >> 5], 1u << (s_list[i] & 31u));
+    __syncthreads();
+    if (threadIdx.x < words) {
+      uint32_t acc = 0;
+      for (uint32_t q = 0; q < threadIdx.x; ++q) acc += __popc(s_bits[q]);
+      s_pref[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    const uint64_t base = ((uint64_t)s_ctl[2] << 32) | s_ctl[1];
+    if (base == ~0ULL) return; // (the segment is full: the host sees its counter and runs the pass again with larger segments)
+    const uint64_t jbase = P.rec_vstart[rec] + tf;
+    for (uint32_t i = threadIdx.x; i < n_emit; i += WIN_THREADS) {
+      const uint32_t idx = s_list[i];
+      const uint64_t slot = (uint64_t)seg * P.seg_cap + base + s_pref[idx >> 5] + __popc(s_bits[idx >> 5] & ((1u << (idx & 31u)) - 1u));
+      P.out_j[slot] = jbase + idx;
+      P.out_key[slot] = s_key[pe(idx)];
     }
     return;
   }
@@ -2639,6 +2683,8 @@ struct WinFuse // what k_window_min<true> hashes and probes with (launch_window_
   HashParams hp;
   const uint32_t* bf;
   FastMod fm;
+  uint64_t* dir_off = nullptr; // ordered output (whole genome): the tiles' directory, see WinParams
+  uint32_t* dir_cnt = nullptr;
 };
 
 int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vs, const uint64_t* d_nv, const uint64_t* d_ts,
@@ -2685,6 +2731,12 @@ int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_
   P.run_pos = P.run_vstart = nullptr;
   P.n_runs = 0;
   P.bf = nullptr;
+  P.dir_off = nullptr;
+  P.dir_cnt = nullptr;
+  if (fuse && !out.d_tile_cnt) {
+    P.dir_off = fuse->dir_off;
+    P.dir_cnt = fuse->dir_cnt;
+  }
   if (fuse) {
     P.code = fuse->code;
     P.run_pos = fuse->run_pos;
@@ -2923,6 +2975,62 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     res.count = sparse->count + GAP_LIST_CAP;
     res.d_ctl = d_gctl;
     return NTS_OK;
+  }
+  if (fuse && n_tiles == 0) {
+    res.count = 0;
+    return NTS_OK;
+  }
+  if (fuse) {
+    // short windows over the whole genome: every tile writes its winners in index order into a segment and leaves (offset, count) in
+    // a directory; scan + gather give the ordered list -- no 0xFF fill of the segments, no radix sort of up to half a billion pairs
+    // (43 ms at w = 10)
+    uint64_t cap = ((uint64_t)(2.5 * (double)est_kmers / (double)(w + 1)) + 2ull * n_rec) / N_SEG + 65536;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      OutSegs od;
+      od.seg_cap = cap;
+      od.d_count = d_seg;
+      const uint64_t slots = cap * N_SEG;
+      od.d_j = (uint64_t*)ws_get(ctx, (pre + "out_j").c_str(), slots * 8);
+      od.d_key = (uint64_t*)ws_get(ctx, (pre + "out_key").c_str(), slots * 8);
+      uint64_t* d_doff = (uint64_t*)ws_get(ctx, (pre + "win_dir_off").c_str(), n_tiles * 8);
+      uint32_t* d_dcnt = (uint32_t*)ws_get(ctx, (pre + "win_dir_cnt").c_str(), n_tiles * 4 + 8);
+      uint64_t* d_dscan = (uint64_t*)ws_get(ctx, (pre + "win_dir_scan").c_str(), n_tiles * 8);
+      uint64_t* d_oj2 = (uint64_t*)ws_get(ctx, (pre + "out_j2").c_str(), slots * 8);
+      uint64_t* d_ok2 = (uint64_t*)ws_get(ctx, (pre + "out_key2").c_str(), slots * 8);
+      unsigned long long* d_ovf = (unsigned long long*)ws_get(ctx, (pre + "win_dir_ovf").c_str(), 8);
+      if (!od.d_j || !od.d_key || !d_doff || !d_dcnt || !d_dscan || !d_oj2 || !d_ok2 || !d_ovf) return NTS_ENOMEM;
+      HIP_TRY(ctx, hipMemsetAsync(d_seg, 0, N_SEG * sizeof(unsigned long long), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(d_ovf, 0, 8, ctx->stream));
+      fuse_args.dir_off = d_doff;
+      fuse_args.dir_cnt = d_dcnt;
+      if ((rc = launch_window_dense(ctx, nullptr, d_vs, d_nv, d_ts, n_rec, n_tiles, w, od, win_tag, nullptr, 0, fuse))) return rc;
+      {
+        ScopedTimer t(ctx, "merge_lists");
+        if (int rc_s = scan_counts<uint32_t>(ctx, d_dcnt, n_tiles, d_dscan)) return rc_s;
+        hipLaunchKernelGGL(k_cand_compact_slots, dim3((uint32_t)((n_tiles + CCS_TILES - 1) / CCS_TILES)), dim3(256), 0, ctx->stream, od.d_j, od.d_key, d_doff, d_dcnt,
+                           d_dscan, n_tiles, d_oj2, d_ok2, slots, d_ovf);
+      }
+      HIP_TRY(ctx, hipGetLastError());
+      unsigned long long segc[N_SEG];
+      uint64_t total = 0;
+      {
+        Mail m(ctx);
+        const uint32_t a_seg = m.add(d_seg, N_SEG);
+        const uint32_t a_scan = m.add(d_dscan + (n_tiles - 1), 1);
+        const uint32_t a_cnt = m.add((const uint64_t*)(d_dcnt + ((n_tiles - 1) & ~1ull)), 1); // (32-bit counts: the pair holding the last one)
+        if ((rc = m.post(ctx))) return rc;
+        for (uint32_t q = 0; q < N_SEG; ++q) segc[q] = ctx->mail[a_seg + q];
+        total = ctx->mail[a_scan] + (uint32_t)(ctx->mail[a_cnt] >> (32 * ((n_tiles - 1) & 1ull)));
+      }
+      uint64_t worst = 0;
+      for (uint32_t q = 0; q < N_SEG; ++q) worst = std::max<uint64_t>(worst, segc[q]);
+      res.d_j = d_oj2;
+      res.d_key = d_ok2;
+      res.count = total;
+      if (worst <= cap) return NTS_OK;
+      if (attempt == 1) return fail(ctx, NTS_EHIP, "minimizer segments overflowed twice");
+      cap = worst + 1024;
+    }
   }
   unsigned long long seg_counts[N_SEG];
   uint64_t count = 0;
