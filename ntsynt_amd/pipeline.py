@@ -664,6 +664,24 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         fut = writers.submit(fn, *a)
         pending_files.append(fut)
         file_of[fut] = name
+    filter_save_started = []
+
+    def start_filter_save():
+        """the filter file, behind everything that follows: straight out of HBM on the library's own copy threads where the filter has a
+        save() (the GPU backend), else device -> host copy + write.  Called as soon as the common filter stands (the file is 0.7 of a
+        run's wall clock: the loaders' clean-up, 50 ms of pinned-memory frees, used to come first) and again, to no effect, further down."""
+        if filter_save_started or bf is None or rank != 0 or common_file is not None:
+            return
+        filter_save_started.append(True)
+        if hasattr(bf, "save"):
+            def save_filter():
+                st.mark("bf_save_begin")
+                bf.save(f"{prefix}.common.bf", bf_header(bf.bytes, k, signature=bf_signature))
+                st.mark("bf_save_end")
+            submit_file(f"{prefix}.common.bf", save_filter)
+        else:
+            submit_file(f"{prefix}.common.bf", lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k, signature=bf_signature))
+
     if common_file is not None:
         # stage 3 on its own: `--common <file>` (ntsynt_run.py:23; consumed by the refinement rounds' indexlr -s, S:175-177)
         if world > 1 or not isinstance(backend, GpuBackend):
@@ -756,6 +774,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
             backend.ctx.trim_bf_build()                       # (the run builds no further filter: the buckets serve what is allocated next)
         st.stop()
         st.mark("common_filter_done")
+        start_filter_save()
     if overlap_load:
         try:
             genomes.wait_all()
@@ -811,17 +830,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
     else:
         out_prefix = prefix
 
-    if bf is not None and rank == 0 and common_file is None:
-        # filter file, behind everything that follows: straight out of HBM on the library's own copy threads where the filter
-        # has a save() (the GPU backend), else device -> host copy + write
-        if hasattr(bf, "save"):
-            def save_filter():
-                st.mark("bf_save_begin")
-                bf.save(f"{prefix}.common.bf", bf_header(bf.bytes, k, signature=bf_signature))
-                st.mark("bf_save_end")
-            submit_file(f"{prefix}.common.bf", save_filter)
-        else:
-            submit_file(f"{prefix}.common.bf", lambda: write_bf(f"{prefix}.common.bf", backend.bf_bits(bf), k, signature=bf_signature))
+    start_filter_save()
 
     join_reserve()                                            # (runs without a filter build get here with the reservation still under way)
     if device_engine:
