@@ -266,3 +266,35 @@ def test_pipeline_ranks_match_single_rank(world, tmp_path):
     for name in names:
         assert (one / name).read_bytes() == (many / name).read_bytes(), name
     assert len((one / "p.synteny_blocks.tsv").read_text().splitlines()) >= 8
+
+
+def test_packed_exchange_on_one_rank_round_trips_every_shape_and_refuses_unordered_lists():
+    """nts_mx_allgather_ex with one rank runs the same pack -> payload -> unpack path as with eight: lists with records that hold no
+    minimizer (their start index equals their successor's), one list whose positions need 64 bits, an empty list, a list of one -- all
+    come back as they went in; a list that is not in record order is refused (the packed form stores one start index per record)"""
+    import numpy as np
+    from ntsynt_amd.device import Context, Minimizers, allgather_minimizers
+    ctx = Context(0)
+    try:
+        rng = np.random.default_rng(3)
+        lists = []
+        for case in range(5):
+            n = [5000, 1, 0, 777, 40000][case]
+            rec = np.sort(rng.choice(np.arange(3, 3 + [40, 1, 1, 900, 7][case]), size=n)).astype(np.uint32)     # gaps in the record ids: records without a minimizer
+            pos = rng.integers(0, (1 << 40) if case == 3 else (1 << 31), size=n).astype(np.uint64)
+            h1 = rng.integers(0, 1 << 63, size=n).astype(np.uint64)
+            lists.append((h1, rec, pos))
+        handles = [Minimizers.from_numpy(ctx, *t) for t in lists]
+        out = allgather_minimizers(ctx, None, handles, [4, 0, 2, 1, 3], 5, slots=5)
+        for gid, t in zip([4, 0, 2, 1, 3], lists):
+            got = out[gid].to_numpy()
+            for a, b in zip(got, t):
+                assert np.array_equal(a, b), gid
+        for m in out + handles:
+            m.free()
+        bad = Minimizers.from_numpy(ctx, np.arange(10, dtype=np.uint64), np.array([0, 0, 1, 1, 2, 1, 2, 2, 3, 3], np.uint32), np.arange(10, dtype=np.uint64))
+        with pytest.raises(RuntimeError, match="record order"):
+            allgather_minimizers(ctx, None, [bad], [0], 1)
+        bad.free()
+    finally:
+        ctx.close()
