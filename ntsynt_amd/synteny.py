@@ -22,6 +22,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 MX_SUFFIX = re.compile(r'^(\S+)\.k\d+\.w\d+.tsv')
+EMPTY_FINAL = ("list index out of range (the last refinement round left no synteny block{}: the reference stops here too -- "
+               "merge_collinear_blocks takes blocks[0] of an empty list, bin/ntsynt_synteny.py:437)")
 
 
 @dataclass
@@ -697,11 +699,17 @@ class SyntenyEngine:
             blocks = self._round_blocks()
             ordered = self._sorted(blocks)
             self._emit(f"{self.prefix}.pre-collinear-merge.synteny_blocks.tsv", ordered)
-            if last and ordered:
+            if last:
+                # S:505-510 calls merge_collinear_blocks twice, unconditionally: with no block left, or none of at least z bases, the
+                # reference ends in an IndexError at S:437 -- the run fails there as well (pipeline.run then removes the block tables, as
+                # Snakemake removes a failed rule's outputs)
+                if not ordered:
+                    raise IndexError(EMPTY_FINAL.format(""))
                 merged = self._merge(ordered)
                 merged = [b for b in merged if self._long_enough(b)]
-                if merged:
-                    merged = self._merge(merged)
+                if not merged:
+                    raise IndexError(EMPTY_FINAL.format(" of at least z bases"))
+                merged = self._merge(merged)
                 if self.dev and merged:
                     self._warn_overlaps([[b.rec[a] for b in merged] for a in range(self.G)],
                                         [[self._start(b, a) for b in merged] for a in range(self.G)],

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import c_vp, u64
-from .synteny import MX_SUFFIX, SyntenyEngine
+from .synteny import EMPTY_FINAL, MX_SUFFIX, SyntenyEngine
 
 IV_OFF = np.int64(1) << 40            # composite interval key: record * 2^40 + position (same as synteny.py)
 # memory layout of nts_interval (include/ntsynt_hip.h): hard-mask intervals travel as one array
@@ -356,11 +356,14 @@ class DeviceSyntenyEngine(SyntenyEngine):
             blocks = self._blocks()
             ordered = self._sorted(blocks)
             self._emit(f"{self.prefix}.pre-collinear-merge.synteny_blocks.tsv", ordered)
-            if last and ordered["n"]:
+            if last:
+                if not ordered["n"]:                           # (S:437: the reference's IndexError -- see SyntenyEngine.run)
+                    raise IndexError(EMPTY_FINAL.format(""))
                 merged = self._merge(ordered)
                 merged = self._take(merged, np.flatnonzero(self._long_mask(merged)))
-                if merged["n"]:
-                    merged = self._merge(merged)
+                if not merged["n"]:
+                    raise IndexError(EMPTY_FINAL.format(" of at least z bases"))
+                merged = self._merge(merged)
                 if self.dev and merged["n"]:
                     self._warn_overlaps(merged["rec"], np.minimum(merged["first_pos"], merged["last_pos"]),
                                         np.maximum(merged["first_pos"], merged["last_pos"]) + self.k)

@@ -660,11 +660,12 @@ class SyntenyOracle:
             blocks = self.drop_small(blocks, 4)
             ordered = sorted(blocks, key=SynBlock.sort_key)
             self._emit(f"{self.prefix}.pre-collinear-merge.synteny_blocks.tsv", ordered)
-            if last and ordered:
+            if last:
+                # S:505-510: both calls are unconditional -- a last round that leaves no block, or none of at least z bases, ends the
+                # reference with `IndexError: list index out of range` at S:437 (`curr_block = blocks[0]`); so does merge_collinear
                 merged = self.merge_collinear(ordered)
                 merged = [b for b in merged if b.long_enough(self.z)]
-                if merged:
-                    merged = self.merge_collinear(merged)
+                merged = self.merge_collinear(merged)
                 if getattr(self, "dev", False):                           # S:513-514
                     self.check_non_overlapping(merged)
                 self._emit(f"{self.prefix}.synteny_blocks.tsv", merged, verbose=True)

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Randomised comparison of the reference's OWN graph stage (bin/ntsynt_synteny.py run over the stand-ins of make_golden_refrun.py)
+with the CPU restatement (oracle/synteny_oracle.py run_pipeline) on families and parameter sets drawn at random: the run's
+pre-collinear-merge and final TSVs, its interarrival file and its --dev warnings must be identical.  Nothing is stored but the log
+(profiles/r06_refrun_stress.log); the nine committed scenarios are what the test suite replays.  Runs ONLY where /root/reference
+exists:  PYTHONHASHSEED=0 python tests/golden/refrun_stress.py [--seconds 300] [--seed 1]"""
+import argparse
+import contextlib
+import io
+import os
+import random
+import sys
+import tempfile
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import make_golden_refrun as M  # noqa: E402
+from oracle import synteny_oracle as SO  # noqa: E402
+
+
+def oracle_outputs(sc, fastas):
+    orig = SO.SyntenyOracle.__init__
+
+    def init(self, *a, **k):
+        orig(self, *a, **k)
+        self.dev = True
+    err = io.StringIO()
+    SO.SyntenyOracle.__init__ = init
+    try:
+        with contextlib.redirect_stderr(err), contextlib.redirect_stdout(io.StringIO()):
+            k, w = sc["k"], sc["w"]
+            from oracle import nts_oracle as O
+            genomes = {p: O.read_fasta(p) for p in fastas}
+            bf = O.common_bf(genomes, k, 0.025) if sc.get("common", True) else None
+            tables, by_tsv = {}, {}
+            for p in fastas:
+                tsv = f"{os.path.basename(p)}.k{k}.w{w}.tsv"
+                tables[tsv] = SO.mx_tables_from_tokens(SO.mx_records_from_arrays(genomes[p].names, O.minimize(genomes[p], k, w, bf)))
+                by_tsv[tsv] = genomes[p]
+            eng = SO.SyntenyOracle(list(tables), by_tsv, k, w, sc["w_rounds"], sc["indel"], sc["merge"], sc["z"], "ora", bf=bf,
+                                   n=sc.get("min_weight", 0), interarrivals=True)
+            eng.load(tables)
+            eng.main()
+    finally:
+        SO.SyntenyOracle.__init__ = orig
+    return eng.outputs, [ln for ln in err.getvalue().splitlines() if ln.startswith("WARNING")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    ns, sb, ab = M.install()
+    rng = random.Random(a.seed)
+    M.OUT = tempfile.mkdtemp(prefix="refrun_stress_")
+    t_end = time.time() + a.seconds
+    n = same = stopped = 0
+    seen = {"min_weight_below_G": 0, "no_common": 0, "blocks": 0, "warnings": 0, "not_oriented": 0}
+    while time.time() < t_end:
+        G = rng.choice([2, 2, 3, 3, 4, 5])
+        sc = dict(name=f"t{n}", n=G, bp=rng.choice([50_000, 90_000, 140_000, 200_000]), ctg=rng.choice([1, 2, 3, 6]),
+                  div=rng.choice([0.002, 0.005, 0.01, 0.02, 0.04]), seed=2000 + rng.randrange(10 ** 6), k=rng.choice([16, 20, 24, 32]),
+                  w=rng.choice([30, 50, 80, 150, 400]), w_rounds=rng.choice([[10, 4], [15, 6], [20], [25, 8], [12, 5]]),
+                  indel=rng.choice([150, 400, 1500, 10000]), merge=rng.choice(["1w", "3w", 60, 600, 5000]), z=rng.choice([40, 100, 300]),
+                  micro=rng.choice([0, 8, 20, 40]), n_runs=rng.random() < 0.4)
+        if sc["w_rounds"][0] >= sc["w"]:
+            continue
+        if rng.random() < 0.3 and G > 2:
+            sc["min_weight"] = rng.randint(2, G - 1)
+            seen["min_weight_below_G"] += 1
+        if rng.random() < 0.15:
+            sc["common"] = False
+            seen["no_common"] += 1
+        n += 1
+        cwd = os.getcwd()
+        try:
+            try:
+                outputs, counts, meta = M.run_scenario(ns, sc)
+            except (SystemExit, IndexError, AssertionError) as e:          # no paths / the reference's merge on an empty list / its erosion assert
+                ref_stop = type(e).__name__
+                outputs = None
+            d = os.path.join(M.OUT, sc["name"])
+            with tempfile.TemporaryDirectory() as tmp:
+                os.chdir(tmp)
+                fastas = []
+                import gzip
+                if outputs is None:                                        # (the scenario's files were not kept: make the family again)
+                    from ntsynt_amd import synth
+                    fastas = synth.make_family(tmp, sc["n"], sc["bp"], sc["ctg"], sc["div"], seed=sc["seed"], n_runs=sc["n_runs"], micro=sc["micro"], line_width=0)
+                else:
+                    for f in meta["fastas"]:
+                        with gzip.open(os.path.join(d, f + ".gz")) as fi, open(f, "wb") as fo:
+                            fo.write(fi.read())
+                        fastas.append(os.path.join(tmp, f))
+                try:
+                    ora, warns = oracle_outputs(sc, fastas)
+                    ora_stop = None
+                except (SystemExit, IndexError, AssertionError) as e:
+                    ora, ora_stop = None, type(e).__name__
+            if outputs is None or ora is None:
+                ok = (outputs is None) == (ora is None)
+                stopped += ok
+                if not ok:
+                    print("MISMATCH (one side stopped)", sc, "reference:", None if outputs is not None else ref_stop, "oracle:", ora_stop, flush=True)
+                    sys.exit(1)
+                continue
+            pre = meta["prefix"]
+            ok = (ora["ora.synteny_blocks.tsv"] == outputs[f"{pre}.synteny_blocks.tsv"].replace("", "") and
+                  ora["ora.pre-collinear-merge.synteny_blocks.tsv"] == outputs[f"{pre}.pre-collinear-merge.synteny_blocks.tsv"] and
+                  ora["ora.interarrivals.tsv"] == outputs[f"{pre}.interarrivals.tsv"] and warns == meta["warnings"])
+            if not ok:
+                print("MISMATCH", sc, flush=True)
+                sys.exit(1)
+            same += 1
+            seen["blocks"] += len(outputs[f"{pre}.synteny_blocks.tsv"].splitlines()) // G
+            seen["warnings"] += len(meta["warnings"])
+            seen["not_oriented"] += meta["n_not_oriented"]
+        finally:
+            os.chdir(cwd)
+            import shutil
+            shutil.rmtree(os.path.join(M.OUT, sc["name"]), ignore_errors=True)
+    print(f"ok: {n} random scenarios -- {same} with every output of the reference's run identical to the restatement's, {stopped} on which both "
+          f"stop (no paths / the reference's own IndexError on an empty final list / its erosion assert); {seen}, seed {a.seed}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -405,11 +405,10 @@ def drive_host(lock, initial_lists, check_outputs=None):
         blocks = lock.round_blocks()
         ordered = h._sorted(blocks)
         h._emit(f"{h.prefix}.pre-collinear-merge.synteny_blocks.tsv", ordered)
-        if last and ordered:
-            merged = h._merge(ordered)
+        if last:
+            merged = h._merge(ordered)                          # (the recorded runs all end with blocks: S:437's IndexError is tests/test_engine_cpu.py's)
             merged = [b for b in merged if h._long_enough(b)]
-            if merged:
-                merged = h._merge(merged)
+            merged = h._merge(merged)
             if h.dev and merged:
                 h._warn_overlaps([[b.rec[a] for b in merged] for a in range(h.G)],
                                  [[h._start(b, a) for b in merged] for a in range(h.G)],

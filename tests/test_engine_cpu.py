@@ -595,3 +595,38 @@ def test_interarrivals_file_matches_the_oracle(tmp_path):
     assert len(want.splitlines()) > 1000
     assert sorted(out["p.interarrivals.tsv"].splitlines()) == sorted(want.splitlines())
     assert out["p.synteny_blocks.tsv"] == ora.outputs["p.synteny_blocks.tsv"]
+
+
+def test_a_last_round_without_blocks_ends_the_run_like_the_reference(tmp_path):
+    """bin/ntsynt_synteny.py:505-510 calls merge_collinear_blocks twice without looking: when the last refinement round leaves no block of
+    at least z bases the reference ends with `IndexError: list index out of range` at S:437 (found by tests/golden/refrun_stress.py
+    running the reference's own code).  Oracle and engine stop the same way -- neither writes a final table of its own making."""
+    cwd = os.getcwd()
+    try:
+        paths = synth.make_family(str(tmp_path), 2, 300_000, 2, 0.01, seed=3)
+        with pytest.raises(IndexError):
+            os.makedirs(tmp_path / "o")
+            os.chdir(tmp_path / "o")
+            SO.run_pipeline(paths, k=24, w=200, w_rounds=[50, 10], indel=500, merge=1000, block_size=10 ** 8, prefix="p")
+        genomes = [O.read_fasta(p) for p in paths]
+        bf = O.common_bf(dict(zip(paths, genomes)), 24, 0.025)
+        tsvs = [f"{os.path.basename(p)}.k24.w200.tsv" for p in paths]
+
+        def sketch_fn(i, masks, new_w):
+            g = genomes[i]
+            seqs = []
+            for r in range(len(g.names)):
+                buf = bytearray(g.record(r))
+                for mr, s, e in masks:
+                    if mr == r:
+                        buf[max(0, s):min(len(buf), e)] = b"N" * (min(len(buf), e) - max(0, s))
+                seqs.append(bytes(buf))
+            return oracle_flat(O.minimize(O.Genome(g.names, seqs), 24, new_w, bf))
+        os.makedirs(tmp_path / "e")
+        os.chdir(tmp_path / "e")
+        eng = SyntenyEngine(tsvs, [g.names for g in genomes], 24, 200, [50, 10], 500, 1000, 10 ** 8, "p", build_graph_numpy, sketch_fn, walk_paths,
+                            degree_fn=edge_degrees)
+        with pytest.raises(IndexError, match=r"ntsynt_synteny\.py:437"):
+            eng.run([oracle_flat(O.minimize(g, 24, 200, bf)) for g in genomes])
+    finally:
+        os.chdir(cwd)
