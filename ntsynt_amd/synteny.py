@@ -506,6 +506,10 @@ class SyntenyEngine:
         return masks
 
     def _new_round_graph(self, blocks, new_w, prev_w):
+        if not blocks:
+            # S:134-146 masks, and S:150-192 sketches again, the assemblies the blocks name: a round that starts without a block reads
+            # no assembly at all and adds nothing to the graph (the run then goes on over the graph as the last round left it)
+            return np.zeros(self.v_hash.size, bool)
         masks = self._mask_intervals(blocks, prev_w)
         nv = self.v_hash.size
         internal = np.zeros(nv, bool)

@@ -340,12 +340,13 @@ class DeviceSyntenyEngine(SyntenyEngine):
         prev_w = self.w
         for new_w in self.w_rounds:
             self.log(f"Extending synteny blocks with w = {new_w}")
-            masks = self._mask_intervals(blocks, prev_w)
-            spans = self._spans(blocks)
-            lists = self._sketch_round(masks, new_w)
-            self._add(lists, spans)
-            for mx in lists:
-                mx.free()
+            if blocks["n"]:                                    # (no block: no assembly is sketched again -- SyntenyEngine._new_round_graph)
+                masks = self._mask_intervals(blocks, prev_w)
+                spans = self._spans(blocks)
+                lists = self._sketch_round(masks, new_w)
+                self._add(lists, spans)
+                for mx in lists:
+                    mx.free()
             if self.simplify:
                 self._simplify_dev(apply_deletions=False)      # S:483-491: the deletions are lost, the promotions stay
             last = new_w == self.w_rounds[-1]

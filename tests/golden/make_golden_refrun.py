@@ -625,6 +625,11 @@ SCENARIOS = [
     dict(name="s6_min_weight_2_of_3", n=3, bp=150_000, ctg=2, div=0.005, seed=762111, k=16, w=80, w_rounds=[10, 6], indel=500, merge=800, z=50, micro=20, n_runs=True, min_weight=2),
     dict(name="s8_min_weight_3_of_4", n=4, bp=150_000, ctg=3, div=0.002, seed=774273, k=20, w=30, w_rounds=[10, 4], indel=500, merge="2w", z=50, micro=20, n_runs=False, min_weight=3),
     dict(name="s9_min_weight_3_of_4_b", n=4, bp=150_000, ctg=2, div=0.005, seed=298962, k=24, w=50, w_rounds=[15, 4], indel=500, merge="2w", z=100, micro=20, n_runs=False, min_weight=3),
+    # a refinement round that ends without a block (found by refrun_stress.py): the next round's synteny_beds is empty, S:134-192 read no
+    # assembly, and the last round's merge_collinear_blocks ends the reference in an IndexError at S:437 (kept: `stopped` in meta.json;
+    # the final table on disk is the initial round's, the pre-merge table the empty one the last round wrote)
+    dict(name="s10_round_without_blocks", n=4, bp=50_000, ctg=1, div=0.005, seed=655642, k=24, w=400, w_rounds=[10, 4], indel=150, merge="1w", z=100, micro=8, n_runs=True,
+         min_weight=3, keep_stopped=True),
     # no common filter (ntSynt --no-common: indexlr without -s, S:181)
     dict(name="s7_no_common_filter", n=2, bp=120_000, ctg=2, div=0.01, seed=107, k=24, w=64, w_rounds=[16, 5], indel=2000, merge=60, z=100, micro=10, n_runs=True, common=False),
 ]
@@ -669,10 +674,19 @@ def run_scenario(ns, sc):
                                          interarrivals=True, t=1)
             trace, mx = [], MxTable()
             so, se = io.StringIO(), io.StringIO()
+            stopped = None
             with contextlib.redirect_stdout(so), contextlib.redirect_stderr(se):
                 eng = ns.NtSyntSynteny(args)
                 record(eng, trace, mx)
-                eng.main_synteny()
+                try:
+                    eng.main_synteny()
+                except IndexError as e:
+                    # (S:437: merge_collinear_blocks on an empty list -- the reference's own end of a run whose last round leaves no block).
+                    # With sc["keep_stopped"] the run is kept as a scenario all the same: its trace up to there is what the engines are
+                    # held against, its final table is the one the initial round wrote
+                    if not sc.get("keep_stopped"):
+                        raise
+                    stopped = f"IndexError: {e}"
             # the initial table is overwritten by the final one (S:516-523): recover it from the trace's first C9 result
             outputs = {}
             for name in (f"{prefix}.synteny_blocks.tsv", f"{prefix}.pre-collinear-merge.synteny_blocks.tsv", f"{prefix}.interarrivals.tsv"):
@@ -688,7 +702,7 @@ def run_scenario(ns, sc):
                     fo.write(fi.read())
                 shutil.copy(p + ".fai", os.path.join(out_dir, p + ".fai"))
             meta = dict(sc)
-            meta.update(fastas=fastas, prefix=prefix, warnings=warnings, n_not_oriented=len(stdout_not_oriented),
+            meta.update(fastas=fastas, prefix=prefix, warnings=warnings, stopped=stopped, n_not_oriented=len(stdout_not_oriented),
                         bf_bytes=int(bf.size) if use_common else 0, bf_popcount=int(O.bf_popcount(bf)) if use_common else 0,
                         tsv_sha1={t: hashlib.sha1(open(t, "rb").read()).hexdigest() for t in tsvs})
             with open(os.path.join(out_dir, "meta.json"), "w") as fh:

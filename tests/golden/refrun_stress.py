@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised comparison of the reference's OWN graph stage (bin/ntsynt_synteny.py run over the stand-ins of make_golden_refrun.py)
-with the CPU restatement (oracle/synteny_oracle.py run_pipeline) on families and parameter sets drawn at random: the run's
+with the CPU restatement (oracle/synteny_oracle.py run_pipeline) AND the product's host-array engine (ntsynt_amd/synteny.py, graph build
+and re-sketch from the CPU test doubles) on families and parameter sets drawn at random: the run's
 pre-collinear-merge and final TSVs, its interarrival file and its --dev warnings must be identical.  Nothing is stored but the log
-(profiles/r06_refrun_stress.log); the nine committed scenarios are what the test suite replays.  Runs ONLY where /root/reference
+(profiles/r06_refrun_stress.log); the ten committed scenarios are what the test suite replays.  Runs ONLY where /root/reference
 exists:  PYTHONHASHSEED=0 python tests/golden/refrun_stress.py [--seconds 300] [--seed 1]"""
 import argparse
 import contextlib
@@ -46,6 +47,25 @@ def oracle_outputs(sc, fastas):
     finally:
         SO.SyntenyOracle.__init__ = orig
     return eng.outputs, [ln for ln in err.getvalue().splitlines() if ln.startswith("WARNING")]
+
+
+class _Shim:
+    "what tests.test_refrun_product.host_engine reads of a Scenario"
+
+    def __init__(self, sc):
+        self.meta = dict(sc, indel=sc["indel"], merge=sc["merge"], z=sc["z"])
+        self.prefix = "eng"
+        self.min_weight = sc.get("min_weight", 0)
+
+
+def product_outputs(sc, fastas):
+    "the product's host-array engine (ntsynt_amd/synteny.py; graph build and re-sketch from the CPU test doubles) on the same family"
+    from tests.test_refrun_product import host_engine
+    eng, initial = host_engine(_Shim(sc), fastas)
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err), contextlib.redirect_stdout(io.StringIO()):
+        out = eng.run(initial)
+    return out, [ln for ln in err.getvalue().splitlines() if ln.startswith("WARNING")]
 
 
 def main():
@@ -100,6 +120,17 @@ def main():
                     ora_stop = None
                 except (SystemExit, IndexError, AssertionError) as e:
                     ora, ora_stop = None, type(e).__name__
+                try:
+                    prod, pwarns = product_outputs(sc, fastas)
+                    prod_stop = None
+                except (SystemExit, IndexError, AssertionError) as e:
+                    prod, prod_stop = None, type(e).__name__
+                if (prod is None) != (ora is None) or (prod is not None and not (
+                        prod["eng.synteny_blocks.tsv"] == ora["ora.synteny_blocks.tsv"] and pwarns == warns and
+                        prod["eng.pre-collinear-merge.synteny_blocks.tsv"] == ora["ora.pre-collinear-merge.synteny_blocks.tsv"] and
+                        sorted(prod["eng.interarrivals.tsv"].splitlines()) == sorted(ora["ora.interarrivals.tsv"].splitlines()))):
+                    print("MISMATCH between the product's host engine and the restatement", sc, prod_stop, ora_stop, flush=True)
+                    sys.exit(1)
             if outputs is None or ora is None:
                 ok = (outputs is None) == (ora is None)
                 stopped += ok
@@ -122,7 +153,7 @@ def main():
             os.chdir(cwd)
             import shutil
             shutil.rmtree(os.path.join(M.OUT, sc["name"]), ignore_errors=True)
-    print(f"ok: {n} random scenarios -- {same} with every output of the reference's run identical to the restatement's, {stopped} on which both "
+    print(f"ok: {n} random scenarios -- {same} with every output of the reference's run identical to the restatement's and the product's host engine's, {stopped} on which all three "
           f"stop (no paths / the reference's own IndexError on an empty final list / its erosion assert); {seen}, seed {a.seed}", flush=True)
 
 

@@ -59,6 +59,18 @@ class Scenario:
     def min_weight(self):
         return self.meta.get("min_weight", 0)
 
+    @property
+    def stopped(self):
+        "the exception the reference's run ended in (a last round without blocks: IndexError at S:437), or None"
+        return self.meta.get("stopped")
+
+    def ends_like_the_reference(self):
+        """Context for whatever runs the scenario to its end: a run the reference finished must finish, one it ended in an IndexError must
+        end in one (what it had written by then is compared by the caller)."""
+        import contextlib
+        import pytest
+        return pytest.raises(IndexError) if self.stopped else contextlib.nullcontext()
+
 
 def edge_digest(edges):
     "the digest make_golden_refrun.py stores for a graph: sha1 over the sorted (smaller name, larger name, weight) lines"
@@ -82,6 +94,7 @@ class Cursor:
     "the trace's events in call order"
 
     def __init__(self, scenario):
+        self.sc = scenario
         self.mx = scenario.trace["mx"]
         self.events = scenario.trace["events"]
         self.i = 0
@@ -320,6 +333,13 @@ class HostLockstep:
             terminal = h._new_round_graph(blocks, new_w, prev_w)
         finally:
             h.graph_fn = graph_fn
+        if "args" not in captured:                             # a round without a block: the engine reads nothing and builds nothing
+            assert not blocks and ev_g["sketch"] == lists_digest({}, {}), "only a round without blocks may skip the re-sketch"
+            nothing = lists_digest({}, {})
+            assert ev_f["lists_out"] == lists_digest({}) and ev_u["lists_common"] == lists_digest({}) and ev_u["n_valid"] == 0
+            assert ev_u["info_after"] == nothing and not ev_x["terminal"] and not ev_x["internal"] and not terminal.any()
+            self.after("add", h)
+            return terminal
         lists, keeps, list_ids = captured["args"]
         sketch, sketch_info, filtered = {}, {}, {}
         for a in range(h.G):
@@ -406,7 +426,9 @@ def drive_host(lock, initial_lists, check_outputs=None):
         ordered = h._sorted(blocks)
         h._emit(f"{h.prefix}.pre-collinear-merge.synteny_blocks.tsv", ordered)
         if last:
-            merged = h._merge(ordered)                          # (the recorded runs all end with blocks: S:437's IndexError is tests/test_engine_cpu.py's)
+            if not ordered:                                     # S:437: the reference stopped here, after its last recorded call
+                assert lock.cur.done() and lock.sc.stopped, "the engine has no block where the reference's run had some"
+            merged = h._merge(ordered)                          # (IndexError without a block, as S:437)
             merged = [b for b in merged if h._long_enough(b)]
             merged = h._merge(merged)
             if h.dev and merged:

@@ -191,6 +191,8 @@ class TracedOracle(SO.SyntenyOracle):
         return out
 
     def merge_collinear(self, blocks):                                # S:428-472
+        if not blocks and self.cur.sc.stopped and self.cur.done():   # S:437: the reference's run ended inside this call
+            return super().merge_collinear(blocks)
         ev = self.cur.take("merge_collinear_blocks")
         assert ev["n_in"] == len(blocks)
         out = super().merge_collinear(blocks)
@@ -217,7 +219,7 @@ def _run_traced(sc, tmp):
     eng.filter_lists = eng._filter_lists_checked
     eng.load(tables)
     err = io.StringIO()
-    with contextlib.redirect_stderr(err):
+    with contextlib.redirect_stderr(err), sc.ends_like_the_reference():
         eng.main()
     return eng, [ln for ln in err.getvalue().splitlines() if ln.startswith("WARNING")]
 
