@@ -39,6 +39,17 @@ def main(argv=None):
                   block_size=int(rng.choice([200, 500, 1000])))
         if isinstance(kw["merge"], str) and kw["merge"].isdigit():
             kw["merge"] = int(kw["merge"])
+        if rng.random() < 0.3 and n_g <= 5:
+            # a tight family: small genomes, short windows, small thresholds -- where rounds end without blocks, paths turn around and
+            # the last round's stops (S:330, S:437) are reached (tests/golden/refrun_stress.py's regime, here through the HIP path)
+            case.update(bp=int(rng.integers(50_000, 400_000)), ctg=int(rng.choice([1, 2, 3])), div=float(rng.choice([0.002, 0.005, 0.02])), micro=int(rng.choice([8, 20])))
+            kw.update(w=int(rng.choice([30, 60, 150, 400])), w_rounds=[int(x) for x in rng.choice([[10, 4], [20, 5], [12, 6]])],
+                      indel=int(rng.choice([150, 500])), merge=rng.choice(["1w", "2w", 600]).item(), block_size=int(rng.choice([50, 100, 150])))
+            if isinstance(kw["merge"], str) and kw["merge"].isdigit():
+                kw["merge"] = int(kw["merge"])
+        # -n (ntsynt_run.py:17): edges fewer than all assemblies support stay
+        if n_g >= 3 and rng.random() < 0.3:
+            kw["n"] = int(rng.integers(2, n_g))
         # the hidden switches of the reference's CLI and the Snakefile's experimental repeat filter, now and then
         kw.update(common=bool(rng.random() >= 0.12), simplify=bool(rng.random() >= 0.2), repeat=bool(rng.random() < 0.1))
         tmp = tempfile.mkdtemp(prefix="nts_stress_")
