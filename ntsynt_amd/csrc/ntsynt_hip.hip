@@ -2945,7 +2945,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
   const char* win_tag = fuse ? (filter ? "hash_probe" : "hash_only") : "window_min"; // (the fused pass is timed as the hashing pass it replaces)
   OutSegs segs;
   segs.d_count = d_seg;
-  segs.seg_cap = std::max<uint64_t>(256, (3 * est_kmers / w + 2 * n_tiles) / N_SEG + 64);
+  segs.seg_cap = std::max<uint64_t>(256, ((uint64_t)(ctx->dense_seg_per_window * (double)est_kmers / (double)w) + 2 * n_tiles) / N_SEG + 64);
   // ---- few uncovered ranges: no host round trip, no sort -----------------------------------------------------
   // the window kernel writes every tile's winners in order to a slot of its own; one workgroup (k_gap_collect) strings
   // the tiles together, k_finalize merges them into the sparse winners; the count is read at the call's end
@@ -3056,6 +3056,8 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     }
     if (worst <= segs.seg_cap) break;
     if (attempt == 1) return fail(ctx, NTS_EHIP, "minimizer segments overflowed twice");
+    if (est_kmers >= (1ull << 20)) // (a genome-sized call: the next one starts from what this one needed)
+      ctx->dense_seg_per_window = std::max(ctx->dense_seg_per_window, 1.15 * (double)worst * N_SEG * (double)w / (double)est_kmers);
     segs.seg_cap = worst;
   }
   res.count = count;
@@ -3713,6 +3715,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     Q.gap_count = d_ctl + N_SEG;
     Q.gap_cap = gap_cap;
     Q.overflow = d_ctl + N_SEG + 1;
+    Q.no_gaps = accept_all ? 1u : 0u; // (the list holds every accepted k-mer that can win: a window without one has no minimizer)
     {
       ScopedTimer t(ctx, "sparse_win");
       hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
@@ -3767,6 +3770,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       m = listed;
       if (listed > m_max) worst = std::max<uint64_t>(worst, listed / N_SEG + 1); // the compacted array was cut short
     }
+    if (NTS_KNOB("NTS_DEBUG_RETRY")) fprintf(stderr, "[select] attempt %d: worst segment %llu of %llu, listed %llu, tiers %d\n", attempt, (unsigned long long)worst, (unsigned long long)cseg_cap, (unsigned long long)m, tp ? 1 : 0);
     if (worst <= cseg_cap) break;
     if (elim_on) ctx->elim_needs_full_cap = true;
     if (attempt == 1) return fail(ctx, NTS_EHIP, "candidate segments overflowed twice");
@@ -3991,7 +3995,10 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   // (tiers forced: wherever the kernel applies.  Windows of 64 .. 199 k-mers, where one threshold never paid and every k-mer was probed:
   //  the tiered selection is looked at there too -- a whole 3 Gbp genome at w = 100 against its family's filter: 90 ms the dense way)
   const bool tiers_forced = ctx->tier_mode == 2 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0;
-  const bool tiers_small_w = ctx->tier_mode == 0 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0 && w >= 64 && w < 200;
+  // (windows below WIN_FUSE_W = 64, round 6: the same selection down to w = 8 where the filter accepts enough -- c0 / w below tier_small_c)
+  const uint32_t tier_min_w = NTS_KNOB("NTS_TIER_MIN_W") ? (uint32_t)atoi(NTS_KNOB("NTS_TIER_MIN_W")) : 8u;
+  const double tier_small_c = NTS_KNOB("NTS_TIER_SMALL_C") ? atof(NTS_KNOB("NTS_TIER_SMALL_C")) : 0.4;
+  const bool tiers_small_w = ctx->tier_mode == 0 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0 && w >= tier_min_w && w < 200;
   if ((pruned || tiers_forced || tiers_small_w) && prune_c == 0) {
     if (filter) {
       uint64_t pc = 0;
@@ -4038,11 +4045,17 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     // Tiered selection (nts_tiers.inc): thresholds tau_0 2^t instead of one threshold, each probed only where a window is still
     // without an accepted k-mer -- ~3.4/p probes per window instead of 11/p.  It takes over where one threshold lists so many
     // k-mers that the upper-halves kernel no longer applies, down to accepted shares where even the first tier is half of all k-mers.
-    if (filter && ctx->sketch_mode == 0 && ctx->tier_mode != 1 && k <= FAST_K_MAX && w >= 64 && w <= 4097) {
+    if (filter && ctx->sketch_mode == 0 && ctx->tier_mode != 1 && k <= FAST_K_MAX && w >= tier_min_w && w <= 4097) {
       const double x0 = ctx->tier_x0 > 0 ? ctx->tier_x0 : 2.4;
       const double c0 = x0 / std::max(p, 1e-6);
       const double switch_c = 54.0 * (double)w / 1000.0; // (beyond it k_hash_select takes over from k_hash_select_hi)
-      if (c0 <= 0.5 * (double)w && (ctx->tier_mode == 2 || want > switch_c)) {
+      // (short windows: the other way is k_window_min<true>, every k-mer probed inside the window tile at ~85 ms per 3 Gbp whatever w;
+      //  the tiers take ~91 ms per probe and k-mer, their probes per k-mer are ~1.9 c0 / w: they pay below c0 / w ~ 0.45 -- scripts/tiers_small_w.py)
+      const double c0_max = (w < WIN_FUSE_W ? tier_small_c : 0.5) * (double)w;
+      // (the accepted k-mers found go through six arrays of 8 bytes sized for 7.5 / w of the k-mers: 108 GB for 3 Gbp at w = 10 --
+      //  beyond 120 GB, or when the allocation fails, the window tiles, which keep nothing but the minimizers, take the call)
+      const bool fits = w >= WIN_FUSE_W || 48.0 * 7.5 * (double)rt.n_valid / (double)w <= 120e9;
+      if (c0 <= c0_max && fits && (ctx->tier_mode == 2 || want > switch_c)) {
         tiered = true;
         pruned = false;
         plan.c0 = c0;
@@ -4109,9 +4122,18 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
 
   for (int attempt = 0;; ++attempt) {
     SortedOut res;
-    if (pruned || accept_all || tiered)
-      SK_TRY(run_pruned(ctx, g, *T, k, w, filter, prune_c, p, res, accept_all, tiered ? &plan : nullptr));
-    else
+    if (pruned || accept_all || tiered) {
+      const int rc_p = run_pruned(ctx, g, *T, k, w, filter, prune_c, p, res, accept_all, tiered ? &plan : nullptr);
+      if (rc_p == NTS_ENOMEM && tiered && !pruned && !accept_all && w < WIN_FUSE_W) {
+        // short windows have a second way that keeps nothing but the minimizers (k_window_min<true>): the lists of accepted k-mers
+        // the tiers fill did not fit the device next to what the caller holds
+        tiered = false;
+        ctx->last_c = ctx->last_tiers = 0;
+        SK_TRY(run_dense_sorted(ctx, g, *T, k, w, filter, nullptr, nullptr, nullptr, rt.n_valid, "", res));
+      } else {
+        SK_TRY(rc_p);
+      }
+    } else
       SK_TRY(run_dense_sorted(ctx, g, *T, k, w, filter, nullptr, nullptr, nullptr, rt.n_valid, "", res));
     const uint64_t count = res.count; // exact, or an upper bound when the count still lives on the device
     mx->n = count;

@@ -88,7 +88,7 @@ def main(argv=None):
         bf = a
         batch = Genome.concat(ctx, [dg, dg2])
         for _ in range(4):
-            w = int(rng.choice([10, 33, 64, 100, 250, 500, 1000, 2500]))
+            w = int(rng.choice([8, 10, 10, 13, 24, 33, 47, 63, 64, 100, 250, 500, 1000, 2500]))   # (below 64: tiers or the window tiles, by the filter)
             mode, c = [("auto", 0), ("pruned", int(rng.choice([1, 4, 12, 40, 300]))), ("dense", 0)][int(rng.integers(0, 3))]
             use_bf = bool(rng.integers(0, 2))
             ctx.sketch_mode(mode, c)

@@ -97,6 +97,37 @@ def test_tiers_equal_dense_and_oracle(ctx, k, w, rate, fpr):
     _check(ctx, og, dg, obf, dbf, k, w)
 
 
+@pytest.mark.parametrize("k,w,rate", [(24, 10, 0.01), (24, 8, 0.002), (24, 16, 0.01), (24, 24, 0.01), (24, 25, 0.02), (24, 33, 0.02), (24, 63, 0.04), (16, 12, 0.01),
+                                      (40, 20, 0.005), (96, 48, 0.003)])
+def test_tiers_below_64_equal_the_window_tiles_and_the_oracle(ctx, k, w, rate):
+    """Short windows (the last refinement round's w = 10, bin/ntSynt:89-91): probes in increasing hash order where a window is still open
+    against k_window_min<true>, which probes every k-mer, and against the oracle.  With w <= k every substitution leaves a stretch of at
+    least w k-mers without an accepted one: such windows have no minimizer on either path."""
+    og, dg, obf, dbf = _case(ctx, 1200 + k + w, LENGTHS, k, 0.025, rate, conserved=[(0, 20000, 26000), (10, 0, 3000)], novel=[(0, 60000, 75000), (13, 1000, 9000)])
+    _check(ctx, og, dg, obf, dbf, k, w)
+
+
+def test_short_windows_go_through_the_tiers_by_themselves(ctx):
+    "the automatic choice: tiers below w = 64 where the filter accepts enough (c0 / w <= 0.4), the window tiles where it does not"
+    from ntsynt_amd.device import sketch
+    k = 24
+    og, dg, obf, dbf = _case(ctx, 58, [300000, 2000, 90000], k, 0.025, 0.004, n_rel=1)
+    for w, tiered in ((10, True), (33, True), (7, False)):
+        mx = sketch(ctx, dg[0], k, w, dbf)
+        got = mx.to_numpy()
+        assert (ctx.sketch_tiers()[2] >= 2) == tiered, w
+        exp = oracle_flat(O.minimize(og[0], k, w, obf))
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b.astype(a.dtype))
+    # a filter that accepts a few per cent: c0 = 2.4 / p is beyond 0.4 w at w = 33 -- every k-mer is probed inside the window tiles
+    og, dg, obf, dbf = _case(ctx, 59, [300000], k, 0.025, 0.08, n_rel=2)
+    mx = sketch(ctx, dg[0], k, 33, dbf)
+    assert ctx.sketch_tiers()[2] == 0
+    exp = oracle_flat(O.minimize(og[0], k, 33, obf))
+    for a, b in zip(mx.to_numpy(), exp):
+        assert np.array_equal(a, b.astype(a.dtype))
+
+
 @pytest.mark.parametrize("x0,half", [(0.2, False), (0.7, True), (2.4, True), (6.0, False), (8.0, False)])
 def test_tier_schedules_give_the_same_list(ctx, x0, half):
     "many thin tiers, few fat ones, steps of 1.5: the schedule changes the probes, never the result"
