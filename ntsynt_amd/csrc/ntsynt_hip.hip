@@ -3997,7 +3997,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   const bool tiers_forced = ctx->tier_mode == 2 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0;
   // (windows below WIN_FUSE_W = 64, round 6: the same selection down to w = 8 where the filter accepts enough -- c0 / w below tier_small_c)
   const uint32_t tier_min_w = NTS_KNOB("NTS_TIER_MIN_W") ? (uint32_t)atoi(NTS_KNOB("NTS_TIER_MIN_W")) : 8u;
-  const double tier_small_c = NTS_KNOB("NTS_TIER_SMALL_C") ? atof(NTS_KNOB("NTS_TIER_SMALL_C")) : 0.4;
+  const double tier_small_c = NTS_KNOB("NTS_TIER_SMALL_C") ? atof(NTS_KNOB("NTS_TIER_SMALL_C")) : 0.25;
   const bool tiers_small_w = ctx->tier_mode == 0 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0 && w >= tier_min_w && w < 200;
   if ((pruned || tiers_forced || tiers_small_w) && prune_c == 0) {
     if (filter) {
@@ -4046,11 +4046,14 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     // without an accepted k-mer -- ~3.4/p probes per window instead of 11/p.  It takes over where one threshold lists so many
     // k-mers that the upper-halves kernel no longer applies, down to accepted shares where even the first tier is half of all k-mers.
     if (filter && ctx->sketch_mode == 0 && ctx->tier_mode != 1 && k <= FAST_K_MAX && w >= tier_min_w && w <= 4097) {
-      const double x0 = ctx->tier_x0 > 0 ? ctx->tier_x0 : 2.4;
+      // (first tier: 2.4 accepted k-mers per window on average; 1.2 below w = 64, where every tier is a large share of the k-mers and a
+      //  thinner first one saves 8-12 % of the probes: scripts/tiers_x0_sweep.py)
+      const double x0 = ctx->tier_x0 > 0 ? ctx->tier_x0 : (w < WIN_FUSE_W ? 1.2 : 2.4);
       const double c0 = x0 / std::max(p, 1e-6);
       const double switch_c = 54.0 * (double)w / 1000.0; // (beyond it k_hash_select takes over from k_hash_select_hi)
       // (short windows: the other way is k_window_min<true>, every k-mer probed inside the window tile at ~85 ms per 3 Gbp whatever w;
-      //  the tiers take ~91 ms per probe and k-mer, their probes per k-mer are ~1.9 c0 / w: they pay below c0 / w ~ 0.45 -- scripts/tiers_small_w.py)
+      //  the tiers take ~91 ms per probe and k-mer and pay while the filter accepts about five k-mers per window: c0 = 1.2 / p <= 0.25 w --
+      //  scripts/tiers_small_w.py, scripts/tiers_x0_sweep.py)
       const double c0_max = (w < WIN_FUSE_W ? tier_small_c : 0.5) * (double)w;
       // (the accepted k-mers found go through six arrays of 8 bytes sized for 7.5 / w of the k-mers: 108 GB for 3 Gbp at w = 10 --
       //  beyond 120 GB, or when the allocation fails, the window tiles, which keep nothing but the minimizers, take the call)
