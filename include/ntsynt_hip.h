@@ -324,7 +324,8 @@ int nts_sketch(nts_ctx* ctx,
    absent from `filter`; either may be NULL.  With a filter-out filter the call takes the every-k-mer-probed kernels. */
 int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const nts_bf* filter, const nts_bf* filter_out,
                   const nts_interval* mask, uint64_t n_mask, nts_mx** out);
-/* Sketch policy.  mode 0 = auto (pruned when w >= 200 and c = 11 / accepted share stays below w/4, below 0.15 w for w < 512),
+/* Sketch policy.  mode 0 = auto (pruned when w >= 200 -- w >= 90 without a filter -- and c = 11 / accepted share stays below w/4, below
+ * 0.15 w for w < 512; with a filter and 8 <= w < 200 the tiered selection, nts_sketch_tiers, where the filter accepts enough),
  * 1 = dense (probe the filter for every k-mer), 2 = pruned: only k-mers whose hash is <= (c / w) * 2^64 are probed;
  * windows holding no accepted candidate are re-evaluated densely, so the result is identical
  * (ntsynt_amd/csrc/nts_pruned.inc).  prune_c = 0: c is chosen per call from the filter's occupancy
@@ -348,7 +349,9 @@ int nts_sketch_select(nts_ctx* ctx, int impl);
  * quarter of the k-mers or more.  Thresholds tau_0 2^t, t = 0, 1, ..., are then probed one after the other, each only where
  * some window still holds no accepted k-mer: ~3.4 / p probes per window instead of 11 / p (p = accepted share), identical
  * output (the filter-in semantics of indexlr -s, bin/ntsynt_run_pipeline.smk:81-85).  mode 0 = automatic (default), 1 = never,
- * 2 = wherever the kernel applies, -1 = leave as is; x0 = accepted k-mers per window the first tier aims at (0: default 2.4);
+ * 2 = wherever the kernel applies, -1 = leave as is; x0 = accepted k-mers per window the first tier aims at (0: default 2.4, 1.2 for
+ * w < 64).  Automatic also means: short windows (8 <= w < 64, the last refinement round's w = 10, bin/ntSynt:89-91) go this way while the
+ * filter accepts about five k-mers per window -- a fifth to a half of the probes of the every-k-mer pass;
  * half_steps: thresholds grow by 1.5 / 1.33 instead of 2.  Of the last nts_sketch call that went this way: k-mers probed,
  * rounds run summed over the tiles, tiers planned (0: it did not go this way). */
 int nts_sketch_tiers(nts_ctx* ctx, int mode, double x0, int half_steps, uint64_t* last_probes, uint64_t* last_rounds, uint32_t* last_tiers);

@@ -238,17 +238,17 @@ int graph_build_core(nts_ctx* ctx, uint32_t n_asm, uint64_t n, GraphDev* G, List
     ScopedTimer t(ctx, "graph_build");
     // C1 + keep mask
     HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp, tmp_sort, d_h, d_h2, d_idx, d_idx2, n, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(k_g_valid, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_idx2, d_asm, d_keep, n, d_valid);
+    NTS_LAUNCH(k_g_valid, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_idx2, d_asm, d_keep, n, d_valid);
   }
   if (hook) {
     G_WS(d_valid_elem, uint8_t*, "g_valid_elem", n);
-    hipLaunchKernelGGL(k_g_valid_scatter, dim3(nb), dim3(256), 0, ctx->stream, d_idx2, d_valid, n, d_valid_elem);
+    NTS_LAUNCH(k_g_valid_scatter, dim3(nb), dim3(256), 0, ctx->stream, d_idx2, d_valid, n, d_valid_elem);
     if (int rc = (*hook)(ctx, n, d_valid_elem, d_asm, d_rec, d_pos, d_list)) return rc;
   }
   {
     ScopedTimer t(ctx, "graph_build");
     // C2a
-    hipLaunchKernelGGL(k_g_common, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_valid, n, n_asm, d_flag);
+    NTS_LAUNCH(k_g_common, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_valid, n, n_asm, d_flag);
     HIP_TRY(ctx, rocprim::exclusive_scan(d_tmp, tmp_scan, d_flag, d_scan, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
   }
   uint64_t last_flag = 0, last_scan = 0;
@@ -264,10 +264,10 @@ int graph_build_core(nts_ctx* ctx, uint32_t n_asm, uint64_t n, GraphDev* G, List
   HIP_TRY(ctx, hipMemsetAsync(d_evid, 0xFF, n * 4, ctx->stream));
   {
     ScopedTimer t(ctx, "graph_build");
-    hipLaunchKernelGGL(k_g_assign, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_idx2, d_valid, d_flag, d_scan, n, d_asm, d_rec, d_pos, nv,
+    NTS_LAUNCH(k_g_assign, dim3(nb), dim3(256), 0, ctx->stream, d_h2, d_idx2, d_valid, d_flag, d_scan, n, d_asm, d_rec, d_pos, nv,
                        d_evid, d_vhash, d_orec, d_opos);
     // survivors in traversal order
-    hipLaunchKernelGGL(k_g_flag_kept, dim3(nb), dim3(256), 0, ctx->stream, d_evid, n, d_flag);
+    NTS_LAUNCH(k_g_flag_kept, dim3(nb), dim3(256), 0, ctx->stream, d_evid, n, d_flag);
     HIP_TRY(ctx, rocprim::exclusive_scan(d_tmp, tmp_scan, d_flag, d_scan, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
   }
   const uint64_t m = (uint64_t)n_asm * nv; // every common hash occurs once per assembly
@@ -287,10 +287,10 @@ int graph_build_core(nts_ctx* ctx, uint32_t n_asm, uint64_t n, GraphDev* G, List
   const uint32_t mb = (uint32_t)((m + 255) / 256);
   {
     ScopedTimer t(ctx, "graph_build");
-    hipLaunchKernelGGL(k_g_compact, dim3(nb), dim3(256), 0, ctx->stream, d_evid, d_scan, n, d_asm, d_list, d_cvid, d_casm, d_clist);
-    hipLaunchKernelGGL(k_g_pairs, dim3(mb), dim3(256), 0, ctx->stream, d_cvid, d_casm, d_clist, m, d_key, d_seq);
+    NTS_LAUNCH(k_g_compact, dim3(nb), dim3(256), 0, ctx->stream, d_evid, d_scan, n, d_asm, d_list, d_cvid, d_casm, d_clist);
+    NTS_LAUNCH(k_g_pairs, dim3(mb), dim3(256), 0, ctx->stream, d_cvid, d_casm, d_clist, m, d_key, d_seq);
     HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp2, tmp_sort2, d_key, d_key2, d_seq, d_seq2, m, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(k_g_edge_heads, dim3(mb), dim3(256), 0, ctx->stream, d_key2, m, d_eh);
+    NTS_LAUNCH(k_g_edge_heads, dim3(mb), dim3(256), 0, ctx->stream, d_key2, m, d_eh);
     HIP_TRY(ctx, rocprim::exclusive_scan(d_tmp2, tmp_scan2, d_eh, d_es, (uint64_t)0, m, rocprim::plus<uint64_t>(), ctx->stream));
   }
   HIP_TRY(ctx, hipMemcpyAsync(&last_flag, d_eh + (m - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -314,12 +314,12 @@ int graph_build_core(nts_ctx* ctx, uint32_t n_asm, uint64_t n, GraphDev* G, List
     G_WS(d_tmp3, void*, "g_tmp3", std::max<size_t>(tmp_sort3, 16));
     const uint32_t eb = (uint32_t)((ne + 255) / 256);
     ScopedTimer t(ctx, "graph_build");
-    hipLaunchKernelGGL(k_g_edges, dim3(mb), dim3(256), 0, ctx->stream, d_key2, d_seq2, d_eh, d_es, m, d_cvid, d_eu0, d_ev0, d_ew0, d_ef0);
+    NTS_LAUNCH(k_g_edges, dim3(mb), dim3(256), 0, ctx->stream, d_key2, d_seq2, d_eh, d_es, m, d_cvid, d_eu0, d_ev0, d_ew0, d_ef0);
     HIP_TRY(ctx, hipMemsetAsync(d_srank, 0xFF, nv * 8, ctx->stream));
-    hipLaunchKernelGGL(k_g_src_rank, dim3(eb), dim3(256), 0, ctx->stream, d_eu0, d_ef0, ne, d_srank);
-    hipLaunchKernelGGL(k_g_order_keys, dim3(eb), dim3(256), 0, ctx->stream, d_eu0, d_ef0, ne, d_srank, d_key, d_seq);
+    NTS_LAUNCH(k_g_src_rank, dim3(eb), dim3(256), 0, ctx->stream, d_eu0, d_ef0, ne, d_srank);
+    NTS_LAUNCH(k_g_order_keys, dim3(eb), dim3(256), 0, ctx->stream, d_eu0, d_ef0, ne, d_srank, d_key, d_seq);
     HIP_TRY(ctx, rocprim::radix_sort_pairs(d_tmp3, tmp_sort3, d_key, d_key2, d_seq, d_seq2, ne, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(k_g_permute_edges, dim3(eb), dim3(256), 0, ctx->stream, d_seq2, ne, d_eu0, d_ev0, d_ew0, d_ef0, d_eu, d_ev, d_ew, d_ef);
+    NTS_LAUNCH(k_g_permute_edges, dim3(eb), dim3(256), 0, ctx->stream, d_seq2, ne, d_eu0, d_ev0, d_ew0, d_ef0, d_eu, d_ev, d_ew, d_ef);
   }
   HIP_TRY(ctx, hipGetLastError());
   G->v_hash = d_vhash;
@@ -398,7 +398,7 @@ extern "C" int nts_graph_build(nts_ctx* ctx, uint32_t n_asm, const nts_mxlist* l
         HIP_TRY(ctx, hipMemcpyAsync(in.keep + o, lists[a].keep, m, hipMemcpyHostToDevice, ctx->stream));
       else
         HIP_TRY(ctx, hipMemsetAsync(in.keep + o, 1, m, ctx->stream));
-      hipLaunchKernelGGL(k_g_number, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, ctx->stream, in.idx + o, in.asm_id + o, m, o, a);
+      NTS_LAUNCH(k_g_number, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, ctx->stream, in.idx + o, in.asm_id + o, m, o, a);
     }
     o += m;
   }

@@ -565,6 +565,22 @@ struct nts_mx
 
 namespace {
 
+// A launch's work-items are counted in 32 bits per dimension (the dispatch packet's grid size): gridDim.x * blockDim.x beyond 2^32 - 1
+// runs TRUNCATED and reports nothing (seen: 8.9 M window tiles of 512 lanes -- every tile past the 2^23rd dropped, hipGetLastError
+// silent).  Every launch of the library goes through NTS_LAUNCH: one that does not fit is handed an empty block, which HIP refuses, so
+// that the hipGetLastError() that follows every launch sequence (the result mailbox at the latest) ends the call with an error.
+inline std::atomic<uint64_t> g_refused_launches{0};
+inline dim3 nts_checked_block(const dim3& grid, const dim3& block)
+{
+  if ((uint64_t)grid.x * (uint64_t)block.x > 0xFFFFFFFFull) {
+    g_refused_launches.fetch_add(1);
+    return dim3(0, 1, 1);
+  }
+  return block;
+}
+#define NTS_LAUNCH_(kern, grid, block, ...) hipLaunchKernelGGL(kern, grid, nts_checked_block(grid, block), __VA_ARGS__)
+#define NTS_LAUNCH(...) NTS_LAUNCH_(__VA_ARGS__) // (arguments expanded first: E_GRID(n) stands for grid, block, LDS bytes and stream)
+
 #define HIP_TRY(ctx, expr)                                                                          \
   do {                                                                                              \
     hipError_t e_ = (expr);                                                                         \

@@ -568,6 +568,7 @@ struct WinParams
   // that wait for their predecessors' counts hold their LDS and wave slots, and the probes in flight halve: 166 instead of 84 ms.)
   uint64_t* dir_off;  // [n_tiles] first slot of the tile's winners in out_j / out_key (~0: its reservation did not fit)
   uint32_t* dir_cnt;  // [n_tiles]
+  uint32_t tile_base = 0; // first tile of this launch (a launch holds fewer than 2^32 / WIN_THREADS tiles: uncovered ranges by the million)
 };
 constexpr uint32_t N_SEG = 64;
 // Short windows (w < WIN_FUSE_W: the last refinement round's w = 10, -d < 1's defaults bin/ntSynt:89-91, and anything below 64): the
@@ -612,7 +613,8 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t lo = 0, hi = P.n_rec;
-  const uint64_t b = blockIdx.x;
+  const uint32_t blk = blockIdx.x + P.tile_base;
+  const uint64_t b = blk;
   while (hi - lo > 1) {
     const uint32_t mid = lo + ((hi - lo) >> 1);
     if (P.tile_start[mid] <= b)
@@ -861,15 +863,15 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
   const uint32_t n_emit = s_ctl[0];
   if (P.tile_cnt != nullptr) {
     // ---- per-tile mode: rank the tile's winners (distinct indices, a handful) by counting, write them in order ----
-    if (threadIdx.x == 0) P.tile_cnt[blockIdx.x] = n_emit;
+    if (threadIdx.x == 0) P.tile_cnt[blk] = n_emit;
     if (n_emit == 0 || n_emit > P.tile_cap) return;
     const uint64_t jb = P.rec_vstart[rec] + tf;
     for (uint32_t i = threadIdx.x; i < n_emit; i += WIN_THREADS) {
       const uint32_t idx = s_list[i];
       uint32_t rank = 0;
       for (uint32_t x = 0; x < n_emit; ++x) rank += s_list[x] < idx ? 1u : 0u;
-      P.out_j[(uint64_t)blockIdx.x * P.tile_cap + rank] = jb + idx;
-      P.out_key[(uint64_t)blockIdx.x * P.tile_cap + rank] = s_key[pe(idx)];
+      P.out_j[(uint64_t)blk * P.tile_cap + rank] = jb + idx;
+      P.out_key[(uint64_t)blk * P.tile_cap + rank] = s_key[pe(idx)];
     }
     return;
   }
@@ -879,12 +881,12 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_tab + 36); // (the tile's staged bases are not needed any more)
     const uint32_t words = (E + 31u) >> 5;                      // <= 131
     uint32_t* s_pref = s_bits + words;
-    const uint32_t seg = blockIdx.x % N_SEG;
+    const uint32_t seg = blk % N_SEG;
     if (threadIdx.x == 0) {
       unsigned long long base = n_emit ? atomicAdd(&P.seg_count[seg], (unsigned long long)n_emit) : 0ull;
       const bool fits = base + n_emit <= P.seg_cap;
-      P.dir_cnt[blockIdx.x] = n_emit;
-      P.dir_off[blockIdx.x] = fits ? (uint64_t)seg * P.seg_cap + base : ~0ULL;
+      P.dir_cnt[blk] = n_emit;
+      P.dir_off[blk] = fits ? (uint64_t)seg * P.seg_cap + base : ~0ULL;
       if (!fits) base = ~0ull;
       s_ctl[1] = (uint32_t)base;
       s_ctl[2] = (uint32_t)(base >> 32);
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(WIN_THREADS) void k_window_min(WinParams P)
   }
   // ---- flush: one returning atomic per workgroup, on one of N_SEG counters ---------------------------
   if (n_emit == 0) return;
-  const uint32_t seg = blockIdx.x % N_SEG;
+  const uint32_t seg = blk % N_SEG;
   if (threadIdx.x == 0) {
     const unsigned long long base = atomicAdd(&P.seg_count[seg], (unsigned long long)n_emit);
     s_ctl[1] = (uint32_t)base;
@@ -1518,13 +1520,13 @@ int launch_hash(nts_ctx* ctx, const char* name, const nts_genome* g, const Genom
   if (blocks > 0x7FFFFFFFULL) return fail(ctx, NTS_ERANGE, "genome too large for one launch");
   ScopedTimer t(ctx, name, true);
   if (MODE == MODE_KEYS && bf_in && !d_tile_ids && ctx->cur_summary && ctx->cur_tile_any) {
-    hipLaunchKernelGGL(k_hash_keys_sparse, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, T.d_run_pos,
+    NTS_LAUNCH(k_hash_keys_sparse, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, T.d_run_pos,
                        T.d_run_vstart, T.n_runs, rt.n_valid, hp, bf_in->d_words, fm, ctx->cur_summary, ctx->cur_summary_shift, keys,
                        ctx->cur_tile_any);
     HIP_TRY(ctx, hipGetLastError());
     return NTS_OK;
   }
-  hipLaunchKernelGGL(k_hash<MODE>, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, T.d_run_pos,
+  NTS_LAUNCH(k_hash<MODE>, dim3((uint32_t)blocks), dim3(HASH_THREADS), 0, ctx->stream, g->d_code + PAD, T.d_run_pos,
                      T.d_run_vstart, T.n_runs, rt.n_valid, hp, bf_in ? bf_in->d_words : nullptr, bf_out ? bf_out->d_words : nullptr,
                      fm, keys, d_tile_ids, d_tile_span, (MODE == MODE_KEYS && ctx->cur_rep) ? ctx->cur_rep->d_words : nullptr,
                      make_fastmod((MODE == MODE_KEYS && ctx->cur_rep) ? ctx->cur_rep->bytes * 8 : 64));
@@ -1744,7 +1746,7 @@ int nts_genome_finish_impl(nts_ctx* ctx, nts_genome* g) // (also called by the F
   if (!d_cnt) return NTS_ENOMEM;
   hipMemsetAsync(d_cnt, 0, 3 * sizeof(unsigned long long), ctx->stream);
   const uint64_t sblocks = (n + 1 + 4095) / 4096;
-  hipLaunchKernelGGL(k_stretch<0>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, nullptr, nullptr,
+  NTS_LAUNCH(k_stretch<0>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, nullptr, nullptr,
                      nullptr);
   unsigned long long n_st = 0;
   hipMemcpyAsync(&n_st, d_cnt, sizeof(n_st), hipMemcpyDeviceToHost, ctx->stream);
@@ -1758,7 +1760,7 @@ int nts_genome_finish_impl(nts_ctx* ctx, nts_genome* g) // (also called by the F
     uint64_t* d_e2 = (uint64_t*)ws_get(ctx, "gf_e2", n_st * 8);
     if (!d_s || !d_e || !d_s2 || !d_e2) return NTS_ENOMEM;
     size_t tmp_bytes = 0;
-    hipLaunchKernelGGL(k_stretch<1>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, d_s, d_e, d_cnt + 1);
+    NTS_LAUNCH(k_stretch<1>, dim3((uint32_t)sblocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_cnt, d_s, d_e, d_cnt + 1);
     rocprim::radix_sort_keys(nullptr, tmp_bytes, d_s, d_s2, n_st, 0, 64, ctx->stream);
     void* d_tmp = ws_get(ctx, "gf_tmp", std::max<size_t>(tmp_bytes, 16));
     if (!d_tmp) return NTS_ENOMEM;
@@ -1827,7 +1829,7 @@ int nts_genome_upload(nts_ctx* ctx, const uint8_t* seq, uint64_t n, const uint64
     if (hipMemcpyAsync(g->d_code + PAD, seq, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
       return bail(NTS_EHIP, "hipMemcpy genome");
     const uint64_t blocks = (n + 4095) / 4096;
-    hipLaunchKernelGGL(k_encode, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n);
+    NTS_LAUNCH(k_encode, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, g->d_code + PAD, n);
   }
   if (int rc = nts_genome_finish_impl(ctx, g)) {
     dev_free(g->d_code);
@@ -1990,7 +1992,7 @@ int nts_genome_synth(nts_ctx* ctx, uint64_t total_bp, uint32_t n_contigs, uint64
   hipMemsetAsync(g->d_code + PAD + n, CODE_INVALID, PAD, ctx->stream);
   hipMemcpyAsync(g->d_rec_off, g->rec_off.data(), n_contigs * 8, hipMemcpyHostToDevice, ctx->stream);
   const uint32_t thr = (uint32_t)(substitution_rate * 4294967296.0);
-  hipLaunchKernelGGL(k_synth, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, g->d_code + PAD, n, seed_ancestor, seed_genome, thr);
+  NTS_LAUNCH(k_synth, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, g->d_code + PAD, n, seed_ancestor, seed_genome, thr);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
     dev_free(g->d_code);
@@ -2085,7 +2087,7 @@ int nts_genome_synth_plan_ex(nts_ctx* ctx, uint32_t n_rec, const uint64_t* rec_l
   hipMemcpyAsync(g->d_rec_off, g->rec_off.data(), (size_t)n_rec * 8, hipMemcpyHostToDevice, ctx->stream);
   hipMemcpyAsync(d_pieces, pieces, (size_t)n_pieces * sizeof(nts_synth_piece), hipMemcpyHostToDevice, ctx->stream);
   const uint32_t thr = (uint32_t)(substitution_rate * 4294967296.0);
-  hipLaunchKernelGGL(k_synth_plan, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_pieces, n_pieces, seed_ancestor,
+  NTS_LAUNCH(k_synth_plan, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, g->d_code + PAD, n, d_pieces, n_pieces, seed_ancestor,
                      seed_genome, thr, R);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   dev_free(d_pieces);
@@ -2106,7 +2108,7 @@ int nts_genome_download(nts_ctx* ctx, const nts_genome* g, uint64_t offset, uint
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   uint8_t* d = (uint8_t*)ws_get(ctx, "decode", len);
   if (!d) return NTS_ENOMEM;
-  hipLaunchKernelGGL(k_decode, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, ctx->stream, g->d_code + PAD + offset, len, d);
+  NTS_LAUNCH(k_decode, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, ctx->stream, g->d_code + PAD + offset, len, d);
   HIP_TRY(ctx, hipMemcpyAsync(ascii, d, len, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return NTS_OK;
@@ -2211,7 +2213,7 @@ int nts_and_raw(nts_ctx* ctx, void* acc_dev, const void* other_dev, uint64_t byt
   const uint64_t n16 = bytes / 16;
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
   ScopedTimer t(ctx, "bf_and");
-  hipLaunchKernelGGL(k_bf_and, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)acc_dev, (const uint4*)other_dev, n16);
+  NTS_LAUNCH(k_bf_and, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)acc_dev, (const uint4*)other_dev, n16);
   HIP_TRY(ctx, hipGetLastError());
   return NTS_OK;
 }
@@ -2320,7 +2322,7 @@ int nts_bf_insert_and(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, uint32_t k
     const uint64_t n16 = (acc->bytes + 15) / 16;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
     ScopedTimer t(ctx, "bf_and");
-    hipLaunchKernelGGL(k_bf_and, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)acc->d_words, (const uint4*)own->d_words, n16);
+    NTS_LAUNCH(k_bf_and, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)acc->d_words, (const uint4*)own->d_words, n16);
   }
   const uint32_t fb = ctx->last_bf_fallback;
   hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -2380,7 +2382,7 @@ int nts_bf_and(nts_ctx* ctx, nts_bf* acc, const nts_bf* other)
   const uint64_t n16 = (acc->bytes + 15) / 16;
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
   ScopedTimer t(ctx, "bf_and");
-  hipLaunchKernelGGL(k_bf_and, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)acc->d_words, (const uint4*)other->d_words, n16);
+  NTS_LAUNCH(k_bf_and, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)acc->d_words, (const uint4*)other->d_words, n16);
   HIP_TRY(ctx, hipGetLastError());
   return NTS_OK;
 }
@@ -2400,7 +2402,7 @@ int nts_bf_popcount(nts_ctx* ctx, const nts_bf* bf, uint64_t* bits_set)
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 8);
   {
     ScopedTimer t(ctx, "bf_popcount");
-    hipLaunchKernelGGL(k_bf_popcount, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4*)bf->d_words, n16, d);
+    NTS_LAUNCH(k_bf_popcount, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4*)bf->d_words, n16, d);
   }
   unsigned long long h = 0;
   hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
@@ -2424,10 +2426,10 @@ int nts_bench_random_probe(nts_ctx* ctx, const nts_bf* bf, uint64_t n_probes, ui
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  hipLaunchKernelGGL(k_bench_probe, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, bf->d_words, fm, n_probes, (uint64_t)1, d); // warm-up
+  NTS_LAUNCH(k_bench_probe, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, bf->d_words, fm, n_probes, (uint64_t)1, d); // warm-up
   hipEventRecord(a, ctx->stream);
   for (uint32_t r = 0; r < repeats; ++r)
-    hipLaunchKernelGGL(k_bench_probe, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, bf->d_words, fm, n_probes, (uint64_t)(r + 2), d);
+    NTS_LAUNCH(k_bench_probe, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, bf->d_words, fm, n_probes, (uint64_t)(r + 2), d);
   hipEventRecord(b, ctx->stream);
   unsigned long long h = 0;
   hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -2452,7 +2454,7 @@ int nts_mod_indices(nts_ctx* ctx, uint64_t bits, int form, const uint64_t* h, ui
   FastMod fm = make_fastmod(bits);
   if (form >= 0) fm.form = std::min<uint32_t>(fm.form, (uint32_t)form);
   HIP_TRY(ctx, hipMemcpyAsync(d, h, n * 8, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_mod_indices, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65535)), dim3(256), 0, ctx->stream, d, n, fm);
+  NTS_LAUNCH(k_mod_indices, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65535)), dim3(256), 0, ctx->stream, d, n, fm);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(out, d, n * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2478,9 +2480,9 @@ int nts_bench_valu(nts_ctx* ctx, int kind, uint32_t waves_per_simd, uint32_t ite
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, ctx->stream, iters / 8 + 1, d_cyc, d_sink); // warm-up (clocks, code)
+  NTS_LAUNCH(fn, dim3(blocks), dim3(256), 0, ctx->stream, iters / 8 + 1, d_cyc, d_sink); // warm-up (clocks, code)
   hipEventRecord(a, ctx->stream);
-  hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, ctx->stream, iters, d_cyc, d_sink);
+  NTS_LAUNCH(fn, dim3(blocks), dim3(256), 0, ctx->stream, iters, d_cyc, d_sink);
   hipEventRecord(b, ctx->stream);
   std::vector<unsigned long long> cyc(n_waves);
   hipMemcpyAsync(cyc.data(), d_cyc, n_waves * 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -2633,7 +2635,7 @@ int nts_hash_all(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint64_t** h0, u
   rc = launch_hash<MODE_KEYS>(ctx, "hash_only", g, *T, k, nullptr, nullptr, d_keys);
   uint64_t* host = (uint64_t*)malloc(std::max<uint64_t>(rt.n_valid, 1) * 8);
   if (rc == NTS_OK && rt.n_valid) {
-    hipLaunchKernelGGL(k_keys_linear, dim3((uint32_t)((rt.n_valid + 255) / 256)), dim3(256), 0, ctx->stream, d_keys, rt.n_valid, d_lin);
+    NTS_LAUNCH(k_keys_linear, dim3((uint32_t)((rt.n_valid + 255) / 256)), dim3(256), 0, ctx->stream, d_keys, rt.n_valid, d_lin);
     hipMemcpyAsync(host, d_lin, rt.n_valid * 8, hipMemcpyDeviceToHost, ctx->stream);
   }
   hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -2747,10 +2749,18 @@ int launch_window_dense(nts_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_
     P.fm = fuse->fm;
   }
   ScopedTimer t(ctx, tag, fuse != nullptr);
-  if (fuse)
-    hipLaunchKernelGGL(k_window_min<true>, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
-  else
-    hipLaunchKernelGGL(k_window_min<false>, dim3((uint32_t)n_tiles), dim3(WIN_THREADS), lds, ctx->stream, P);
+  // (a launch counts its work-items in 32 bits: tiles by the million -- one per uncovered range of a selection forced to list next to
+  //  nothing -- go out in as many launches as it takes)
+  uint64_t per_launch = 0xFFFFFFFFull / WIN_THREADS;
+  if (NTS_KNOB("NTS_WIN_TILES_PER_LAUNCH")) per_launch = strtoull(NTS_KNOB("NTS_WIN_TILES_PER_LAUNCH"), nullptr, 10);
+  for (uint64_t t0 = 0; t0 < n_tiles; t0 += per_launch) {
+    const uint32_t n_now = (uint32_t)std::min<uint64_t>(per_launch, n_tiles - t0);
+    P.tile_base = (uint32_t)t0;
+    if (fuse)
+      NTS_LAUNCH(k_window_min<true>, dim3(n_now), dim3(WIN_THREADS), lds, ctx->stream, P);
+    else
+      NTS_LAUNCH(k_window_min<false>, dim3(n_now), dim3(WIN_THREADS), lds, ctx->stream, P);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return NTS_OK;
 }
@@ -2830,7 +2840,7 @@ struct Mail
   int launch(nts_ctx* ctx)
   {
     P.seq = ++ctx->mail_seq;
-    hipLaunchKernelGGL(k_mail, dim3(1), dim3(256), 0, ctx->stream, P);
+    NTS_LAUNCH(k_mail, dim3(1), dim3(256), 0, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
     return NTS_OK;
   }
@@ -2963,7 +2973,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     if ((rc = launch_window_dense(ctx, d_keys, d_vs, d_nv, d_ts, n_rec, n_tiles, w, tl, win_tag, d_tiles, n_tile_ids, fuse))) return rc;
     {
       ScopedTimer t(ctx, "merge_lists");
-      hipLaunchKernelGGL(k_gap_collect, dim3(1), dim3(GAP_COLLECT_THREADS), 0, ctx->stream, tl.d_tile_cnt, (uint32_t)n_tiles, tl.d_j, tl.d_key,
+      NTS_LAUNCH(k_gap_collect, dim3(1), dim3(GAP_COLLECT_THREADS), 0, ctx->stream, tl.d_tile_cnt, (uint32_t)n_tiles, tl.d_j, tl.d_key,
                          sparse->count, d_gj, d_gk, d_gctl);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -3007,7 +3017,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
       {
         ScopedTimer t(ctx, "merge_lists");
         if (int rc_s = scan_counts<uint32_t>(ctx, d_dcnt, n_tiles, d_dscan)) return rc_s;
-        hipLaunchKernelGGL(k_cand_compact_slots, dim3((uint32_t)((n_tiles + CCS_TILES - 1) / CCS_TILES)), dim3(256), 0, ctx->stream, od.d_j, od.d_key, d_doff, d_dcnt,
+        NTS_LAUNCH(k_cand_compact_slots, dim3((uint32_t)((n_tiles + CCS_TILES - 1) / CCS_TILES)), dim3(256), 0, ctx->stream, od.d_j, od.d_key, d_doff, d_dcnt,
                            d_dscan, n_tiles, d_oj2, d_ok2, slots, d_ovf);
       }
       HIP_TRY(ctx, hipGetLastError());
@@ -3092,7 +3102,7 @@ int ensure_pack(nts_ctx* ctx, const nts_genome* g)
   HIP_TRY(ctx, dev_malloc((void**)&p, (n_words + 320) * 4));
   {
     ScopedTimer t(ctx, "pack_image");
-    if (n_words) hipLaunchKernelGGL(k_pack2, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, g->d_code + PAD, n_words, p);
+    if (n_words) NTS_LAUNCH(k_pack2, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, g->d_code + PAD, n_words, p);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -3126,7 +3136,7 @@ int bf_make_summary(nts_ctx* ctx, const nts_bf* filter, uint32_t shift)
   const uint64_t n16 = (filter->bytes + 15) / 16;
   {
     ScopedTimer t(ctx, "bf_summary");
-    hipLaunchKernelGGL(k_bf_summary, dim3((uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 16)), dim3(256), 0, ctx->stream,
+    NTS_LAUNCH(k_bf_summary, dim3((uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 16)), dim3(256), 0, ctx->stream,
                        (const uint4*)filter->d_words, n16, shift, filter->d_summary, filter->d_fold, FOLD_WORDS);
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (another context may read the summary from its own stream as soon as the lock is free)
@@ -3157,7 +3167,7 @@ int launch_accept(nts_ctx* ctx, const nts_genome* g, uint32_t k, const AcceptPar
     const uint64_t groups4 = (n_kt + 3) / 4;
     const uint64_t wgs = NTS_KNOB("NTS_ACC4R_WGS") ? (uint64_t)std::max(1, atoi(NTS_KNOB("NTS_ACC4R_WGS"))) : 256ull;
     const dim3 grid4((uint32_t)std::min<uint64_t>(groups4, wgs));
-#define ACC4R_RUN(B, F) hipLaunchKernelGGL((k_hash_accept4r<B, F>), grid4, dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A, g->d_pack, fold, n_kt)
+#define ACC4R_RUN(B, F) NTS_LAUNCH((k_hash_accept4r<B, F>), grid4, dim3(ACC4_THREADS), sizeof(Accept4rLds), ctx->stream, A, g->d_pack, fold, n_kt)
     if (NTS_KNOB("NTS_ACC4R_BLOCK") && atoi(NTS_KNOB("NTS_ACC4R_BLOCK")) == 4)
       ACC4R_RUN(4, -1); // (blocks of four, the modulus form read at run time: the kernel as it was, for comparisons)
     else if (A.fm.form == 2)
@@ -3173,10 +3183,10 @@ int launch_accept(nts_ctx* ctx, const nts_genome* g, uint32_t k, const AcceptPar
                                        (int)sizeof(Accept4Lds)));
       ctx->acc4_lds_set = true;
     }
-    hipLaunchKernelGGL(k_hash_accept4, dim3((uint32_t)((n_kt + 3) / 4)), dim3(ACC4_THREADS), sizeof(Accept4Lds), ctx->stream, A, fold,
+    NTS_LAUNCH(k_hash_accept4, dim3((uint32_t)((n_kt + 3) / 4)), dim3(ACC4_THREADS), sizeof(Accept4Lds), ctx->stream, A, fold,
                        n_kt);
   } else {
-    hipLaunchKernelGGL(k_hash_accept, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, A);
+    NTS_LAUNCH(k_hash_accept, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, A);
   }
   return NTS_OK;
 }
@@ -3266,11 +3276,11 @@ int bf_level_sparse(nts_ctx* ctx, nts_bf* acc, const nts_genome* g, const Genome
   const uint64_t n_sw = (n_gran + 31) / 32;
   acc->popcnt = -1; // from here on the filter changes
   ++acc->version;
-  hipLaunchKernelGGL(k_bf_sparse_clear, dim3((uint32_t)std::min<uint64_t>((n_sw + 3) / 4, 256 * 16)), dim3(256), 0, ctx->stream, (uint4*)acc->d_words, n16,
+  NTS_LAUNCH(k_bf_sparse_clear, dim3((uint32_t)std::min<uint64_t>((n_sw + 3) / 4, 256 * 16)), dim3(256), 0, ctx->stream, (uint4*)acc->d_words, n16,
                      acc->d_summary, n_sw, shift);
   HIP_TRY(ctx, hipMemsetAsync(acc->d_summary, 0, acc->summary_words * 4, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(acc->d_fold, 0, 2 * FOLD_WORDS * 4, ctx->stream));
-  hipLaunchKernelGGL(k_bf_sparse_set, dim3((uint32_t)((n_kt * 32 + 255) / 256)), dim3(256), 0, ctx->stream, acc->d_words, A.fm, d_sk, seg_cap, d_toff, d_tcnt,
+  NTS_LAUNCH(k_bf_sparse_set, dim3((uint32_t)((n_kt * 32 + 255) / 256)), dim3(256), 0, ctx->stream, acc->d_words, A.fm, d_sk, seg_cap, d_toff, d_tcnt,
                      n_kt, acc->d_summary, shift, acc->d_fold, d_ctl + N_SEG);
   HIP_TRY(ctx, hipGetLastError());
   unsigned long long n_set = 0;
@@ -3303,11 +3313,11 @@ void launch_tiers(nts_ctx* ctx, const TierParams& Q, uint64_t n_tiles)
 {
   const dim3 grid((uint32_t)n_tiles), block(TR_THREADS);
   if (Q.fm.form == 2)
-    hipLaunchKernelGGL(k_hash_tiers<2>, grid, block, 0, ctx->stream, Q);
+    NTS_LAUNCH(k_hash_tiers<2>, grid, block, 0, ctx->stream, Q);
   else if (Q.fm.form == 1)
-    hipLaunchKernelGGL(k_hash_tiers<1>, grid, block, 0, ctx->stream, Q);
+    NTS_LAUNCH(k_hash_tiers<1>, grid, block, 0, ctx->stream, Q);
   else
-    hipLaunchKernelGGL(k_hash_tiers<0>, grid, block, 0, ctx->stream, Q);
+    NTS_LAUNCH(k_hash_tiers<0>, grid, block, 0, ctx->stream, Q);
 }
 
 __global__ void k_gap_tiers_ctl(const uint64_t* __restrict__ blk_scan_last, const uint64_t* __restrict__ blk_cnt_last, uint64_t n_sparse,
@@ -3431,14 +3441,14 @@ int run_gap_tiers(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint
   Q.exp_stop = 0;
   {
     ScopedTimer t(ctx, "hash_probe"); // (the group the dense pass over the ranges is timed under)
-    hipLaunchKernelGGL(k_tier_dir, dim3((uint32_t)((n_gt + 255) / 256)), dim3(256), 0, ctx->stream, T.d_run_vstart, T.n_runs, T.d_rec_vstart, g->n_rec,
+    NTS_LAUNCH(k_tier_dir, dim3((uint32_t)((n_gt + 255) / 256)), dim3(256), 0, ctx->stream, T.d_run_vstart, T.n_runs, T.d_rec_vstart, g->n_rec,
                        T.rt.n_valid, halo, core, n_gt, d_tiles, d_dir);
     launch_tiers(ctx, Q, n_gt);
   }
   {
     ScopedTimer t(ctx, "window_min");
     if (int rc_s = scan_counts<uint32_t>(ctx, d_tcnt, n_gt, d_tscan)) return rc_s;
-    hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)((n_gt + CC_TILES - 1) / CC_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, seg_cap, d_toff, d_tcnt, d_tord,
+    NTS_LAUNCH(k_cand_compact, dim3((uint32_t)((n_gt + CC_TILES - 1) / CC_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, seg_cap, d_toff, d_tcnt, d_tord,
                        d_tscan, n_gt, d_pj, d_pk, m_max, d_ctl + N_SEG + 1, false);
     SparseParams S;
     S.pj = d_pj;
@@ -3459,10 +3469,10 @@ int run_gap_tiers(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint
     S.gap_cap = 0;
     S.overflow = d_ctl + N_SEG + 1;
     S.rec_holes = 1;
-    hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, S);
+    NTS_LAUNCH(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, S);
     if (int rc_s = scan_counts<uint64_t>(ctx, d_bcnt, n_blk, d_bscan)) return rc_s;
-    hipLaunchKernelGGL(k_gather_winners, dim3((uint32_t)n_blk), dim3(256), 0, ctx->stream, d_stj, d_stk, d_bcnt, d_bscan, d_gj, d_gk);
-    hipLaunchKernelGGL(k_gap_tiers_ctl, dim3(1), dim3(1), 0, ctx->stream, d_bscan + (n_blk - 1), d_bcnt + (n_blk - 1), sparse.count, d_ctl + N_SEG + 1, d_gctl);
+    NTS_LAUNCH(k_gather_winners, dim3((uint32_t)n_blk), dim3(256), 0, ctx->stream, d_stj, d_stk, d_bcnt, d_bscan, d_gj, d_gk);
+    NTS_LAUNCH(k_gap_tiers_ctl, dim3(1), dim3(1), 0, ctx->stream, d_bscan + (n_blk - 1), d_bcnt + (n_blk - 1), sparse.count, d_ctl + N_SEG + 1, d_gctl);
   }
   HIP_TRY(ctx, hipGetLastError());
   res.d_j = sparse.d_j;
@@ -3604,7 +3614,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       Q.tiles = nullptr;
       Q.excl_on = Q.excl_hi = 0;
       ScopedTimer t(ctx, "hash_tiers", true);
-      hipLaunchKernelGGL(k_tier_dir, dim3((uint32_t)((n_kt + 255) / 256)), dim3(256), 0, ctx->stream, T.d_run_vstart, T.n_runs, T.d_rec_vstart, g->n_rec, V,
+      NTS_LAUNCH(k_tier_dir, dim3((uint32_t)((n_kt + 255) / 256)), dim3(256), 0, ctx->stream, T.d_run_vstart, T.n_runs, T.d_rec_vstart, g->n_rec, V,
                          tp->halo, tp->core, n_kt, (const TierTile*)nullptr, d_dir);
       launch_tiers(ctx, Q, n_kt);
     } else if (accept_all) {
@@ -3673,27 +3683,27 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
         const uint64_t per_wg = (uint64_t)HIW_WAVES * tpw;
         const dim3 grid((uint32_t)((n_kt + per_wg - 1) / per_wg));
         if (filter && hi_per == 2)
-          hipLaunchKernelGGL((k_hash_select_hi<true, 2>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
+          NTS_LAUNCH((k_hash_select_hi<true, 2>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
         else if (filter)
-          hipLaunchKernelGGL((k_hash_select_hi<true, 4>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
+          NTS_LAUNCH((k_hash_select_hi<true, 4>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
         else if (hi_per == 2)
-          hipLaunchKernelGGL((k_hash_select_hi<false, 2>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
+          NTS_LAUNCH((k_hash_select_hi<false, 2>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
         else
-          hipLaunchKernelGGL((k_hash_select_hi<false, 4>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
+          NTS_LAUNCH((k_hash_select_hi<false, 4>), grid, dim3(HIW_THREADS), nch * 4096u, ctx->stream, S, nch, tpw, n_kt);
       }
       else if (64.0 * frac > 2.5)
-        hipLaunchKernelGGL(k_hash_select<16>, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
+        NTS_LAUNCH(k_hash_select<16>, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
       else
-        hipLaunchKernelGGL(k_hash_select<8>, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
+        NTS_LAUNCH(k_hash_select<8>, dim3((uint32_t)n_kt), dim3(HASH_THREADS), 0, ctx->stream, S);
     }
     {
       ScopedTimer t(ctx, "cand_compact");
       if (int rc_s = scan_counts<uint32_t>(ctx, d_tcnt, n_kt, d_tscan)) return rc_s;
       if (sel_hi)
-        hipLaunchKernelGGL(k_cand_compact_slots, dim3((uint32_t)((n_kt + CCS_TILES - 1) / CCS_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, d_toff, d_tcnt, d_tscan, n_kt,
+        NTS_LAUNCH(k_cand_compact_slots, dim3((uint32_t)((n_kt + CCS_TILES - 1) / CCS_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, d_toff, d_tcnt, d_tscan, n_kt,
                            d_pj, d_pk, m_max, d_ctl + N_SEG + 1);
       else
-        hipLaunchKernelGGL(k_cand_compact, dim3((uint32_t)((n_kt + CC_TILES - 1) / CC_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tord, d_tscan, n_kt,
+        NTS_LAUNCH(k_cand_compact, dim3((uint32_t)((n_kt + CC_TILES - 1) / CC_TILES)), dim3(256), 0, ctx->stream, d_sj, d_sk, cseg_cap, d_toff, d_tcnt, d_tord, d_tscan, n_kt,
                            d_pj, d_pk, m_max, d_ctl + N_SEG + 1, false);
     }
     SparseParams Q;
@@ -3718,7 +3728,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
     Q.no_gaps = accept_all ? 1u : 0u; // (the list holds every accepted k-mer that can win: a window without one has no minimizer)
     {
       ScopedTimer t(ctx, "sparse_win");
-      hipLaunchKernelGGL(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
+      NTS_LAUNCH(k_sparse_win, dim3((uint32_t)n_blk), dim3(SPARSE_THREADS), 0, ctx->stream, Q);
       // ordered output without a sort: scan the per-workgroup counts, gather (below; the candidate segments are free again)
       if (int rc_s = scan_counts<uint64_t>(ctx, d_bcnt, n_blk, d_bscan)) return rc_s;
     }
@@ -3742,7 +3752,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
       if (rc_m) return rc_m;
       {
         ScopedTimer t(ctx, "gather_winners");
-        hipLaunchKernelGGL(k_gather_winners, dim3((uint32_t)n_blk), dim3(256), 0, ctx->stream, d_stj, d_stk, d_bcnt, d_bscan, d_sj, d_sk);
+        NTS_LAUNCH(k_gather_winners, dim3((uint32_t)n_blk), dim3(256), 0, ctx->stream, d_stj, d_stk, d_bcnt, d_bscan, d_sj, d_sk);
       }
       HIP_TRY(ctx, hipGetLastError());
       if ((rc_m = mb.wait(ctx))) return rc_m;
@@ -3841,7 +3851,7 @@ int run_pruned(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, uint32_
   PR_WS(d_mk, uint64_t*, "merged_key", total * 8);
   {
     ScopedTimer t(ctx, "merge_lists");
-    hipLaunchKernelGGL(k_merge_lists, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_sj, d_sk, n_sparse, dense.d_j, dense.d_key,
+    NTS_LAUNCH(k_merge_lists, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_sj, d_sk, n_sparse, dense.d_j, dense.d_key,
                        dense.count, d_mj, d_mk);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -3985,7 +3995,10 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   // windows uncovered (they are re-evaluated densely).  The select kernel probes its candidates in batches and keeps
   // only the accepted ones, so c may grow until a quarter of the k-mers are candidates (p down to 48/w); below that
   // the dense kernels take over.
-  bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= 200);
+  // (one threshold from w = 200 with a filter -- below it the tiers -- and from w = 90 without one, where every k-mer below the threshold is a
+  //  candidate at once: 3 Gbp at w = 90 / 100 / 150 / 199: 23 / 12.7 / 8.6 / 7.0 ms against 46 / 45 / 39 / 36 through the key array; scripts/mode_sweep.py)
+  const uint32_t prune_min_w = filter ? 200u : 90u;
+  bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= prune_min_w);
   // a filter-out filter (indexlr -r: experimental in the reference) is served by the every-k-mer-probed kernels only
   if (filter_out) pruned = false;
   uint32_t prune_c = ctx->prune_c;
@@ -4041,7 +4054,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     // 3 x 100 Mbp: c = 35 -> 56 Gbases/s against 34 dense, c = 50 -> 17; at w = 1000, c = 203 still gives 94)
     const double cap = (w >= 512 ? 0.25 : 0.15) * (double)w;
     prune_c = (uint32_t)std::min(want, cap);
-    if ((ctx->sketch_mode == 0 && want > cap) || w < 200) pruned = ctx->sketch_mode == 2;
+    if ((ctx->sketch_mode == 0 && want > cap) || w < prune_min_w) pruned = ctx->sketch_mode == 2;
     // Tiered selection (nts_tiers.inc): thresholds tau_0 2^t instead of one threshold, each probed only where a window is still
     // without an accepted k-mer -- ~3.4/p probes per window instead of 11/p.  It takes over where one threshold lists so many
     // k-mers that the upper-halves kernel no longer applies, down to accepted shares where even the first tier is half of all k-mers.
@@ -4150,10 +4163,10 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
         uint32_t* const d_crun = (uint32_t*)(d_cb + n_chunks);
         uint32_t* const d_crec = d_crun + n_chunks;
         ScopedTimer t(ctx, "finalize");
-        hipLaunchKernelGGL(k_fin_chunks, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, ctx->stream, res.d_j, n_first,
+        NTS_LAUNCH(k_fin_chunks, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, ctx->stream, res.d_j, n_first,
                            res.d_ctl ? res.d_ctl + 1 : nullptr, res.b_j, res.b_j ? res.d_ctl : nullptr, T->d_run_pos, T->d_run_vstart, T->n_runs,
                            g->d_rec_off, g->n_rec, d_cb, d_crun, d_crec);
-        hipLaunchKernelGGL(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, res.d_j, res.d_key, (uint64_t)count,
+        NTS_LAUNCH(k_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, res.d_j, res.d_key, (uint64_t)count,
                            res.d_ctl ? res.d_ctl + 1 : nullptr, res.b_j, res.b_key, res.b_j ? res.d_ctl : nullptr, res.na, T->d_run_pos, T->d_run_vstart, T->n_runs, g->d_rec_off, g->n_rec, k,
                            d_cb, d_crun, d_crec, mx->d_h1, mx->d_rec, mx->d_pos);
       }
