@@ -501,6 +501,7 @@ struct nts_ctx
   const nts_bf* cur_rep = nullptr; // filter-out filter of the running nts_sketch_ex call (indexlr -r), or null
   double dense_seg_per_window = 3.0; // minimizers per w k-mers the every-k-mer path sizes its output segments for; raised by the call that needed more
                                      // (accepted k-mers in clusters: 4 % divergence at w = 48 gives 3.4), so that only that one call runs twice
+  double fused_seg_per_window = 2.5; // the same for the window tiles that hash their own k-mers (per w + 1 k-mers)
   bool elim_needs_full_cap = false; // a call's candidate lists did not fit half the capacity sized for the accepted k-mers (run_pruned)
   int select_impl = 0;  // candidate selection of the pruned sketch: 0 auto, 1 full-width kernel, 2 upper-halves kernel also for assemblies in pieces
   int summary_mode = 0; // 0 auto, 1 never (tests)

@@ -2994,7 +2994,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     // short windows over the whole genome: every tile writes its winners in index order into a segment and leaves (offset, count) in
     // a directory; scan + gather give the ordered list -- no 0xFF fill of the segments, no radix sort of up to half a billion pairs
     // (43 ms at w = 10)
-    uint64_t cap = ((uint64_t)(2.5 * (double)est_kmers / (double)(w + 1)) + 2ull * n_rec) / N_SEG + 65536;
+    uint64_t cap = ((uint64_t)(ctx->fused_seg_per_window * (double)est_kmers / (double)(w + 1)) + 2ull * n_rec) / N_SEG + 65536;
     for (int attempt = 0; attempt < 2; ++attempt) {
       OutSegs od;
       od.seg_cap = cap;
@@ -3039,6 +3039,8 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
       res.count = total;
       if (worst <= cap) return NTS_OK;
       if (attempt == 1) return fail(ctx, NTS_EHIP, "minimizer segments overflowed twice");
+      if (est_kmers >= (1ull << 20)) // (accepted k-mers in clusters -- k = 64 at w = 63: 2.9 per window; the next call starts from what this one needed)
+        ctx->fused_seg_per_window = std::max(ctx->fused_seg_per_window, 1.15 * (double)worst * N_SEG * (double)(w + 1) / (double)est_kmers);
       cap = worst + 1024;
     }
   }
@@ -4008,9 +4010,9 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   // (tiers forced: wherever the kernel applies.  Windows of 64 .. 199 k-mers, where one threshold never paid and every k-mer was probed:
   //  the tiered selection is looked at there too -- a whole 3 Gbp genome at w = 100 against its family's filter: 90 ms the dense way)
   const bool tiers_forced = ctx->tier_mode == 2 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0;
-  // (windows below WIN_FUSE_W = 64, round 6: the same selection down to w = 8 where the filter accepts enough -- c0 / w below tier_small_c)
+  // (windows below WIN_FUSE_W = 64, round 6: the same selection down to w = 8 where its estimated cost stays below tier_small_c of the every-k-mer pass)
   const uint32_t tier_min_w = NTS_KNOB("NTS_TIER_MIN_W") ? (uint32_t)atoi(NTS_KNOB("NTS_TIER_MIN_W")) : 8u;
-  const double tier_small_c = NTS_KNOB("NTS_TIER_SMALL_C") ? atof(NTS_KNOB("NTS_TIER_SMALL_C")) : 0.25;
+  const double tier_small_c = NTS_KNOB("NTS_TIER_SMALL_C") ? atof(NTS_KNOB("NTS_TIER_SMALL_C")) : 0.85;
   const bool tiers_small_w = ctx->tier_mode == 0 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0 && w >= tier_min_w && w < 200;
   if ((pruned || tiers_forced || tiers_small_w) && prune_c == 0) {
     if (filter) {
@@ -4064,14 +4066,20 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
       const double x0 = ctx->tier_x0 > 0 ? ctx->tier_x0 : (w < WIN_FUSE_W ? 1.2 : 2.4);
       const double c0 = x0 / std::max(p, 1e-6);
       const double switch_c = 54.0 * (double)w / 1000.0; // (beyond it k_hash_select takes over from k_hash_select_hi)
-      // (short windows: the other way is k_window_min<true>, every k-mer probed inside the window tile at ~85 ms per 3 Gbp whatever w;
-      //  the tiers take ~91 ms per probe and k-mer and pay while the filter accepts about five k-mers per window: c0 = 1.2 / p <= 0.25 w --
-      //  scripts/tiers_small_w.py, scripts/tiers_x0_sweep.py)
-      const double c0_max = (w < WIN_FUSE_W ? tier_small_c : 0.5) * (double)w;
-      // (the accepted k-mers found go through six arrays of 8 bytes sized for 7.5 / w of the k-mers: 108 GB for 3 Gbp at w = 10 --
-      //  beyond 120 GB, or when the allocation fails, the window tiles, which keep nothing but the minimizers, take the call)
+      // Below w = 200 the other way probes every k-mer (k_window_min<true> under 64: ~85 ms per 3 Gbp at k = 24, 105 at k = 100; the key array
+      // above: 110-120).  The tiers cost ~91 ms per (probe per k-mer) at k = 24 and more with k -- a listed k-mer is hashed from scratch,
+      // ceil(k / 4) table reads: 290 ms at k = 100 -- and where w <= k they probe every k-mer of the stretch a substitution empties.  Probes
+      // per k-mer, fitted to scripts/tiers_small_w.py, tiers_x0_sweep.py and the k = 16 / 100 runs: 0.9 (1 - p) min(1, (k/w)^2) + 2.5 / (p w).
+      bool pays = true;
+      if (w < 200 && ctx->tier_mode != 2) {
+        const double kw = std::min(1.0, (double)k / (double)w);
+        const double est = std::min(1.0, 0.9 * (1.0 - p) * kw * kw + 2.5 / std::max(p * (double)w, 1e-9));
+        const double per_probe = 0.3 + 0.7 * (double)k / 24.0;
+        pays = per_probe * est <= tier_small_c * (1.0 + 0.002 * ((double)k - 24.0));
+      }
+      const double c0_max = 0.5 * (double)w;
       const bool fits = w >= WIN_FUSE_W || 48.0 * 7.5 * (double)rt.n_valid / (double)w <= 120e9;
-      if (c0 <= c0_max && fits && (ctx->tier_mode == 2 || want > switch_c)) {
+      if (c0 <= c0_max && fits && pays && (ctx->tier_mode == 2 || want > switch_c)) {
         tiered = true;
         pruned = false;
         plan.c0 = c0;

@@ -9,7 +9,7 @@ import time
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 os.environ["NTS_TIER_MIN_W"] = "4"
-os.environ.setdefault("NTS_TIER_SMALL_C", "0.5")       # (the product's limit is 0.18: here the tiers run wherever they can)
+os.environ.setdefault("NTS_TIER_SMALL_C", "100")       # (the product stops at an estimated 0.85 of the every-k-mer pass: here the tiers run wherever they can)
 import numpy as np  # noqa: E402
 from ntsynt_amd.device import BloomFilter, Context, Genome, bf_size_bytes, sketch  # noqa: E402
 

@@ -108,7 +108,7 @@ def test_tiers_below_64_equal_the_window_tiles_and_the_oracle(ctx, k, w, rate):
 
 
 def test_short_windows_go_through_the_tiers_by_themselves(ctx):
-    "the automatic choice: tiers below w = 64 where the filter accepts enough (c0 = 1.2 / p <= 0.25 w), the window tiles where it does not"
+    "the automatic choice: tiers below w = 64 where their estimated probes pay (ntsynt_hip.hip: `pays`), the window tiles where they do not"
     from ntsynt_amd.device import sketch
     k = 24
     og, dg, obf, dbf = _case(ctx, 58, [300000, 2000, 90000], k, 0.025, 0.004, n_rel=1)
@@ -119,7 +119,7 @@ def test_short_windows_go_through_the_tiers_by_themselves(ctx):
         exp = oracle_flat(O.minimize(og[0], k, w, obf))
         for a, b in zip(got, exp):
             assert np.array_equal(a, b.astype(a.dtype))
-    # a filter that accepts a few per cent: c0 = 1.2 / p is beyond 0.25 w at w = 33 -- every k-mer is probed inside the window tiles
+    # a filter that accepts a few per cent: nearly every k-mer would be probed anyway -- every k-mer is probed inside the window tiles
     og, dg, obf, dbf = _case(ctx, 59, [300000], k, 0.025, 0.08, n_rel=2)
     mx = sketch(ctx, dg[0], k, 33, dbf)
     assert ctx.sketch_tiers()[2] == 0
