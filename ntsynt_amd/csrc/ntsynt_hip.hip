@@ -4079,7 +4079,10 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
       }
       const double c0_max = 0.5 * (double)w;
       const bool fits = w >= WIN_FUSE_W || 48.0 * 7.5 * (double)rt.n_valid / (double)w <= 120e9;
-      if (c0 <= c0_max && fits && pays && (ctx->tier_mode == 2 || want > switch_c)) {
+      // (an assembly in pieces lists fewer candidates per window -- cp = 8.7 -- but that says nothing about where the tiers overtake the one
+      //  threshold: the comparison is made with the whole-genome figure; 200,000 contigs at w = 250, p = 0.7: tiers 7.4 ms, one threshold 10.4)
+      const double want_whole = std::max(8.0, std::ceil(11.0 / std::max(p, 1e-4)));
+      if (c0 <= c0_max && fits && pays && (ctx->tier_mode == 2 || want_whole > switch_c)) {
         tiered = true;
         pruned = false;
         plan.c0 = c0;
