@@ -48,6 +48,11 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lv 
 find $O/stats_lv -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_c4_levels.csv
 python profiles/summarize.py $O/kernel_stats_c4_levels.csv "rocprofv3 --kernel-trace --stats -- python scripts/c4_levels.py --genomes 9 --modes auto (8 cascade levels, the last the literal way)" > $O/kernel_stats_c4_levels.md
 rm -rf $O/stats_lv
+# short windows (w = 10 / 33 / 63 on one 3 Gbp genome: the product's choice, the window tiles, the key array)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sw -o s -- python scripts/short_windows_bench.py > $O/short_windows.json 2> $O/short_windows.log
+find $O/stats_sw -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_short_windows.csv
+python profiles/summarize.py $O/kernel_stats_short_windows.csv "rocprofv3 --kernel-trace --stats -- python scripts/short_windows_bench.py (one 3 Gbp genome, w = 10 / 33 / 63, with and without the filter, three ways)" > $O/kernel_stats_short_windows.md
+rm -rf $O/stats_sw
 # end to end (FASTA files -> TSV)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_e2e -o s -- python scripts/e2e_synth.py > $O/e2e.json 2> $O/e2e.log
 find $O/stats_e2e -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_e2e.csv
