@@ -2955,7 +2955,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
   const char* win_tag = fuse ? (filter ? "hash_probe" : "hash_only") : "window_min"; // (the fused pass is timed as the hashing pass it replaces)
   OutSegs segs;
   segs.d_count = d_seg;
-  segs.seg_cap = std::max<uint64_t>(256, ((uint64_t)(ctx->dense_seg_per_window * (double)est_kmers / (double)w) + 2 * n_tiles) / N_SEG + 64);
+  segs.seg_cap = std::max<uint64_t>(256, ((uint64_t)(std::min(ctx->dense_seg_per_window, (double)w) * (double)est_kmers / (double)w) + 2 * n_tiles) / N_SEG + 64);
   // ---- few uncovered ranges: no host round trip, no sort -----------------------------------------------------
   // the window kernel writes every tile's winners in order to a slot of its own; one workgroup (k_gap_collect) strings
   // the tiles together, k_finalize merges them into the sparse winners; the count is read at the call's end
@@ -2994,7 +2994,7 @@ int run_dense_sorted(nts_ctx* ctx, const nts_genome* g, const GenomeTables& T, u
     // short windows over the whole genome: every tile writes its winners in index order into a segment and leaves (offset, count) in
     // a directory; scan + gather give the ordered list -- no 0xFF fill of the segments, no radix sort of up to half a billion pairs
     // (43 ms at w = 10)
-    uint64_t cap = ((uint64_t)(ctx->fused_seg_per_window * (double)est_kmers / (double)(w + 1)) + 2ull * n_rec) / N_SEG + 65536;
+    uint64_t cap = ((uint64_t)(std::min(ctx->fused_seg_per_window, (double)(w + 1)) * (double)est_kmers / (double)(w + 1)) + 2ull * n_rec) / N_SEG + 65536;
     for (int attempt = 0; attempt < 2; ++attempt) {
       OutSegs od;
       od.seg_cap = cap;
