@@ -630,6 +630,10 @@ SCENARIOS = [
     # the final table on disk is the initial round's, the pre-merge table the empty one the last round wrote)
     dict(name="s10_round_without_blocks", n=4, bp=50_000, ctg=1, div=0.005, seed=655642, k=24, w=400, w_rounds=[10, 4], indel=150, merge="1w", z=100, micro=8, n_runs=True,
          min_weight=3, keep_stopped=True),
+    # --no-simplify-graph (bin/ntSynt:75-76 -> ntsynt_run.py --simplify-graph absent: S:615-616, S:483-491 skipped) and -m 75 (the share of
+    # increasing / decreasing position differences that orients a contig, ntsynt_run.py -m, synteny_block.py)
+    dict(name="s11_no_simplify_m75", n=3, bp=150_000, ctg=2, div=0.008, seed=111, k=24, w=60, w_rounds=[20, 5], indel=300, merge="3w", z=120, micro=16, n_runs=True,
+         simplify=False, m=75),
     # no common filter (ntSynt --no-common: indexlr without -s, S:181)
     dict(name="s7_no_common_filter", n=2, bp=120_000, ctg=2, div=0.01, seed=107, k=24, w=64, w_rounds=[16, 5], indel=2000, merge=60, z=100, micro=10, n_runs=True, common=False),
 ]
@@ -670,7 +674,7 @@ def run_scenario(ns, sc):
                 tsvs.append(tsv)
             args = types.SimpleNamespace(FILES=list(tsvs), fastas=list(fastas), n=sc.get("min_weight", 0), p=prefix, k=k, w=w, z=sc["z"], filter=None,
                                          common=f"{prefix}.common.bf" if use_common else None, repeat=None, btllib_t=1, w_rounds=list(sc["w_rounds"]),
-                                         bp=sc["indel"], collinear_merge=str(sc["merge"]), simplify_graph=True, m=90, dev=True,
+                                         bp=sc["indel"], collinear_merge=str(sc["merge"]), simplify_graph=sc.get("simplify", True), m=sc.get("m", 90), dev=True,
                                          interarrivals=True, t=1)
             trace, mx = [], MxTable()
             so, se = io.StringIO(), io.StringIO()

@@ -3,7 +3,7 @@
 with the CPU restatement (oracle/synteny_oracle.py run_pipeline) AND the product's host-array engine (ntsynt_amd/synteny.py, graph build
 and re-sketch from the CPU test doubles) on families and parameter sets drawn at random: the run's
 pre-collinear-merge and final TSVs, its interarrival file and its --dev warnings must be identical.  Nothing is stored but the log
-(profiles/r06_refrun_stress.log); the ten committed scenarios are what the test suite replays.  Runs ONLY where /root/reference
+(profiles/r06_refrun_stress.log); the eleven committed scenarios are what the test suite replays.  Runs ONLY where /root/reference
 exists:  PYTHONHASHSEED=0 python tests/golden/refrun_stress.py [--seconds 300] [--seed 1]"""
 import argparse
 import contextlib
@@ -41,7 +41,7 @@ def oracle_outputs(sc, fastas):
                 tables[tsv] = SO.mx_tables_from_tokens(SO.mx_records_from_arrays(genomes[p].names, O.minimize(genomes[p], k, w, bf)))
                 by_tsv[tsv] = genomes[p]
             eng = SO.SyntenyOracle(list(tables), by_tsv, k, w, sc["w_rounds"], sc["indel"], sc["merge"], sc["z"], "ora", bf=bf,
-                                   n=sc.get("min_weight", 0), interarrivals=True)
+                                   n=sc.get("min_weight", 0), interarrivals=True, simplify=sc.get("simplify", True), m=sc.get("m", 90))
             eng.load(tables)
             eng.main()
     finally:
@@ -56,6 +56,8 @@ class _Shim:
         self.meta = dict(sc, indel=sc["indel"], merge=sc["merge"], z=sc["z"])
         self.prefix = "eng"
         self.min_weight = sc.get("min_weight", 0)
+        self.simplify = sc.get("simplify", True)
+        self.m = sc.get("m", 90)
 
 
 def product_outputs(sc, fastas):
@@ -94,6 +96,12 @@ def main():
         if rng.random() < 0.15:
             sc["common"] = False
             seen["no_common"] += 1
+        if rng.random() < 0.2:                                      # ntSynt --no-simplify-graph
+            sc["simplify"] = False
+            seen["no_simplify"] = seen.get("no_simplify", 0) + 1
+        if rng.random() < 0.3:                                      # ntsynt_run.py -m
+            sc["m"] = rng.choice([100, 75, 60, 51])
+            seen["m_not_90"] = seen.get("m_not_90", 0) + 1
         n += 1
         cwd = os.getcwd()
         try:

@@ -53,7 +53,17 @@ class Scenario:
         "the run's parameters under the names oracle.synteny_oracle.run_pipeline / ntsynt_amd.pipeline.run share"
         m = self.meta
         return dict(k=m["k"], w=m["w"], w_rounds=m["w_rounds"], indel=m["indel"], merge=m["merge"], block_size=m["z"],
-                    common=m.get("common", True), prefix=self.prefix)
+                    common=m.get("common", True), prefix=self.prefix, simplify=self.simplify)
+
+    @property
+    def simplify(self):
+        "False: the run was made without --simplify-graph (ntsynt_run.py), i.e. ntSynt --no-simplify-graph"
+        return self.meta.get("simplify", True)
+
+    @property
+    def m(self):
+        "ntsynt_run.py -m: per cent of position differences that must agree to orient a contig [90]"
+        return self.meta.get("m", 90)
 
     @property
     def min_weight(self):

@@ -41,12 +41,12 @@ def test_pipeline_writes_the_reference_runs_bytes(ctx, name, engine, in_tmp_cwd)
         # the reference's run ended in an IndexError at S:437 (a round without blocks): so does this one, and like a failed Snakemake rule
         # it leaves no block table behind (the tables up to that point are compared in the lockstep test below)
         with contextlib.redirect_stderr(err), pytest.raises(IndexError, match="ntsynt_synteny.py:437"):
-            pipeline.run(fastas, log=lambda *a: None, ctx=ctx, engine=engine, n=sc.min_weight, dev=True, interarrivals=True, **sc.kwargs())
+            pipeline.run(fastas, log=lambda *a: None, ctx=ctx, engine=engine, n=sc.min_weight, m=sc.m, dev=True, interarrivals=True, **sc.kwargs())
         assert not os.path.exists(f"{sc.prefix}.synteny_blocks.tsv") and not os.path.exists(f"{sc.prefix}.pre-collinear-merge.synteny_blocks.tsv")
         _same_minimizer_files(sc)
         return
     with contextlib.redirect_stderr(err):
-        eng = pipeline.run(fastas, log=lambda *a: None, ctx=ctx, engine=engine, n=sc.min_weight, dev=True, interarrivals=True, **sc.kwargs())
+        eng = pipeline.run(fastas, log=lambda *a: None, ctx=ctx, engine=engine, n=sc.min_weight, m=sc.m, dev=True, interarrivals=True, **sc.kwargs())
     assert type(eng).__name__ == ("DeviceSyntenyEngine" if engine == "device" else "SyntenyEngine")
     out = eng.outputs
     assert out[f"{sc.prefix}.pre-collinear-merge.synteny_blocks.tsv"] == sc.expected("pre-collinear-merge.synteny_blocks.tsv")
@@ -105,8 +105,9 @@ def test_device_engine_in_lockstep_with_the_reference_run(ctx, name, in_tmp_cwd)
         os.chdir("h")
         host = SyntenyEngine(tsvs, names, k, w, rounds, m["indel"], m["merge"], m["z"], sc.prefix,
                              lambda ls, kp, li: build_graph_device(ctx, ls, kp, li), sketch_np, walk_paths, degree_fn=edge_degrees,
-                             n=sc.min_weight, dev=True, interarrivals=True)
-        dev = DeviceSyntenyEngine(ctx, tsvs, names, k, w, rounds, m["indel"], m["merge"], m["z"], sc.prefix, sketch_dev, n=sc.min_weight)
+                             n=sc.min_weight, dev=True, interarrivals=True, simplify=sc.simplify, m=sc.m)
+        dev = DeviceSyntenyEngine(ctx, tsvs, names, k, w, rounds, m["indel"], m["merge"], m["z"], sc.prefix, sketch_dev, n=sc.min_weight,
+                                  simplify=sc.simplify, m=sc.m)
         initial = [sketch_np(i, None, w) for i in range(n)]
         st = {"round": -1, "db": None, "hb": None, "prev_w": w}
 

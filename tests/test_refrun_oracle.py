@@ -214,7 +214,7 @@ def _run_traced(sc, tmp):
         tables[tsv] = SO.read_minimizers_tsv(tsv)
         by_tsv[tsv] = genomes[p]
     eng = TracedOracle(list(tables), by_tsv, k, w, m["w_rounds"], m["indel"], m["merge"], m["z"], sc.prefix, bf=bf, n=sc.min_weight,
-                       interarrivals=True).attach(sc)
+                       interarrivals=True, simplify=sc.simplify, m=sc.m).attach(sc)
     # the instance's filter_lists is reached through the class (a staticmethod): route it through the checked version
     eng.filter_lists = eng._filter_lists_checked
     eng.load(tables)

@@ -48,7 +48,7 @@ def host_engine(sc, fastas, native=True):
 
     eng = SyntenyEngine(tsvs, [g.names for g in genomes], k, w, m["w_rounds"], m["indel"], m["merge"], m["z"], sc.prefix,
                         build_graph_numpy, sketch_fn, walk_paths, degree_fn=edge_degrees if native else None, n=sc.min_weight,
-                        dev=True, interarrivals=True)
+                        dev=True, interarrivals=True, simplify=getattr(sc, "simplify", True), m=getattr(sc, "m", 90))
     return eng, initial
 
 
