@@ -742,7 +742,7 @@ def divergence_defaults(d):
 
 def run_pipeline(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=10000,
                  merge=10000, block_size=500, common=True, simplify=True, threads=1,
-                 write_mx_tsv=True, log=None, bf_rounding="up", interarrivals=False, repeat=False, n=0):
+                 write_mx_tsv=True, log=None, bf_rounding="up", interarrivals=False, repeat=False, n=0, m=90):
     """FASTA paths -> {output file name: text}; files are written into the CWD like the reference.
     Stage order: make_common_bf (smk:55-62) -> indexlr per genome (smk:74-85) -> ntsynt_run.py
     (smk:87-103)."""
@@ -766,7 +766,7 @@ def run_pipeline(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10
             tables[tsv] = mx_tables_from_tokens(mx_records_from_arrays(genomes[p].names, mins))
         by_tsv[tsv] = genomes[p]
     eng = SyntenyOracle(list(tables), by_tsv, k, w, w_rounds, indel, merge, block_size, prefix,
-                        bf=bf, simplify=simplify, threads=threads, log=log, interarrivals=interarrivals, n=n)
+                        bf=bf, simplify=simplify, threads=threads, log=log, interarrivals=interarrivals, n=n, m=m)
     eng.load(tables)
     eng.main()
     eng.bf = bf

@@ -50,6 +50,9 @@ def main(argv=None):
         # -n (ntsynt_run.py:17): edges fewer than all assemblies support stay
         if n_g >= 3 and rng.random() < 0.3:
             kw["n"] = int(rng.integers(2, n_g))
+        # -m (ntsynt_run.py): the share of agreeing position differences that orients a contig
+        if rng.random() < 0.25:
+            kw["m"] = int(rng.choice([100, 75, 60, 51]))
         # the hidden switches of the reference's CLI and the Snakefile's experimental repeat filter, now and then
         kw.update(common=bool(rng.random() >= 0.12), simplify=bool(rng.random() >= 0.2), repeat=bool(rng.random() < 0.1))
         tmp = tempfile.mkdtemp(prefix="nts_stress_")
