@@ -324,8 +324,8 @@ int nts_sketch(nts_ctx* ctx,
    absent from `filter`; either may be NULL.  With a filter-out filter the call takes the every-k-mer-probed kernels. */
 int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint32_t w, const nts_bf* filter, const nts_bf* filter_out,
                   const nts_interval* mask, uint64_t n_mask, nts_mx** out);
-/* Sketch policy.  mode 0 = auto (pruned when w >= 200 -- w >= 90 without a filter -- and c = 11 / accepted share stays below w/4, below
- * 0.15 w for w < 512; with a filter and 8 <= w < 200 the tiered selection, nts_sketch_tiers, where the filter accepts enough),
+/* Sketch policy.  mode 0 = auto (pruned when w >= 200 and c = 11 / accepted share stays below w/4, below 0.15 w for w < 512; for
+ * 8 <= w < 200 the tiered selection, nts_sketch_tiers, where its estimated probes pay -- always so without a filter),
  * 1 = dense (probe the filter for every k-mer), 2 = pruned: only k-mers whose hash is <= (c / w) * 2^64 are probed;
  * windows holding no accepted candidate are re-evaluated densely, so the result is identical
  * (ntsynt_amd/csrc/nts_pruned.inc).  prune_c = 0: c is chosen per call from the filter's occupancy

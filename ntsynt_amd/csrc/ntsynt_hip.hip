@@ -3997,9 +3997,10 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   // windows uncovered (they are re-evaluated densely).  The select kernel probes its candidates in batches and keeps
   // only the accepted ones, so c may grow until a quarter of the k-mers are candidates (p down to 48/w); below that
   // the dense kernels take over.
-  // (one threshold from w = 200 with a filter -- below it the tiers -- and from w = 90 without one, where every k-mer below the threshold is a
-  //  candidate at once: 3 Gbp at w = 90 / 100 / 150 / 199: 23 / 12.7 / 8.6 / 7.0 ms against 46 / 45 / 39 / 36 through the key array; scripts/mode_sweep.py)
-  const uint32_t prune_min_w = filter ? 200u : 90u;
+  // (one threshold from w = 200; below it the tiers, with or without a filter -- without one, ntSynt --no-common, every listed k-mer is accepted and
+  //  the rounds only decide which k-mers are hashed in full: 3 Gbp at w = 10 / 33 / 63 / 90 / 150 / 200: 35 / 14 / 10 / 8 / 6.5 / 6.1 ms, against 64 / 57 /
+  //  49 ms through the window tiles and 23 / 8.5 / 7.0 with one threshold; scripts/mode_sweep.py)
+  const uint32_t prune_min_w = 200u;
   bool pruned = ctx->sketch_mode == 2 || (ctx->sketch_mode == 0 && w >= prune_min_w);
   // a filter-out filter (indexlr -r: experimental in the reference) is served by the every-k-mer-probed kernels only
   if (filter_out) pruned = false;
@@ -4009,11 +4010,13 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
   TierPlan plan;
   // (tiers forced: wherever the kernel applies.  Windows of 64 .. 199 k-mers, where one threshold never paid and every k-mer was probed:
   //  the tiered selection is looked at there too -- a whole 3 Gbp genome at w = 100 against its family's filter: 90 ms the dense way)
-  const bool tiers_forced = ctx->tier_mode == 2 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0;
+  const bool tiers_forced = ctx->tier_mode == 2 && ctx->sketch_mode == 0 && !filter_out && prune_c == 0;
   // (windows below WIN_FUSE_W = 64, round 6: the same selection down to w = 8 where its estimated cost stays below tier_small_c of the every-k-mer pass)
   const uint32_t tier_min_w = NTS_KNOB("NTS_TIER_MIN_W") ? (uint32_t)atoi(NTS_KNOB("NTS_TIER_MIN_W")) : 8u;
   const double tier_small_c = NTS_KNOB("NTS_TIER_SMALL_C") ? atof(NTS_KNOB("NTS_TIER_SMALL_C")) : 0.85;
-  const bool tiers_small_w = ctx->tier_mode == 0 && ctx->sketch_mode == 0 && filter && !filter_out && prune_c == 0 && w >= tier_min_w && w < 200;
+  // (without a filter -- ntSynt --no-common -- below the window where one threshold takes over: every listed k-mer is accepted, the tiers only
+  //  decide which k-mers are hashed in full at all)
+  const bool tiers_small_w = ctx->tier_mode == 0 && ctx->sketch_mode == 0 && !filter_out && prune_c == 0 && w >= tier_min_w && w < 200;
   if ((pruned || tiers_forced || tiers_small_w) && prune_c == 0) {
     if (filter) {
       uint64_t pc = 0;
@@ -4060,7 +4063,7 @@ extern "C" int nts_sketch_ex(nts_ctx* ctx, const nts_genome* g, uint32_t k, uint
     // Tiered selection (nts_tiers.inc): thresholds tau_0 2^t instead of one threshold, each probed only where a window is still
     // without an accepted k-mer -- ~3.4/p probes per window instead of 11/p.  It takes over where one threshold lists so many
     // k-mers that the upper-halves kernel no longer applies, down to accepted shares where even the first tier is half of all k-mers.
-    if (filter && ctx->sketch_mode == 0 && ctx->tier_mode != 1 && k <= FAST_K_MAX && w >= tier_min_w && w <= 4097) {
+    if (!filter_out && ctx->sketch_mode == 0 && ctx->tier_mode != 1 && k <= FAST_K_MAX && w >= tier_min_w && w <= 4097) {
       // (first tier: 2.4 accepted k-mers per window on average; 1.2 below w = 64, where every tier is a large share of the k-mers and a
       //  thinner first one saves 8-12 % of the probes: scripts/tiers_x0_sweep.py)
       const double x0 = ctx->tier_x0 > 0 ? ctx->tier_x0 : (w < WIN_FUSE_W ? 1.2 : 2.4);

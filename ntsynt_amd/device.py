@@ -73,7 +73,7 @@ class Context:
         return ms.value, n.value
 
     def sketch_mode(self, mode="auto", prune_c=0):
-        """'auto' (pruned when w >= 200, or w >= 90 without a filter; tiers below that where the filter accepts enough), 'dense' (probe the filter for every k-mer) or 'pruned'
+        """'auto' (pruned when w >= 200; tiers below that where they pay), 'dense' (probe the filter for every k-mer) or 'pruned'
         (probe only k-mers whose hash is <= prune_c/w of the hash range; identical output)."""
         code = {"auto": 0, "dense": 1, "pruned": 2}[mode]
         self.check(self.lib.nts_sketch_mode(self.h, code, int(prune_c)), "nts_sketch_mode")

@@ -24,8 +24,6 @@ for filt, tag in ((None, "no filter"), (bf, "filter")):
         row = {}
         counts = set()
         for label, mode, tiers in (("auto", "auto", "auto"), ("pruned", "pruned", "never"), ("dense", "dense", "never"), ("tiers", "auto", "always")):
-            if label == "tiers" and filt is None:
-                continue
             ctx.sketch_mode(mode)
             ctx.sketch_tiers(tiers)
             try:

@@ -128,6 +128,25 @@ def test_short_windows_go_through_the_tiers_by_themselves(ctx):
         assert np.array_equal(a, b.astype(a.dtype))
 
 
+@pytest.mark.parametrize("k,w", [(24, 10), (24, 33), (24, 63), (24, 70), (16, 8), (64, 25)])
+def test_short_windows_without_a_filter_go_through_the_tiers(ctx, k, w):
+    """ntSynt --no-common (indexlr without -s, bin/ntsynt_run_pipeline.smk:81-85) below the window where one threshold takes over: every listed
+    k-mer is accepted, the rounds decide which k-mers are hashed in full at all.  Against the window tiles and the oracle."""
+    from ntsynt_amd.device import sketch
+    rng = np.random.default_rng(300 + k + w)
+    seqs = random_records(rng, LENGTHS, n_frac=0.002)
+    names = [f"r{i}" for i in range(len(seqs))]
+    o, d = to_oracle(names, seqs), to_device(ctx, names, seqs)
+    got = sketch(ctx, d, k, w, None).to_numpy()
+    assert ctx.sketch_tiers()[2] >= 2, "the call did not go through k_hash_tiers"
+    ctx.sketch_mode("dense")
+    dense = sketch(ctx, d, k, w, None).to_numpy()
+    ctx.sketch_mode("auto")
+    exp = oracle_flat(O.minimize(o, k, w, None))
+    for a, b, c in zip(got, dense, exp):
+        assert np.array_equal(a, b) and np.array_equal(a, c.astype(a.dtype))
+
+
 @pytest.mark.parametrize("x0,half", [(0.2, False), (0.7, True), (2.4, True), (6.0, False), (8.0, False)])
 def test_tier_schedules_give_the_same_list(ctx, x0, half):
     "many thin tiers, few fat ones, steps of 1.5: the schedule changes the probes, never the result"
