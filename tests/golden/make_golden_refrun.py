@@ -342,9 +342,9 @@ STATE = {"bf": {}}          # common.bf path -> bit array (what `indexlr -s <pat
 
 
 def _run_indexlr(fasta, k, w, t, s=None, r=None):
-    assert r is None
+    "ntjoin_utils.run_indexlr: `indexlr --long --pos --seq -k k -w w [-s <filter-in>] [-r <filter-out>]` into <fasta>.k<k>.w<w>.tsv"
     g = O.read_fasta(fasta)
-    mins = O.minimize(g, k, w, STATE["bf"][s] if s else None)
+    mins = O.minimize(g, k, w, STATE["bf"][s] if s else None, repeat=STATE["bf"][r] if r else None)
     out = f"{fasta}.k{k}.w{w}.tsv"
     O.write_indexlr_tsv(out, g, mins, k)
     return out
@@ -385,6 +385,7 @@ def install():
     mods["intervaltree"].Interval, mods["intervaltree"].IntervalTree = Interval, IntervalTree
     mods["ncls"].NCLS = NCLS
     mods["pybedtools"].BedTool = BedTool
+    mods["btllib"].KmerBloomFilter = lambda path: STATE["bf"][path]      # (S:606: what ntJoin's read_minimizers asks `contains` of; here the bits)
     u = mods["ntjoin_utils"]
     u.Minimizer, u.Bed = Minimizer, Bed
     u.read_minimizers = SO.read_minimizers_tsv
@@ -634,6 +635,13 @@ SCENARIOS = [
     # increasing / decreasing position differences that orients a contig, ntsynt_run.py -m, synteny_block.py)
     dict(name="s11_no_simplify_m75", n=3, bp=150_000, ctg=2, div=0.008, seed=111, k=24, w=60, w_rounds=[20, 5], indel=300, merge="3w", z=120, micro=16, n_runs=True,
          simplify=False, m=75),
+    # stage 3's experimental repeat filter (ntsynt_run.py --filter / --repeat; S:172-185, S:601-607): `Indexlr` = the refinement rounds' indexlr
+    # runs get -r <repeat filter> next to -s <common>; `Filter` = ntJoin's read_minimizers(file, repeat_bf) leaves out the minimizers whose k-mer
+    # the filter holds, for the initial files and every round's lists
+    dict(name="s12_filter_indexlr", n=3, bp=180_000, ctg=2, div=0.006, seed=112, k=24, w=60, w_rounds=[20, 6], indel=400, merge="3w", z=120, micro=10, n_runs=False,
+         filter="Indexlr"),
+    dict(name="s13_filter_filter", n=3, bp=180_000, ctg=2, div=0.006, seed=113, k=24, w=60, w_rounds=[20, 6], indel=400, merge="3w", z=120, micro=10, n_runs=False,
+         filter="Filter"),
     # no common filter (ntSynt --no-common: indexlr without -s, S:181)
     dict(name="s7_no_common_filter", n=2, bp=120_000, ctg=2, div=0.01, seed=107, k=24, w=64, w_rounds=[16, 5], indel=2000, merge=60, z=100, micro=10, n_runs=True, common=False),
 ]
@@ -662,18 +670,35 @@ def run_scenario(ns, sc):
             fastas = [os.path.basename(p) for p in fastas]            # the reference works in the CWD
             k, w = sc["k"], sc["w"]
             prefix = "ref"
+            if sc.get("filter"):
+                # something for a repeat filter to hold: in every genome a stretch of the first record once more further down
+                for p in fastas:
+                    g0 = O.read_fasta(p)
+                    recs = [bytes(g0.record(i)) for i in range(len(g0.names))]
+                    r0 = recs[0]
+                    a, b, at = len(r0) // 10, len(r0) // 10 + max(2000, len(r0) // 8), len(r0) // 2
+                    recs[0] = r0[:at] + r0[a:b] + r0[at:]
+                    with open(p, "wb") as fh:
+                        for nm, rec in zip(g0.names, recs):
+                            fh.write(b">" + nm.encode() + b"\n" + rec + b"\n")
             genomes = {p: O.read_fasta(p) for p in fastas}
             use_common = sc.get("common", True)
             bf = O.common_bf(genomes, k, 0.025) if use_common else None
             STATE["bf"] = {f"{prefix}.common.bf": bf}
+            rep = None
+            if sc.get("filter"):
+                # the repeat filter of rule make_repeat_bf (smk:65-72; restated: oracle/nts_oracle.py repeat_bf), sized like the common filter
+                rep_bytes = int(bf.size) if use_common else O.bf_ctor_bytes(O.bf_approx_bytes(genomes[sorted(fastas)[0]].total_bp, 0.025))
+                rep = O.repeat_bf([genomes[p] for p in fastas], k, rep_bytes)
+                STATE["bf"][f"{prefix}.repeat.bf"] = rep
             tsvs = []
             for p in fastas:
                 write_fai(p)
                 tsv = f"{p}.k{k}.w{w}.tsv"
                 O.write_indexlr_tsv(tsv, genomes[p], O.minimize(genomes[p], k, w, bf), k)
                 tsvs.append(tsv)
-            args = types.SimpleNamespace(FILES=list(tsvs), fastas=list(fastas), n=sc.get("min_weight", 0), p=prefix, k=k, w=w, z=sc["z"], filter=None,
-                                         common=f"{prefix}.common.bf" if use_common else None, repeat=None, btllib_t=1, w_rounds=list(sc["w_rounds"]),
+            args = types.SimpleNamespace(FILES=list(tsvs), fastas=list(fastas), n=sc.get("min_weight", 0), p=prefix, k=k, w=w, z=sc["z"], filter=sc.get("filter"),
+                                         common=f"{prefix}.common.bf" if use_common else None, repeat=f"{prefix}.repeat.bf" if rep is not None else None, btllib_t=1, w_rounds=list(sc["w_rounds"]),
                                          bp=sc["indel"], collinear_merge=str(sc["merge"]), simplify_graph=sc.get("simplify", True), m=sc.get("m", 90), dev=True,
                                          interarrivals=True, t=1)
             trace, mx = [], MxTable()
@@ -709,6 +734,8 @@ def run_scenario(ns, sc):
             meta.update(fastas=fastas, prefix=prefix, warnings=warnings, stopped=stopped, n_not_oriented=len(stdout_not_oriented),
                         bf_bytes=int(bf.size) if use_common else 0, bf_popcount=int(O.bf_popcount(bf)) if use_common else 0,
                         tsv_sha1={t: hashlib.sha1(open(t, "rb").read()).hexdigest() for t in tsvs})
+            if rep is not None:
+                meta.update(repeat_bytes=int(rep.size), repeat_popcount=int(O.bf_popcount(rep)))
             with open(os.path.join(out_dir, "meta.json"), "w") as fh:
                 json.dump(meta, fh, indent=1)
             with gzip.GzipFile(os.path.join(out_dir, "trace.json.gz"), "wb", mtime=0) as fh:

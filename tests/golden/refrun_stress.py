@@ -3,7 +3,7 @@
 with the CPU restatement (oracle/synteny_oracle.py run_pipeline) AND the product's host-array engine (ntsynt_amd/synteny.py, graph build
 and re-sketch from the CPU test doubles) on families and parameter sets drawn at random: the run's
 pre-collinear-merge and final TSVs, its interarrival file and its --dev warnings must be identical.  Nothing is stored but the log
-(profiles/r06_refrun_stress.log); the eleven committed scenarios are what the test suite replays.  Runs ONLY where /root/reference
+(profiles/r06_refrun_stress.log); the thirteen committed scenarios are what the test suite replays.  Runs ONLY where /root/reference
 exists:  PYTHONHASHSEED=0 python tests/golden/refrun_stress.py [--seconds 300] [--seed 1]"""
 import argparse
 import contextlib

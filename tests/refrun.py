@@ -61,6 +61,18 @@ class Scenario:
         return self.meta.get("simplify", True)
 
     @property
+    def filter_mode(self):
+        "ntsynt_run.py --filter: None, 'Indexlr' (refinement sketches with -r <repeat filter>) or 'Filter' (lists read without the k-mers it holds)"
+        return self.meta.get("filter")
+
+    def repeat_filter(self, genomes):
+        "the run's repeat filter, built again (oracle.nts_oracle.repeat_bf over the genomes in argument order) and checked against the record"
+        from oracle import nts_oracle as O
+        rep = O.repeat_bf(genomes, self.meta["k"], self.meta["repeat_bytes"])
+        assert int(O.bf_popcount(rep)) == self.meta["repeat_popcount"]
+        return rep
+
+    @property
     def m(self):
         "ntsynt_run.py -m: per cent of position differences that must agree to orient a contig [90]"
         return self.meta.get("m", 90)

@@ -37,6 +37,35 @@ def test_pipeline_writes_the_reference_runs_bytes(ctx, name, engine, in_tmp_cwd)
     sc = Scenario(name)
     fastas = sc.unpack(str(in_tmp_cwd))
     err = io.StringIO()
+    if sc.filter_mode:
+        # stage 3 on its own, on the reference's command line (bin/ntsynt_run.py ... --filter <mode> --repeat <bf> --common <bf>): minimizer files,
+        # common filter and repeat filter are the run's inputs -- written here by the CPU restatement, which the CPU suite holds against the same
+        # recorded run (tests/test_refrun_oracle.py)
+        from ntsynt_amd import stage_cli
+        from ntsynt_amd.pipeline import write_bf
+        from oracle import nts_oracle as O
+        m = sc.meta
+        k, w = m["k"], m["w"]
+        genomes = {p: O.read_fasta(p) for p in fastas}
+        common = O.common_bf(genomes, k, 0.025)
+        write_bf(f"{sc.prefix}.common.bf", common, k)
+        write_bf(f"{sc.prefix}.repeat.bf", sc.repeat_filter([genomes[p] for p in fastas]), k)
+        tsvs = []
+        for p in fastas:
+            tsvs.append(f"{os.path.basename(p)}.k{k}.w{w}.tsv")
+            O.write_indexlr_tsv(tsvs[-1], genomes[p], O.minimize(genomes[p], k, w, common), k)
+        argv = tsvs + ["-k", str(k), "-w", str(w), "-p", sc.prefix, "--w-rounds"] + [str(x) for x in m["w_rounds"]] + \
+            ["--bp", str(m["indel"]), "--collinear-merge", str(m["merge"]), "-z", str(m["z"]), "--common", f"{sc.prefix}.common.bf", "--simplify-graph",
+             "--filter", sc.filter_mode, "--repeat", f"{sc.prefix}.repeat.bf", "--dev", "--fastas"] + fastas
+        if engine == "host":
+            pytest.skip("the stage executable runs the device engine (the host-array engine meets these runs in tests/test_refrun_product.py)")
+        with contextlib.redirect_stderr(err), contextlib.redirect_stdout(io.StringIO()):
+            assert stage_cli.run(argv) == 0
+        for suffix in ("pre-collinear-merge.synteny_blocks.tsv", "synteny_blocks.tsv"):
+            with open(f"{sc.prefix}.{suffix}") as fh:
+                assert fh.read() == sc.expected(suffix), suffix
+        assert [ln for ln in err.getvalue().splitlines() if ln.startswith("WARNING")] == sc.meta["warnings"]
+        return
     if sc.stopped:
         # the reference's run ended in an IndexError at S:437 (a round without blocks): so does this one, and like a failed Snakemake rule
         # it leaves no block table behind (the tables up to that point are compared in the lockstep test below)
@@ -90,14 +119,30 @@ def test_device_engine_in_lockstep_with_the_reference_run(ctx, name, in_tmp_cwd)
     tsvs = [f"{os.path.basename(p)}.k{k}.w{w}.tsv" for p in paths]
     names = [r.names for r in recs]
 
+    # stage 3's repeat filter as ntsynt_amd.pipeline hands it on: filter-out of the refinement sketches (Indexlr), or every list screened (Filter)
+    rep = None
+    if sc.filter_mode:
+        from oracle import nts_oracle as O
+        bits = sc.repeat_filter([O.read_fasta(p) for p in paths])
+        rep = BloomFilter(ctx, bits.size, k)
+        rep.from_numpy(bits)
+
+    def one(i, masks, new_w, refine):
+        mx = sketch(ctx, genomes[i], k, new_w, bf, masks, repeat=rep if (refine and sc.filter_mode == "Indexlr") else None)
+        if sc.filter_mode == "Filter":
+            kept = mx.screened(genomes[i], k, rep)
+            mx.free()
+            mx = kept
+        return mx
+
     def sketch_np(i, masks, new_w):
-        mx = sketch(ctx, genomes[i], k, new_w, bf, masks)
+        mx = one(i, masks, new_w, masks is not None)
         out = mx.to_numpy()
         mx.free()
         return out
 
     def sketch_dev(masks_by_asm, new_w):
-        return {i: sketch(ctx, genomes[i], k, new_w, bf, msk) for i, msk in masks_by_asm.items()}
+        return {i: one(i, msk, new_w, True) for i, msk in masks_by_asm.items()}
 
     os.makedirs("h")
     os.makedirs("d")
@@ -172,3 +217,5 @@ def test_device_engine_in_lockstep_with_the_reference_run(ctx, name, in_tmp_cwd)
             g.free()
         if bf is not None:
             bf.free()
+        if rep is not None:
+            rep.free()

@@ -201,7 +201,7 @@ class TracedOracle(SO.SyntenyOracle):
         return out
 
 
-def _run_traced(sc, tmp):
+def _run_traced(sc, tmp, use_repeat=True):
     fastas = sc.unpack(str(tmp))
     m = sc.meta
     k, w = m["k"], m["w"]
@@ -217,6 +217,13 @@ def _run_traced(sc, tmp):
                        interarrivals=True, simplify=sc.simplify, m=sc.m).attach(sc)
     # the instance's filter_lists is reached through the class (a staticmethod): route it through the checked version
     eng.filter_lists = eng._filter_lists_checked
+    if sc.filter_mode and use_repeat:
+        rep = sc.repeat_filter([genomes[p] for p in fastas])
+        if sc.filter_mode == "Indexlr":                               # S:172-180: the refinement rounds' indexlr runs with -r
+            eng.refine_repeat = rep
+        else:                                                        # S:184-185, S:605-607: read_minimizers(file, repeat_bf), every time
+            eng.screen_repeat = rep
+            tables = {t: SO.read_minimizers_tsv(t, repeat_bf=rep) for t in tables}
     eng.load(tables)
     err = io.StringIO()
     with contextlib.redirect_stderr(err), sc.ends_like_the_reference():
@@ -234,6 +241,13 @@ def test_oracle_in_lockstep_with_the_reference_run(name, in_tmp_cwd):
     assert eng.outputs[f"{sc.prefix}.interarrivals.tsv"] == sc.expected("interarrivals.tsv")
     assert warnings == sc.meta["warnings"]
     assert eng.seen["masked"] > 0
+
+
+@pytest.mark.parametrize("name", [n for n in refrun.scenario_names() if Scenario(n).filter_mode])
+def test_the_repeat_filter_matters_in_its_scenarios(name, in_tmp_cwd):
+    "negative control: the same run without the repeat filter leaves the reference's trace (else these scenarios prove nothing about --filter)"
+    with pytest.raises(AssertionError):
+        _run_traced(Scenario(name), in_tmp_cwd, use_repeat=False)
 
 
 def test_the_scenarios_reach_every_rule(in_tmp_cwd):

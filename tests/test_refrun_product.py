@@ -31,7 +31,20 @@ def host_engine(sc, fastas, native=True):
     genomes = [O.read_fasta(p) for p in fastas]
     bf = O.common_bf({p: g for p, g in zip(fastas, genomes)}, k, 0.025) if m.get("common", True) else None
     tsvs = [f"{os.path.basename(p)}.k{k}.w{w}.tsv" for p in fastas]
-    initial = [oracle_flat(O.minimize(g, k, w, bf)) for g in genomes]
+    # stage 3's repeat filter (ntsynt_run.py --filter, S:172-185, S:601-607) the way ntsynt_amd.pipeline hands it to the engine: `Indexlr`
+    # = the refinement sketches are made with it as filter-out; `Filter` = every list, initial and refined, is screened before the engine
+    # sees it (nts_mx_screen on the device; here the same rule on the test doubles' lists)
+    mode = getattr(sc, "filter_mode", None)
+    rep = sc.repeat_filter(genomes) if mode else None
+
+    def screened(g, flat):
+        if mode != "Filter":
+            return flat
+        h1, rec, pos = flat
+        keep = np.array([not O.bf_contains(rep, O.hash_kmer(bytes(g.record(int(r))[int(p):int(p) + k]))[0]) for r, p in zip(rec, pos)], dtype=bool)
+        return h1[keep], rec[keep], pos[keep]
+
+    initial = [screened(g, oracle_flat(O.minimize(g, k, w, bf))) for g in genomes]
 
     def sketch_fn(i, masks, new_w):
         g = genomes[i]
@@ -44,7 +57,8 @@ def host_engine(sc, fastas, native=True):
                     if e > s:
                         buf[s:e] = b"N" * (e - s)
             seqs.append(bytes(buf))
-        return oracle_flat(O.minimize(O.Genome(g.names, seqs), k, new_w, bf))
+        masked = O.Genome(g.names, seqs)
+        return screened(masked, oracle_flat(O.minimize(masked, k, new_w, bf, repeat=rep if mode == "Indexlr" else None)))
 
     eng = SyntenyEngine(tsvs, [g.names for g in genomes], k, w, m["w_rounds"], m["indel"], m["merge"], m["z"], sc.prefix,
                         build_graph_numpy, sketch_fn, walk_paths, degree_fn=edge_degrees if native else None, n=sc.min_weight,
