@@ -223,3 +223,31 @@ def test_stage3_filter_indexlr_and_filter_filter_against_the_oracle_engine(tmp_p
     r = subprocess.run([sys.executable, os.path.join(BIN, "ntsynt_run.py")] + args + ["-p", "x", "--filter", "Filter", "--repeat", "f.repeat.bf", "--initial-only"],
                        cwd=str(tmp_path), capture_output=True)
     assert r.returncode == 2 and b"not with --initial-only" in r.stderr
+
+
+def test_repeat_filter_executable_writes_the_reference_runs_bits(tmp_path):
+    """bin/ntsynt_make_repeat_bfs (nts_bf_insert_repeats) on the families of tests/golden/repeat_bf/: the bits of the file it writes are the bits
+    the reference's own bin/ntsynt_make_repeat_bfs.py left in its filter when it was run on the same arguments in the build container
+    (tests/golden/make_golden_repeat_bf.py; stand-in btllib with the restatement's filter and hash rules)."""
+    import gzip
+    import hashlib
+    import json
+    from ntsynt_amd.pipeline import read_bf
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "repeat_bf")
+    with open(os.path.join(src, "cases.json")) as fh:
+        vec = json.load(fh)
+    for f in vec["families"]["a"] + vec["families"]["b"]:
+        with gzip.open(os.path.join(src, f + ".gz")) as fi, open(tmp_path / f, "wb") as fo:
+            fo.write(fi.read())
+    done = 0
+    for case in vec["cases"]:
+        if case["end"] != "ran":
+            continue
+        out = _run([os.path.join(BIN, "ntsynt_make_repeat_bfs")] + case["argv"], str(tmp_path)).stdout.decode()
+        assert [ln for ln in out.splitlines() if ln.startswith("Calculated")] == case["stdout"], case["argv"]
+        bits, k = read_bf(str(tmp_path / case["saved"]))
+        assert k == int(case["argv"][case["argv"].index("-k") + 1])
+        assert (int(bits.size), hashlib.sha1(bits.tobytes()).hexdigest()) == (case["bytes"], case["sha1"]), case["argv"]
+        os.remove(tmp_path / case["saved"])
+        done += 1
+    assert done >= 7
