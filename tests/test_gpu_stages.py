@@ -251,3 +251,50 @@ def test_repeat_filter_executable_writes_the_reference_runs_bits(tmp_path):
         os.remove(tmp_path / case["saved"])
         done += 1
     assert done >= 7
+
+
+def test_the_snakefiles_own_command_lines_run_on_this_builds_executables(tmp_path, golden_dir):
+    """One configuration of tests/golden/smk_commands.json (the lines bin/ntsynt_run_pipeline.smk issues for `ntSynt -d 3 a.fa b.fa`, expanded
+    from the Snakefile itself in the build container) run word for word in the rule order Snakemake would take -- make_common_bf, indexlr per
+    genome, ntsynt_synteny; samtools' faidx lines are not this build's -- with <bin> = this build's bin/.  The final table against the CPU
+    restatement with the configuration's parameters."""
+    import json
+    import shlex
+    import yaml
+    with open(os.path.join(golden_dir, "smk_commands.json")) as fh:
+        runs = json.load(fh)["runs"]
+    run = next(r for r in runs if r["config"]["w_rounds"] == "250 100" and r["config"]["common"] == "True" and r["config"]["references"] == "[a.fa, b.fa]"
+               and r["config"]["prefix"] == "ntSynt.k24.w1000" and r["config"]["indel_merge"] == "50000")
+    cfg = {k: yaml.safe_load(v) for k, v in run["config"].items()}
+    paths = synth.make_family(str(tmp_path), 2, 2_500_000, 3, 0.01, seed=77, micro=6)
+    for p, name in zip(paths, cfg["references"]):
+        os.rename(p, tmp_path / name)
+    order = {"make_common_bf": 0, "indexlr": 1, "ntsynt_synteny": 2}
+    for cmd in sorted((c for c in run["commands"] if c["rule"] in order), key=lambda c: order[c["rule"]]):
+        words = shlex.split(cmd["shell"])
+        out = None
+        if ">" in words:
+            out = words[words.index(">") + 1]
+            words = words[:words.index(">")]
+        if words[0] == "python3":
+            words = words[1:]
+        words[0] = os.path.join(BIN, os.path.basename(words[0]))
+        r = subprocess.run([sys.executable] + words, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, (cmd["shell"], r.stderr.decode()[-1500:])
+        if out:
+            with open(tmp_path / out, "wb") as fh:
+                fh.write(r.stdout)
+        for f in cmd["output"]:
+            assert os.path.exists(tmp_path / f), (cmd["rule"], f)
+    cwd = os.getcwd()
+    os.makedirs(tmp_path / "ora")
+    os.chdir(tmp_path / "ora")
+    try:
+        ora = SO.run_pipeline([str(tmp_path / n) for n in cfg["references"]], k=cfg["kmer"], w=cfg["window"], fpr=cfg["fpr"],
+                              w_rounds=[int(x) for x in cfg["w_rounds"].split()], indel=cfg["indel_merge"], merge=cfg["collinear_merge"],
+                              block_size=cfg["block_size"], prefix=cfg["prefix"])
+    finally:
+        os.chdir(cwd)
+    for n in (f"{cfg['prefix']}.synteny_blocks.tsv", f"{cfg['prefix']}.pre-collinear-merge.synteny_blocks.tsv"):
+        assert open(tmp_path / n).read() == ora.outputs[n], n
+    assert len(ora.outputs[f"{cfg['prefix']}.synteny_blocks.tsv"].splitlines()) >= 4
