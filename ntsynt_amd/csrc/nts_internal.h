@@ -586,7 +586,8 @@ inline dim3 nts_checked_block(const dim3& grid, const dim3& block)
   do {                                                                                              \
     hipError_t e_ = (expr);                                                                         \
     if (e_ != hipSuccess) {                                                                         \
-      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                               \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_) +                              \
+                   (g_refused_launches.exchange(0) ? " -- a launch of more than 2^32 - 1 work-items was refused instead of run truncated (NTS_LAUNCH)" : ""); \
       return e_ == hipErrorOutOfMemory ? NTS_ENOMEM : NTS_EHIP;                                     \
     }                                                                                               \
   } while (0)

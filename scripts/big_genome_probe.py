@@ -12,8 +12,9 @@ from ntsynt_amd.device import BloomFilter, Context, Genome, bf_size_bytes, sketc
 ctx = Context(0)
 n = int(float(os.environ.get("MBP", "6000")) * 1e6)
 t = time.time()
-g0 = Genome.synth(ctx, n, 40, 20240207, 1, 0.005)
-g1 = Genome.synth(ctx, n, 40, 20240207, 2, 0.005)
+contigs = int(os.environ.get("CONTIGS", "40"))            # (1: a single record beyond 2^32 bases -- positions need their 64 bits)
+g0 = Genome.synth(ctx, n, contigs, 20240207, 1, 0.005)
+g1 = Genome.synth(ctx, n, contigs, 20240207, 2, 0.005)
 ctx.sync()
 print("synth", round(time.time() - t, 2), "s; bases", g0.total_bp, flush=True)
 _, nb = bf_size_bytes(g0.total_bp, 0.025)
@@ -24,11 +25,18 @@ bf.insert_and(g1)
 pc = bf.popcount()
 print("insert_and ok, popcount", pc, "share of bits", round(pc / (nb * 8), 5), flush=True)
 ctx.trim_bf_build()
-for w, mode in ((1000, "auto"), (1000, "dense"), (100, "auto"), (33, "auto"), (33, "dense")):
-    ctx.sketch_mode(mode)
-    t = time.time()
-    mx = sketch(ctx, g1, 24, w, bf)
-    c = len(mx)
-    ctx.sync()
-    print("w", w, mode, "minimizers", c, round((time.time() - t) * 1e3, 1), "ms", flush=True)
-    mx.free()
+import numpy as np  # noqa: E402
+for w in (1000, 100):
+    got = {}
+    for mode in ("auto", "dense"):
+        ctx.sketch_mode(mode)
+        t = time.time()
+        mx = sketch(ctx, g1, 24, w, bf)
+        c = len(mx)
+        ctx.sync()
+        dt = time.time() - t
+        got[mode] = mx.to_numpy()
+        mx.free()
+        print("w", w, mode, "minimizers", c, round(dt * 1e3, 1), "ms; largest position", int(got[mode][2].max()), flush=True)
+    print("   whole lists:", "SAME" if all(np.array_equal(a, b) for a, b in zip(got["auto"], got["dense"])) else "DIFFERENT", flush=True)
+ctx.sketch_mode("auto")

@@ -49,7 +49,7 @@ def test_a_launch_that_would_run_truncated_is_refused(monkeypatch):
     ctx = Context(0, variant="experiments")
     try:
         g = Genome.synth(ctx, 620_000_000, 24, 20240207, 2, 0.005)
-        with pytest.raises(NtsError):
+        with pytest.raises(NtsError, match="2\\^32"):
             _lists(ctx, g, 24, 16, "pruned", 1)
         # the context is usable afterwards
         monkeypatch.delenv("NTS_WIN_TILES_PER_LAUNCH")
