@@ -8,6 +8,7 @@ order and text (synteny_block.py:72-109), collinear merging (S:428-472) and the 
 (S:134-146) -- inherited from ntsynt_amd.synteny.SyntenyEngine, which stays as the host-array twin the GPU tests compare
 this engine with, state by state.  It never touches the oracle."""
 import ctypes
+import os
 import sys
 
 import numpy as np
@@ -157,6 +158,8 @@ class DeviceSyntenyEngine(SyntenyEngine):
     def _simplify_dev(self, apply_deletions):
         "run_graph_simplification (S:548-590) on the table of candidate edges and their neighbourhood (nts_bubble_rule)"
         cand, inc_e, inc_u, inc_v, inc_w = self.graph.bubbles()
+        if os.environ.get("NTS_DEBUG_ENGINE"):
+            print(f"[engine simplify] candidate edges {cand.size}, edges at their ends {inc_e.size}", file=sys.stderr, flush=True)
         if cand.size == 0:
             return
         wmax = self.G                                          # sum of the weights, all 1 (S:32, S:571)

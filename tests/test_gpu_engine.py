@@ -297,3 +297,59 @@ def test_interarrivals_from_the_device_engine(tmp_path):
     assert len(want.splitlines()) > 1000
     assert sorted(got.splitlines()) == sorted(want.splitlines())
     assert eng.outputs["p.synteny_blocks.tsv"] == ora.outputs["p.synteny_blocks.tsv"]
+
+
+def test_an_edge_that_exists_keeps_its_slot_and_takes_the_new_weight(ctx, tmp_path):
+    """nts_engine_add on a graph that holds some of the new build's edges already (ntJoin's build_graph with graph=<the running graph>, as
+    bin/ntsynt_synteny.py:476-485 calls it every refinement round): the existing edge keeps its slot and takes the new weight, the others
+    are appended.  The join of new edges against live ones runs on the device (sorted pair keys + look-up; it was a host-side dictionary
+    until dense sketches made it tens of millions of entries): here against the host-array twin, with thousands of such edges."""
+    from ntsynt_amd.device import Minimizers
+    from ntsynt_amd.graph import build_graph_device, edge_degrees, walk_paths
+    from ntsynt_amd.synteny import SyntenyEngine
+    from ntsynt_amd.synteny_device import DeviceSyntenyEngine
+    rng = np.random.default_rng(8)
+    n = 20000
+    hashes = np.unique(rng.integers(1, 1 << 40, size=2 * n, dtype=np.uint64))[:n]         # (distinct; NOT a choice out of an arange of 2^40)
+    rng.shuffle(hashes)
+    assert hashes.size == n
+    tsvs = ["a.fa.k24.w100.tsv", "b.fa.k24.w100.tsv", "c.fa.k24.w100.tsv"]
+    names = [["c1", "c2"]] * 3
+
+    def lists_of(idx, jitter):
+        out = []
+        for a in range(3):
+            h = hashes[idx]
+            pos = (np.arange(idx.size, dtype=np.uint64) * np.uint64(150) + np.uint64(1000 * a + jitter))
+            rec = (np.arange(idx.size) >= idx.size // 2).astype(np.uint32)
+            out.append((h, rec, pos))
+        return out
+
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        host = SyntenyEngine(tsvs, names, 24, 100, [20, 5], 500, 1000, 100, "p", lambda ls, kp, li: build_graph_device(ctx, ls, kp, li), None, walk_paths,
+                             degree_fn=edge_degrees)
+        dev = DeviceSyntenyEngine(ctx, tsvs, names, 24, 100, [20, 5], 500, 1000, 100, "p", None)
+        first = lists_of(np.arange(0, n // 2), 0)
+        # the second build: a third of the old chain again (its adjacent pairs are edges that exist), runs of new minimizers in between
+        again = np.sort(rng.choice(np.arange(0, n // 2), size=n // 6, replace=False))
+        take = np.sort(np.concatenate([np.arange(2000, 5000), again, np.arange(n // 2, n)]))
+        take = np.unique(take)
+        second = lists_of(take, 7)
+        for step, lists in (("first build", first), ("second build", second)):
+            ordered = [lists[i] for i in host.input_order]
+            host._add_graph(host.graph_fn(ordered, None, None))
+            handles = [Minimizers.from_numpy(ctx, *lists[i]) for i in dev.input_order]
+            dev._add(handles, None)
+            for mx in handles:
+                mx.free()
+            _state_equal(host, dev, step)
+        # the case is what it claims: edges of the second build between vertices of the first that were edges already
+        old = np.arange(n) < n // 2
+        order = np.argsort(take)
+        consecutive = np.abs(np.diff(take[order])) == 1
+        assert int((consecutive & old[take[order]][:-1] & old[take[order]][1:]).sum()) > 1000
+        dev.graph.free()
+    finally:
+        os.chdir(cwd)
