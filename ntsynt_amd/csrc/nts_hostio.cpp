@@ -788,16 +788,33 @@ extern "C" int nts_bubble_rule(uint64_t n_cand, const uint32_t* cand_edge, uint6
   if (!n_out || (n_cand && (!cand_edge || !doomed || !promoted)) || (n_inc && (!inc_edge || !inc_u || !inc_v || !inc_w))) return NTS_EINVAL;
   *n_out = 0;
   if (n_cand == 0 || n_inc == 0) return NTS_OK;
-  // vertices of the table, numbered densely
-  std::vector<uint32_t> verts;
-  verts.reserve(2 * n_inc);
-  for (uint64_t i = 0; i < n_inc; ++i) {
-    verts.push_back(inc_u[i]);
-    verts.push_back(inc_v[i]);
+  // vertices of the table, numbered densely in ascending order.  Vertex ids are indices into the engine's vertex table: a direct table
+  // id -> dense number (presence marks, then a running count) unless the ids are far sparser than the table is long -- sorting 2 n_inc ids
+  // and a binary search per end point were 20 of this function's 25 seconds on a table of 12.8 M edges (short windows on Gbp genomes:
+  // 3 M candidate edges per round).
+  std::vector<uint32_t> verts, dense;
+  uint32_t vmax = 0;
+  for (uint64_t i = 0; i < n_inc; ++i) vmax = std::max(vmax, std::max(inc_u[i], inc_v[i]));
+  const bool direct = (uint64_t)vmax < 64ull * n_inc + (1ull << 20);
+  if (direct) {
+    dense.assign((size_t)vmax + 1, 0u);
+    for (uint64_t i = 0; i < n_inc; ++i) dense[inc_u[i]] = dense[inc_v[i]] = 1u;
+    uint32_t count = 0;
+    for (size_t v = 0; v <= vmax; ++v)
+      if (dense[v]) {
+        dense[v] = count++;
+        verts.push_back((uint32_t)v);
+      }
+  } else {
+    verts.reserve(2 * n_inc);
+    for (uint64_t i = 0; i < n_inc; ++i) {
+      verts.push_back(inc_u[i]);
+      verts.push_back(inc_v[i]);
+    }
+    std::sort(verts.begin(), verts.end());
+    verts.erase(std::unique(verts.begin(), verts.end()), verts.end());
   }
-  std::sort(verts.begin(), verts.end());
-  verts.erase(std::unique(verts.begin(), verts.end()), verts.end());
-  auto vid = [&](uint32_t v) { return (uint32_t)(std::lower_bound(verts.begin(), verts.end(), v) - verts.begin()); };
+  auto vid = [&](uint32_t v) { return direct ? dense[v] : (uint32_t)(std::lower_bound(verts.begin(), verts.end(), v) - verts.begin()); };
   const size_t nv = verts.size();
   // adjacency in CSR form; a later edge between the same pair replaces the earlier one (dict assignment), which cannot happen
   // among live edges but is kept
@@ -823,8 +840,10 @@ extern "C" int nts_bubble_rule(uint64_t n_cand, const uint32_t* cand_edge, uint6
     return c;
   };
   uint64_t out = 0;
+  const uint32_t* at = inc_edge; // (both lists ascend: the look-up walks on from the candidate before)
   for (uint64_t c = 0; c < n_cand; ++c) {
-    const uint32_t* at = std::lower_bound(inc_edge, inc_edge + n_inc, cand_edge[c]);
+    if (c && cand_edge[c] < cand_edge[c - 1]) at = inc_edge; // (not ascending after all: search from the start)
+    at = std::lower_bound(at, inc_edge + n_inc, cand_edge[c]);
     if (at == inc_edge + n_inc || *at != cand_edge[c]) return NTS_EINVAL; // a candidate is incident to its own end points
     const uint64_t i = (uint64_t)(at - inc_edge);
     const uint32_t s = lu[i], t = lv[i];

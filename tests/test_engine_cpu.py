@@ -630,3 +630,27 @@ def test_a_last_round_without_blocks_ends_the_run_like_the_reference(tmp_path):
             eng.run([oracle_flat(O.minimize(g, 24, 200, bf)) for g in genomes])
     finally:
         os.chdir(cwd)
+
+
+def test_bubble_rule_numbers_its_vertices_either_way():
+    """nts_bubble_rule numbers the table's vertices through a direct id -> number table when the ids are about as dense as the table is long, through
+    a sorted list otherwise (a handful of candidates in a graph of millions): the same rule either way -- here the same table with its vertex ids
+    moved far up, which flips the choice."""
+    import ctypes
+    from ntsynt_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n_inc, n_cand, nvg = 60000, 9000, 150000
+    inc_edge = np.sort(rng.choice(np.arange(400000, dtype=np.uint32), size=n_inc, replace=False)).astype(np.uint32)
+    u = rng.integers(0, nvg, size=n_inc, dtype=np.uint32)
+    v = (u + rng.integers(1, 3, size=n_inc, dtype=np.uint32)).astype(np.uint32)
+    w = rng.integers(1, 4, size=n_inc, dtype=np.uint32)
+    cand = np.sort(rng.choice(inc_edge, size=n_cand, replace=False)).astype(np.uint32)
+    outs = []
+    for shift in (0, 3_000_000_000):
+        uu, vv = (u + np.uint32(shift)).astype(np.uint32), (v + np.uint32(shift)).astype(np.uint32)
+        doomed, promoted, n = np.empty(n_cand, np.uint32), np.empty(n_cand, np.uint32), ctypes.c_uint64()
+        assert lib.nts_bubble_rule(n_cand, cand.ctypes.data, n_inc, inc_edge.ctypes.data, uu.ctypes.data, vv.ctypes.data, w.ctypes.data, 3,
+                                   doomed.ctypes.data, promoted.ctypes.data, ctypes.byref(n)) == 0
+        outs.append(((doomed[:n.value].astype(np.int64) - shift).tolist(), promoted[:n.value].tolist()))
+    assert outs[0] == outs[1] and len(outs[0][0]) > 20
