@@ -452,22 +452,26 @@ def _exchange_lists(backend, local, n_total):
     return [merged[i] for i in range(n_total)]
 
 
-def plan_bytes(file_bytes, fpr, build_filter):
+def plan_bytes(file_bytes, fpr, build_filter, w=1000):
     """Device bytes a run over files of these sizes will have live at its peak (an upper estimate from the files alone: a base per byte,
     four per byte of a .gz): the filter (39.5 bits per base of the first file in sorted order at fpr 0.025: A1), the Bloom build's two
     bucket arrays and bypass list (12 bytes per k-mer of the largest genome), the resident genomes with their 2-bit images and tables
-    (1.3 bytes per base), sketch and graph workspaces.  3 x 3 Gbp: 63.6 GB planned, 60.2 GB measured (bench.py e2e)."""
+    (1.3 bytes per base), sketch and graph workspaces (growing with the sketch density 2 / (w + 1)).  3 x 3 Gbp at w = 1000: 66.5 GB planned, 60.2 GB
+    measured (bench.py e2e)."""
     import math
     if not file_bytes:
         return 0
     n0, n_max, total = file_bytes[0], max(file_bytes), sum(file_bytes)
     plan = 1.3 * total + (2 << 30)
+    # the lists and the graph build grow with the sketch's density: ~2 / (w + 1) minimizers per base, ~100 bytes each through nts_engine_add's
+    # input columns, sort buffers and vertex tables (nothing to speak of at the default w = 1000; 9 GB for 3 x 1 Gbp at w = 64)
+    plan += 100.0 * total * 2.0 / (max(int(w), 1) + 1)
     if build_filter:
         plan += math.ceil(-n0 / math.log(1 - fpr)) / 8 + 12 * n_max
     return int(plan)
 
 
-def reserve_for_run(ctx, fastas, fpr, build_filter, log=None):
+def reserve_for_run(ctx, fastas, fpr, build_filter, log=None, w=1000):
     """nts_mem_reserve of what plan_bytes says, less what the process's allocation cache already holds, started on a thread of its own;
     returns an object whose join() gives the bytes reserved (0: nothing asked, or the driver refused -- the run then allocates as it goes)"""
     class _Nothing:
@@ -482,7 +486,7 @@ def reserve_for_run(ctx, fastas, fpr, build_filter, log=None):
         except OSError:
             return _Nothing()
         sizes.append(sz * 4 if p.endswith(".gz") else sz)
-    want = plan_bytes(sizes, fpr, build_filter) - ctx.mem_cache_stats()[0]
+    want = plan_bytes(sizes, fpr, build_filter, w) - ctx.mem_cache_stats()[0]
     if want < (256 << 20):                                      # small runs: the driver's latency is not what they wait for
         return _Nothing()
     return ctx.mem_reserve_async(want)
@@ -551,7 +555,7 @@ def run(fastas, k=24, w=1000, fpr=0.025, prefix=None, w_rounds=(100, 10), indel=
         # On a thread of its own: memory the GPU has not handed out since the driver came up costs 7-20 ms per GB on the boxes this
         # build ran on (0.5 s for a 3 x 3 Gbp run's 65 GB; scripts/malloc_probe.py, bench.py `allocator`), time the first file's ingest
         # can share.  Joined before the filter is allocated.
-        reserving.append(reserve_for_run(backend.ctx, fastas if world == 1 else mine, fpr, common and common_file is None, log))
+        reserving.append(reserve_for_run(backend.ctx, fastas if world == 1 else mine, fpr, common and common_file is None, log, w=w))
     # limits of this implementation, checked before anything is written (the reference has none of them)
     for ww in [w] + list(w_rounds):
         if not 1 <= int(ww) <= MAX_W:
