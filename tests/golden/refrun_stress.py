@@ -40,8 +40,21 @@ def oracle_outputs(sc, fastas):
                 tsv = f"{os.path.basename(p)}.k{k}.w{w}.tsv"
                 tables[tsv] = SO.mx_tables_from_tokens(SO.mx_records_from_arrays(genomes[p].names, O.minimize(genomes[p], k, w, bf)))
                 by_tsv[tsv] = genomes[p]
+            if sc.get("filter"):
+                rep = O.repeat_bf([genomes[p] for p in fastas], k, int(bf.size))          # (sized like the common filter, as make_golden_refrun.py does)
+                if sc["filter"] == "Filter":
+                    import tempfile as _tf
+                    with _tf.TemporaryDirectory() as td:
+                        for p in fastas:
+                            tsv = f"{os.path.basename(p)}.k{k}.w{w}.tsv"
+                            O.write_indexlr_tsv(os.path.join(td, tsv), genomes[p], O.minimize(genomes[p], k, w, bf), k)
+                            tables[tsv] = SO.read_minimizers_tsv(os.path.join(td, tsv), repeat_bf=rep)
             eng = SO.SyntenyOracle(list(tables), by_tsv, k, w, sc["w_rounds"], sc["indel"], sc["merge"], sc["z"], "ora", bf=bf,
                                    n=sc.get("min_weight", 0), interarrivals=True, simplify=sc.get("simplify", True), m=sc.get("m", 90))
+            if sc.get("filter") == "Indexlr":
+                eng.refine_repeat = rep
+            elif sc.get("filter") == "Filter":
+                eng.screen_repeat = rep
             eng.load(tables)
             eng.main()
     finally:
@@ -58,6 +71,12 @@ class _Shim:
         self.min_weight = sc.get("min_weight", 0)
         self.simplify = sc.get("simplify", True)
         self.m = sc.get("m", 90)
+        self.filter_mode = sc.get("filter")
+
+    def repeat_filter(self, genomes):
+        from oracle import nts_oracle as O
+        common = O.common_bf({i: g for i, g in enumerate(genomes)}, self.meta["k"], 0.025)
+        return O.repeat_bf(genomes, self.meta["k"], int(common.size))
 
 
 def product_outputs(sc, fastas):
@@ -99,6 +118,9 @@ def main():
         if rng.random() < 0.2:                                      # ntSynt --no-simplify-graph
             sc["simplify"] = False
             seen["no_simplify"] = seen.get("no_simplify", 0) + 1
+        if rng.random() < 0.15 and sc.get("common", True):          # ntsynt_run.py --filter Indexlr | Filter --repeat <bf>
+            sc["filter"] = rng.choice(["Indexlr", "Filter"])
+            seen["repeat_filter"] = seen.get("repeat_filter", 0) + 1
         if rng.random() < 0.3:                                      # ntsynt_run.py -m
             sc["m"] = rng.choice([100, 75, 60, 51])
             seen["m_not_90"] = seen.get("m_not_90", 0) + 1
@@ -115,6 +137,9 @@ def main():
                 os.chdir(tmp)
                 fastas = []
                 import gzip
+                if outputs is None and sc.get("filter"):
+                    stopped += 1                                           # (its files carried a repeated stretch the generator put in: not made again)
+                    continue
                 if outputs is None:                                        # (the scenario's files were not kept: make the family again)
                     from ntsynt_amd import synth
                     fastas = synth.make_family(tmp, sc["n"], sc["bp"], sc["ctg"], sc["div"], seed=sc["seed"], n_runs=sc["n_runs"], micro=sc["micro"], line_width=0)
